@@ -1,0 +1,121 @@
+/*
+ * mosfhet_oracle.h -- CPU ORACLE for the TFHE programmable-bootstrap hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the smoke check in
+ * __graft_entry__.py and bench.py's cpu_baseline leg may load it.  The shipped
+ * library (mosfhet_amd/csrc) never links, imports or calls anything in oracle/.
+ *
+ * What it is: a plain-C restatement of the algorithms of antoniocgj/MOSFHET on the
+ * path  programmable_bootstrap -> functional_bootstrap -> blind_rotate ->
+ * trgsw_mul_trlwe_DFT -> sample extract -> tlwe_keyswitch, over flat buffers.
+ * Every function cites the reference file:line it follows.
+ *
+ * Parity status: PINNED.  The integer functions are checked bit-for-bit and the
+ * floating-point ones within the reference's own tolerances against
+ *   (a) the reference itself, compiled from /root/reference by oracle/ref/Makefile
+ *       into oracle/_ref/ (FFNT pure-C and AVX-512 SPQLIOS builds), and
+ *   (b) the golden vectors in tests/golden/ that were produced by that build
+ *       (tests/golden/make_golden.py),
+ * see tests/test_oracle_vs_reference.py and tests/test_oracle_golden.py.
+ *
+ * Floating point: the reference has three interchangeable FFT back-ends whose
+ * results differ in the low ~26-30 bits.  The oracle's
+ * negacyclic transform computes the same mathematical map (evaluation of the
+ * folded polynomial at the roots of X^N = -1, "Torus -> DFT" of
+ * src/fft/ffnt/ffnt.c:235-271,820-831) with one fixed, documented operation order
+ * (oracle_fft.c).  The HIP kernels use exactly that order, so GPU-vs-oracle
+ * comparisons are bit-exact even across a full n-step blind rotation, while
+ * oracle-vs-reference comparisons use the reference's tolerances.
+ *
+ * Flat layouts (W = 64, Torus = uint64_t, all arithmetic mod 2^64):
+ *   TLWE(n)            u64[n+1]                 a[0..n-1], b           (mosfhet.h:51-54)
+ *   TRLWE(k,N)         u64[k+1][N]              a[0..k-1], b           (mosfhet.h:73-76)
+ *   TRGSW(k,N,l)       u64[(k+1)l][k+1][N]      row p*l+j              (mosfhet.h:106-109, trgsw.c:152-168)
+ *   bootstrap key      u64[n][(k+1)l][k+1][N]   torus domain           (bootstrap.c:14-18 before trgsw_to_DFT)
+ *   LWE KS key         u64[n_in][t][2^bb-1][n_out+1]                   (tlwe.c:193-212)
+ *   DFT polynomial     double[N]  = N/2 complex, interleaved (re,im), oracle slot order
+ */
+#ifndef MOSFHET_ORACLE_H
+#define MOSFHET_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint64_t Torus;
+
+/* ---- scalars (src/misc.c:13-28) ---- */
+Torus    orc_double2torus(double x);
+uint64_t orc_torus2int(Torus x, int log_scale);
+Torus    orc_int2torus(uint64_t x, int log_scale);
+
+/* ---- integer polynomial ops ---- */
+void orc_poly_decompose_i(Torus *out, const Torus *in, int N, int Bg_bit, int l, int i);       /* polynomial.c:74-89 */
+void orc_poly_decompose(Torus *out /*[l][N]*/, const Torus *in, int N, int Bg_bit, int l);     /* polynomial.c:55-72 */
+void orc_poly_mul_by_xai(Torus *out, const Torus *in, int N, int a);                           /* polynomial.c:184-199 */
+void orc_poly_mul_by_xai_addto(Torus *out, const Torus *in, int N, int a);                     /* polynomial.c:202-217 */
+void orc_poly_mul_by_xai_minus_1(Torus *out, const Torus *in, int N, int a);                   /* polynomial.c:220-235 */
+void orc_poly_naive_mul(Torus *out, const Torus *in1, const Torus *in2, int N);                /* polynomial.c:290-303 */
+void orc_poly_naive_mul_addto(Torus *out, const Torus *in1, const Torus *in2, int N);          /* polynomial.c:264-274 */
+void orc_poly_permute(Torus *out, const Torus *in, int N, uint64_t gen);                       /* polynomial.c:442-450 */
+void orc_trlwe_extract_tlwe(Torus *out, const Torus *in, int k, int N, int idx);               /* trlwe.c:540-552 */
+void orc_trlwe_torus_packing(Torus *out, const Torus *lut, int k, int N, int size);            /* trlwe.c:662-667 */
+void orc_tlwe_keyswitch(Torus *out, const Torus *in, const Torus *ksk,
+                        int n_in, int n_out, int t, int base_bit);                             /* tlwe.c:289-303 */
+Torus orc_tlwe_phase(const Torus *c, const Torus *s, int n);                                   /* tlwe.c:135-141 */
+void orc_trlwe_phase(Torus *out, const Torus *c, const Torus *s /*[k][N]*/, int k, int N);     /* trlwe.c:324-331 (exact, naive product) */
+void orc_pbs_preprocess(Torus *out, const Torus *in, int n, int N, int kappa, int theta);      /* bootstrap.c:208-217 */
+
+/* ---- negacyclic transform (oracle_fft.c) ---- */
+typedef struct orc_fft_plan orc_fft_plan;        /* twiddles for one N */
+orc_fft_plan *orc_fft_plan_new(int N);
+void orc_fft_plan_free(orc_fft_plan *p);
+const double *orc_fft_twiddles(const orc_fft_plan *p, int *count_complex); /* (re,im) pairs, level-major */
+/* the table generator itself, so the product's table can be compared with it */
+void orc_fft_make_twiddles(double *out /*[2*(N/2-1)]*/, int N);
+
+void orc_torus_to_dft(const orc_fft_plan *p, double *out /*[N]*/, const Torus *in);   /* polynomial.c:368-375 -> execute_reverse_torus64 */
+void orc_int_to_dft(const orc_fft_plan *p, double *out, const int64_t *in);          /* same, input already signed small ints */
+void orc_dft_to_torus(const orc_fft_plan *p, Torus *out, const double *in);           /* polynomial.c:359-366 -> execute_direct_torus64 (AVX-512 rounding, fft_processor_spqlios.c:155-165) */
+void orc_dft_mul(double *out, const double *a, const double *b, int N);               /* polynomial.c:379-401 */
+void orc_dft_mul_addto(double *out, const double *a, const double *b, int N);         /* polynomial.c:406-426 */
+void orc_poly_mul_fft(const orc_fft_plan *p, Torus *out, const Torus *a, const Torus *b); /* polynomial.c:276-288 */
+
+/* ---- TRGSW / bootstrap ---- */
+void orc_trgsw_to_dft(const orc_fft_plan *p, double *out /*[(k+1)l][k+1][N]*/,
+                      const Torus *in, int k, int l);                                 /* trgsw.c:345-349 */
+void orc_trgsw_mul_trlwe_dft(const orc_fft_plan *p, double *out_dft /*[k+1][N]*/, const Torus *in /*[k+1][N]*/,
+                             const double *trgsw_dft, int k, int l, int Bg_bit);       /* trgsw.c:385-423 */
+void orc_external_product(const orc_fft_plan *p, Torus *out, const Torus *in,
+                          const double *trgsw_dft, int k, int l, int Bg_bit);          /* trgsw.c:385 + trlwe.c:629 */
+void orc_blind_rotate(const orc_fft_plan *p, Torus *acc /*[k+1][N] in place*/, const Torus *a,
+                      const double *bk_dft /*[n][(k+1)l][k+1][N]*/, int n, int k, int l, int Bg_bit); /* bootstrap.c:107-122 */
+void orc_functional_bootstrap_wo_extract(const orc_fft_plan *p, Torus *out /*[k+1][N]*/, const Torus *tv,
+                      const Torus *in /*[n+1]*/, const double *bk_dft, int n, int k, int l, int Bg_bit,
+                      int torus_base);                                                 /* bootstrap.c:192-198 */
+void orc_functional_bootstrap(const orc_fft_plan *p, Torus *out /*[kN+1]*/, const Torus *tv, const Torus *in,
+                      const double *bk_dft, int n, int k, int l, int Bg_bit, int torus_base); /* bootstrap.c:200-206 */
+void orc_programmable_bootstrap(const orc_fft_plan *p, Torus *out, const Torus *tv, const Torus *in,
+                      const double *bk_dft, int n, int k, int l, int Bg_bit,
+                      int precision, int kappa, int theta);                            /* bootstrap.c:208-220 */
+
+/* ---- deterministic test-input generation (own code; the reference's RNG is RDRAND-seeded
+ *      and not reproducible, src/misc.c:34-49) ---- */
+typedef struct { uint64_t s; } orc_rng;
+uint64_t orc_rng_next(orc_rng *r);                       /* splitmix64 */
+double   orc_rng_normal(orc_rng *r, double sigma);       /* Box-Muller as misc.c:87-91 */
+void orc_gen_binary_key(orc_rng *r, Torus *s, int n);    /* tlwe.c:70-82 with bound 2 */
+void orc_tlwe_sample(orc_rng *r, Torus *out, Torus m, const Torus *s, int n, double sigma);            /* tlwe.c:106-115 */
+void orc_trlwe_sample(orc_rng *r, Torus *out, const Torus *m, const Torus *s, int k, int N, double sigma); /* trlwe.c:296-316 (binary key) */
+void orc_trgsw_monomial_sample(orc_rng *r, Torus *out, int64_t m, int e, const Torus *s,
+                               int k, int N, int l, int Bg_bit, double sigma);         /* trgsw.c:152-168 */
+void orc_gen_bootstrap_key(orc_rng *r, Torus *bk /*[n][(k+1)l][k+1][N]*/, const Torus *lwe_s, int n,
+                           const Torus *rlwe_s, int k, int N, int l, int Bg_bit, double sigma); /* bootstrap.c:14-18 */
+void orc_gen_tlwe_ks_key(orc_rng *r, Torus *ksk, const Torus *s_in, int n_in, const Torus *s_out, int n_out,
+                         int t, int base_bit, double sigma);                           /* tlwe.c:193-212 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

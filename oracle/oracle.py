@@ -1,0 +1,327 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by the mosfhet_amd package.
+All arrays are numpy uint64 / float64, C-contiguous, in the flat layouts of
+mosfhet_oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+U64P = C.POINTER(C.c_uint64)
+F64P = C.POINTER(C.c_double)
+
+
+def build(force=False):
+    """Compile liboracle.so with gcc (building the checker is not using it)."""
+    if force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+        for f in ("oracle_int.c", "oracle_fft.c", "oracle_tfhe.c", "mosfhet_oracle.h")
+    ):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_fft_plan_new.restype = C.c_void_p
+        _lib.orc_fft_plan_new.argtypes = [C.c_int]
+        _lib.orc_fft_plan_free.argtypes = [C.c_void_p]
+        _lib.orc_torus2int.restype = C.c_uint64
+        _lib.orc_torus2int.argtypes = [C.c_uint64, C.c_int]
+        _lib.orc_double2torus.restype = C.c_uint64
+        _lib.orc_double2torus.argtypes = [C.c_double]
+        _lib.orc_tlwe_phase.restype = C.c_uint64
+        _lib.orc_rng_next.restype = C.c_uint64
+    return _lib
+
+
+def _u(a):
+    assert a.dtype == np.uint64 and a.flags.c_contiguous, (a.dtype, a.flags)
+    return a.ctypes.data_as(U64P)
+
+
+def _d(a):
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    return a.ctypes.data_as(F64P)
+
+
+def u64(x):
+    return np.ascontiguousarray(x, dtype=np.uint64)
+
+
+class Plan:
+    """Twiddle plan for ring degree N (orc_fft_plan)."""
+
+    def __init__(self, N):
+        self.N = N
+        self.h = C.c_void_p(lib().orc_fft_plan_new(N))
+
+    def __del__(self):
+        try:
+            lib().orc_fft_plan_free(self.h)
+        except Exception:
+            pass
+
+    def twiddles(self):
+        out = np.zeros(2 * (self.N // 2 - 1), dtype=np.float64)
+        lib().orc_fft_make_twiddles(_d(out), C.c_int(self.N))
+        return out
+
+
+_plans = {}
+
+
+def plan(N):
+    if N not in _plans:
+        _plans[N] = Plan(N)
+    return _plans[N]
+
+
+class Rng:
+    def __init__(self, seed):
+        self.s = C.c_uint64(seed)
+
+    def ref(self):
+        return C.byref(self.s)
+
+    def next(self):
+        return lib().orc_rng_next(self.ref())
+
+    def words(self, n):
+        return np.array([self.next() for _ in range(n)], dtype=np.uint64)
+
+
+# ---------------- scalars ----------------
+def torus2int(x, log_scale):
+    return lib().orc_torus2int(C.c_uint64(int(x)), log_scale)
+
+
+def double2torus(x):
+    return lib().orc_double2torus(C.c_double(x))
+
+
+# ---------------- integer polynomial ops ----------------
+def poly_decompose_i(p, Bg_bit, l, i):
+    out = np.empty_like(p)
+    lib().orc_poly_decompose_i(_u(out), _u(p), C.c_int(p.size), Bg_bit, l, i)
+    return out
+
+
+def poly_decompose(p, Bg_bit, l):
+    out = np.empty((l, p.size), dtype=np.uint64)
+    lib().orc_poly_decompose(_u(out), _u(p), C.c_int(p.size), Bg_bit, l)
+    return out
+
+
+def poly_mul_by_xai(p, a):
+    out = np.empty_like(p)
+    lib().orc_poly_mul_by_xai(_u(out), _u(p), C.c_int(p.size), C.c_int(a))
+    return out
+
+
+def poly_mul_by_xai_addto(acc, p, a):
+    out = acc.copy()
+    lib().orc_poly_mul_by_xai_addto(_u(out), _u(p), C.c_int(p.size), C.c_int(a))
+    return out
+
+
+def poly_mul_by_xai_minus_1(p, a):
+    out = np.empty_like(p)
+    lib().orc_poly_mul_by_xai_minus_1(_u(out), _u(p), C.c_int(p.size), C.c_int(a))
+    return out
+
+
+def poly_naive_mul(a, b):
+    out = np.empty_like(a)
+    lib().orc_poly_naive_mul(_u(out), _u(a), _u(b), C.c_int(a.size))
+    return out
+
+
+def poly_permute(p, gen):
+    out = np.empty_like(p)
+    lib().orc_poly_permute(_u(out), _u(p), C.c_int(p.size), C.c_uint64(gen))
+    return out
+
+
+def trlwe_extract_tlwe(c, idx):
+    k1, N = c.shape
+    out = np.empty((k1 - 1) * N + 1, dtype=np.uint64)
+    lib().orc_trlwe_extract_tlwe(_u(out), _u(c), k1 - 1, N, idx)
+    return out
+
+
+def trlwe_torus_packing(lut, k, N):
+    out = np.empty((k + 1, N), dtype=np.uint64)
+    lib().orc_trlwe_torus_packing(_u(out), _u(u64(lut)), k, N, len(lut))
+    return out
+
+
+def tlwe_keyswitch(c, ksk, n_out, t, base_bit):
+    n_in = c.size - 1
+    out = np.empty(n_out + 1, dtype=np.uint64)
+    lib().orc_tlwe_keyswitch(_u(out), _u(c), _u(ksk), n_in, n_out, t, base_bit)
+    return out
+
+
+def tlwe_phase(c, s):
+    return lib().orc_tlwe_phase(_u(c), _u(s), C.c_int(s.size))
+
+
+def trlwe_phase(c, s):
+    k1, N = c.shape
+    out = np.empty(N, dtype=np.uint64)
+    lib().orc_trlwe_phase(_u(out), _u(c), _u(s), k1 - 1, N)
+    return out
+
+
+def pbs_preprocess(c, N, kappa, theta):
+    out = np.empty_like(c)
+    lib().orc_pbs_preprocess(_u(out), _u(c), C.c_int(c.size - 1), N, kappa, theta)
+    return out
+
+
+# ---------------- transform ----------------
+def torus_to_dft(p):
+    out = np.empty(p.size, dtype=np.float64)
+    lib().orc_torus_to_dft(plan(p.size).h, _d(out), _u(p))
+    return out
+
+
+def dft_to_torus(f):
+    out = np.empty(f.size, dtype=np.uint64)
+    lib().orc_dft_to_torus(plan(f.size).h, _u(out), _d(f))
+    return out
+
+
+def dft_mul(a, b):
+    out = np.empty_like(a)
+    lib().orc_dft_mul(_d(out), _d(a), _d(b), C.c_int(a.size))
+    return out
+
+
+def dft_mul_addto(acc, a, b):
+    out = acc.copy()
+    lib().orc_dft_mul_addto(_d(out), _d(a), _d(b), C.c_int(a.size))
+    return out
+
+
+def poly_mul_fft(a, b):
+    out = np.empty_like(a)
+    lib().orc_poly_mul_fft(plan(a.size).h, _u(out), _u(a), _u(b))
+    return out
+
+
+# ---------------- TRGSW / bootstrap ----------------
+def trgsw_to_dft(g, k, l):
+    N = g.shape[-1]
+    out = np.empty(g.shape, dtype=np.float64)
+    lib().orc_trgsw_to_dft(plan(N).h, _d(out), _u(g), k, l)
+    return out
+
+
+def bk_to_dft(bk, k, l):
+    """bk: u64[n][(k+1)l][k+1][N] -> float64 same shape (oracle slot order)."""
+    out = np.empty(bk.shape, dtype=np.float64)
+    for i in range(bk.shape[0]):
+        out[i] = trgsw_to_dft(bk[i], k, l)
+    return out
+
+
+def external_product(c, g_dft, l, Bg_bit):
+    k1, N = c.shape
+    out = np.empty_like(c)
+    lib().orc_external_product(plan(N).h, _u(out), _u(c), _d(g_dft), k1 - 1, l, Bg_bit)
+    return out
+
+
+def blind_rotate(acc, a, bk_dft, l, Bg_bit):
+    k1, N = acc.shape
+    out = acc.copy()
+    lib().orc_blind_rotate(plan(N).h, _u(out), _u(a), _d(bk_dft), C.c_int(a.size), k1 - 1, l, Bg_bit)
+    return out
+
+
+def functional_bootstrap_wo_extract(tv, c, bk_dft, l, Bg_bit, torus_base):
+    k1, N = tv.shape
+    out = np.empty_like(tv)
+    lib().orc_functional_bootstrap_wo_extract(plan(N).h, _u(out), _u(tv), _u(c), _d(bk_dft),
+                                              C.c_int(c.size - 1), k1 - 1, l, Bg_bit, torus_base)
+    return out
+
+
+def functional_bootstrap(tv, c, bk_dft, l, Bg_bit, torus_base):
+    k1, N = tv.shape
+    out = np.empty((k1 - 1) * N + 1, dtype=np.uint64)
+    lib().orc_functional_bootstrap(plan(N).h, _u(out), _u(tv), _u(c), _d(bk_dft),
+                                   C.c_int(c.size - 1), k1 - 1, l, Bg_bit, torus_base)
+    return out
+
+
+def programmable_bootstrap(tv, c, bk_dft, l, Bg_bit, precision, kappa, theta):
+    k1, N = tv.shape
+    out = np.empty((k1 - 1) * N + 1, dtype=np.uint64)
+    lib().orc_programmable_bootstrap(plan(N).h, _u(out), _u(tv), _u(c), _d(bk_dft),
+                                     C.c_int(c.size - 1), k1 - 1, l, Bg_bit, precision, kappa, theta)
+    return out
+
+
+# ---------------- deterministic inputs ----------------
+def gen_binary_key(rng, n):
+    s = np.empty(n, dtype=np.uint64)
+    lib().orc_gen_binary_key(rng.ref(), _u(s), n)
+    return s
+
+
+def tlwe_sample(rng, m, s, sigma):
+    out = np.empty(s.size + 1, dtype=np.uint64)
+    lib().orc_tlwe_sample(rng.ref(), _u(out), C.c_uint64(int(m) & (2**64 - 1)), _u(s), C.c_int(s.size),
+                          C.c_double(sigma))
+    return out
+
+
+def trlwe_sample(rng, m, s, sigma):
+    k, N = s.shape
+    out = np.empty((k + 1, N), dtype=np.uint64)
+    mp = _u(m) if m is not None else None
+    lib().orc_trlwe_sample(rng.ref(), _u(out), mp, _u(s), k, N, C.c_double(sigma))
+    return out
+
+
+def trgsw_monomial_sample(rng, m, e, s, l, Bg_bit, sigma):
+    k, N = s.shape
+    out = np.empty(((k + 1) * l, k + 1, N), dtype=np.uint64)
+    lib().orc_trgsw_monomial_sample(rng.ref(), _u(out), C.c_int64(m), e, _u(s), k, N, l, Bg_bit,
+                                    C.c_double(sigma))
+    return out
+
+
+def gen_bootstrap_key(rng, lwe_s, rlwe_s, l, Bg_bit, sigma):
+    k, N = rlwe_s.shape
+    n = lwe_s.size
+    bk = np.empty((n, (k + 1) * l, k + 1, N), dtype=np.uint64)
+    lib().orc_gen_bootstrap_key(rng.ref(), _u(bk), _u(lwe_s), n, _u(rlwe_s), k, N, l, Bg_bit, C.c_double(sigma))
+    return bk
+
+
+def gen_tlwe_ks_key(rng, s_in, s_out, t, base_bit, sigma):
+    ksk = np.empty((s_in.size, t, (1 << base_bit) - 1, s_out.size + 1), dtype=np.uint64)
+    lib().orc_gen_tlwe_ks_key(rng.ref(), _u(ksk), _u(s_in), C.c_int(s_in.size), _u(s_out), C.c_int(s_out.size),
+                              t, base_bit, C.c_double(sigma))
+    return ksk
+
+
+def torus_dist(a, b):
+    """|(int64)(a - b)| -- the wrap-aware torus distance."""
+    d = (np.asarray(a, dtype=np.uint64) - np.asarray(b, dtype=np.uint64)).astype(np.int64)
+    return np.abs(d.astype(np.float64))

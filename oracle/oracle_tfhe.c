@@ -1,0 +1,197 @@
+/*
+ * oracle_tfhe.c -- TRGSW external product, blind rotation, functional / programmable
+ * bootstrap, plus deterministic key and sample generation for the tests.
+ * TEST INFRASTRUCTURE ONLY (see mosfhet_oracle.h).
+ */
+#include "mosfhet_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define W 64
+
+/* src/trgsw.c:345-349  trgsw_to_DFT: every polynomial of every row */
+void orc_trgsw_to_dft(const orc_fft_plan *p, double *out, const Torus *in, int k, int l) {
+  int cnt = 0;
+  (void)orc_fft_twiddles(p, &cnt);
+  const int N = 2 * (cnt + 1);
+  const size_t polys = (size_t)(k + 1) * l * (k + 1);
+  for (size_t q = 0; q < polys; q++) orc_torus_to_dft(p, out + q * N, in + q * N);
+}
+
+/* src/trgsw.c:385-423  trgsw_mul_trlwe_DFT.
+ * out_DFT[c] = sum_{p<=k} sum_{j<l} DFT(digit_j(in[p])) (.) row[p*l+j][c], rows of a[0] first, b last,
+ * levels in increasing j, accumulated in that order (first product, then mul-add). */
+void orc_trgsw_mul_trlwe_dft(const orc_fft_plan *p, double *out_dft, const Torus *in,
+                             const double *trgsw_dft, int k, int l, int Bg_bit) {
+  int cnt = 0;
+  (void)orc_fft_twiddles(p, &cnt);
+  const int N = 2 * (cnt + 1);
+  Torus *dec = (Torus *)malloc(sizeof(Torus) * (size_t)N);
+  double *dec_dft = (double *)malloc(sizeof(double) * (size_t)N);
+  memset(out_dft, 0, sizeof(double) * (size_t)(k + 1) * N);
+  for (int q = 0; q <= k; q++) {
+    for (int j = 0; j < l; j++) {
+      orc_poly_decompose_i(dec, in + (size_t)q * N, N, Bg_bit, l, j);
+      orc_int_to_dft(p, dec_dft, (const int64_t *)dec);
+      const double *row = trgsw_dft + (size_t)(q * l + j) * (k + 1) * N;
+      for (int c = 0; c <= k; c++) orc_dft_mul_addto(out_dft + (size_t)c * N, dec_dft, row + (size_t)c * N, N);
+    }
+  }
+  free(dec);
+  free(dec_dft);
+}
+
+/* trgsw_mul_trlwe_DFT followed by trlwe_from_DFT (src/trlwe.c:629-634) */
+void orc_external_product(const orc_fft_plan *p, Torus *out, const Torus *in,
+                          const double *trgsw_dft, int k, int l, int Bg_bit) {
+  int cnt = 0;
+  (void)orc_fft_twiddles(p, &cnt);
+  const int N = 2 * (cnt + 1);
+  double *tmp = (double *)malloc(sizeof(double) * (size_t)(k + 1) * N);
+  orc_trgsw_mul_trlwe_dft(p, tmp, in, trgsw_dft, k, l, Bg_bit);
+  for (int c = 0; c <= k; c++) orc_dft_to_torus(p, out + (size_t)c * N, tmp + (size_t)c * N);
+  free(tmp);
+}
+
+static int log2_int(int x) {
+  int r = 0;
+  while ((1 << r) < x) r++;
+  return r;
+}
+
+/* src/bootstrap.c:107-122  blind_rotate: acc += BK_i (.) (acc * (X^a_i - 1)), skipping a_i == 0 */
+void orc_blind_rotate(const orc_fft_plan *p, Torus *acc, const Torus *a, const double *bk_dft,
+                      int n, int k, int l, int Bg_bit) {
+  int cnt = 0;
+  (void)orc_fft_twiddles(p, &cnt);
+  const int N = 2 * (cnt + 1), log_2N = log2_int(2 * N);
+  const size_t trgsw_sz = (size_t)(k + 1) * l * (k + 1) * N;
+  Torus *rot = (Torus *)malloc(sizeof(Torus) * (size_t)(k + 1) * N);
+  Torus *prod = (Torus *)malloc(sizeof(Torus) * (size_t)(k + 1) * N);
+  for (int i = 0; i < n; i++) {
+    const int ai = (int)orc_torus2int(a[i], log_2N);
+    if (!ai) continue;
+    for (int c = 0; c <= k; c++) orc_poly_mul_by_xai_minus_1(rot + (size_t)c * N, acc + (size_t)c * N, N, ai);
+    orc_external_product(p, prod, rot, bk_dft + (size_t)i * trgsw_sz, k, l, Bg_bit);
+    for (size_t c = 0; c < (size_t)(k + 1) * N; c++) acc[c] += prod[c];
+  }
+  free(rot);
+  free(prod);
+}
+
+/* src/bootstrap.c:192-198 */
+void orc_functional_bootstrap_wo_extract(const orc_fft_plan *p, Torus *out, const Torus *tv, const Torus *in,
+                                         const double *bk_dft, int n, int k, int l, int Bg_bit, int torus_base) {
+  int cnt = 0;
+  (void)orc_fft_twiddles(p, &cnt);
+  const int N = 2 * (cnt + 1), log_2N = log2_int(2 * N);
+  const Torus prec_offset = orc_double2torus(1. / (4 * torus_base));
+  const int rot = 2 * N - (int)orc_torus2int(in[n] + prec_offset, log_2N);
+  for (int c = 0; c <= k; c++) orc_poly_mul_by_xai(out + (size_t)c * N, tv + (size_t)c * N, N, rot);
+  orc_blind_rotate(p, out, in, bk_dft, n, k, l, Bg_bit);
+}
+
+/* src/bootstrap.c:200-206 */
+void orc_functional_bootstrap(const orc_fft_plan *p, Torus *out, const Torus *tv, const Torus *in,
+                              const double *bk_dft, int n, int k, int l, int Bg_bit, int torus_base) {
+  int cnt = 0;
+  (void)orc_fft_twiddles(p, &cnt);
+  const int N = 2 * (cnt + 1);
+  Torus *acc = (Torus *)malloc(sizeof(Torus) * (size_t)(k + 1) * N);
+  orc_functional_bootstrap_wo_extract(p, acc, tv, in, bk_dft, n, k, l, Bg_bit, torus_base);
+  orc_trlwe_extract_tlwe(out, acc, k, N, 0);
+  free(acc);
+}
+
+/* src/bootstrap.c:208-220 */
+void orc_programmable_bootstrap(const orc_fft_plan *p, Torus *out, const Torus *tv, const Torus *in,
+                                const double *bk_dft, int n, int k, int l, int Bg_bit,
+                                int precision, int kappa, int theta) {
+  int cnt = 0;
+  (void)orc_fft_twiddles(p, &cnt);
+  const int N = 2 * (cnt + 1);
+  Torus *tmp = (Torus *)malloc(sizeof(Torus) * (size_t)(n + 1));
+  orc_pbs_preprocess(tmp, in, n, N, kappa, theta);
+  orc_functional_bootstrap(p, out, tv, tmp, bk_dft, n, k, l, Bg_bit, 1 << (precision - 1));
+  free(tmp);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Deterministic inputs.  The reference seeds from RDRAND / urandom (src/misc.c:34-49) and is not
+ * reproducible, so tests draw keys and samples from splitmix64 with the same distributions.
+ * ------------------------------------------------------------------------------------------ */
+uint64_t orc_rng_next(orc_rng *r) {
+  uint64_t z = (r->s += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+/* src/misc.c:87-91  Box-Muller on two uniform torus values (shifted off zero) */
+double orc_rng_normal(orc_rng *r, double sigma) {
+  const double u1 = ((double)(orc_rng_next(r) >> 11) + 0.5) * 0x1p-53;
+  const double u2 = ((double)(orc_rng_next(r) >> 11) + 0.5) * 0x1p-53;
+  return cos(2. * M_PI * u1) * sqrt(-2. * log(u2)) * sigma;
+}
+
+/* src/tlwe.c:70-82 with bound = 2: s = r & 1 */
+void orc_gen_binary_key(orc_rng *r, Torus *s, int n) {
+  for (int i = 0; i < n; i++) s[i] = orc_rng_next(r) & 1;
+}
+
+/* src/tlwe.c:106-115  b = <a,s> + m + e */
+void orc_tlwe_sample(orc_rng *r, Torus *out, Torus m, const Torus *s, int n, double sigma) {
+  Torus b = m;
+  for (int i = 0; i < n; i++) {
+    out[i] = orc_rng_next(r);
+    b += s[i] * out[i];
+  }
+  out[n] = b + orc_double2torus(orc_rng_normal(r, sigma));
+}
+
+/* src/trlwe.c:296-316  b = sum_p a_p * s_p + e (+ m); exact negacyclic product */
+void orc_trlwe_sample(orc_rng *r, Torus *out, const Torus *m, const Torus *s, int k, int N, double sigma) {
+  Torus *b = out + (size_t)k * N;
+  for (int p = 0; p < k; p++)
+    for (int i = 0; i < N; i++) out[(size_t)p * N + i] = orc_rng_next(r);
+  for (int i = 0; i < N; i++) b[i] = orc_double2torus(orc_rng_normal(r, sigma));
+  for (int p = 0; p < k; p++) orc_poly_naive_mul_addto(b, out + (size_t)p * N, s + (size_t)p * N, N);
+  if (m)
+    for (int i = 0; i < N; i++) b[i] += m[i];
+}
+
+/* src/trgsw.c:152-168  TRGSW(m X^e): (k+1)l fresh TRLWE(0) rows, row p*l+j gets m*2^(W-(j+1)Bg) on
+ * coefficient e of component p */
+void orc_trgsw_monomial_sample(orc_rng *r, Torus *out, int64_t m, int e, const Torus *s,
+                               int k, int N, int l, int Bg_bit, double sigma) {
+  if (e & N) m = -m;
+  e &= N - 1;
+  const size_t row = (size_t)(k + 1) * N;
+  for (int q = 0; q < (k + 1) * l; q++) orc_trlwe_sample(r, out + q * row, NULL, s, k, N, sigma);
+  for (int j = 0; j < l; j++) {
+    const Torus h = (Torus)1 << (W - (j + 1) * Bg_bit);
+    for (int p = 0; p <= k; p++) out[(size_t)(p * l + j) * row + (size_t)p * N + e] += (Torus)m * h;
+  }
+}
+
+/* src/bootstrap.c:14-18  BK_i = TRGSW(s_i) (message on X^0), kept in the torus domain here */
+void orc_gen_bootstrap_key(orc_rng *r, Torus *bk, const Torus *lwe_s, int n, const Torus *rlwe_s,
+                           int k, int N, int l, int Bg_bit, double sigma) {
+  const size_t sz = (size_t)(k + 1) * l * (k + 1) * N;
+  for (int i = 0; i < n; i++)
+    orc_trgsw_monomial_sample(r, bk + (size_t)i * sz, (int64_t)lwe_s[i], 0, rlwe_s, k, N, l, Bg_bit, sigma);
+}
+
+/* src/tlwe.c:193-212  KS[i][j][v-1] = TLWE_out(s_in[i] * v * 2^(W-(j+1)bb)) */
+void orc_gen_tlwe_ks_key(orc_rng *r, Torus *ksk, const Torus *s_in, int n_in, const Torus *s_out, int n_out,
+                         int t, int base_bit, double sigma) {
+  const int base = 1 << base_bit;
+  const size_t row = (size_t)n_out + 1;
+  for (int i = 0; i < n_in; i++)
+    for (int j = 0; j < t; j++)
+      for (int v = 1; v < base; v++) {
+        const Torus msg = s_in[i] * (Torus)v * ((Torus)1 << (W - (j + 1) * base_bit));
+        orc_tlwe_sample(r, ksk + (((size_t)i * t + j) * (base - 1) + (v - 1)) * row, msg, s_out, n_out, sigma);
+      }
+}

@@ -1,0 +1,286 @@
+/*
+ * ref_harness.c -- flat-buffer shim over the REAL reference library (antoniocgj/MOSFHET).
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is our own code; it is compiled TOGETHER WITH the
+ * reference's sources where they lie under /root/reference (oracle/ref/Makefile) into
+ * oracle/_ref/libmosfhet_ref_{avx512,ffnt}.so.  Nothing from the reference is copied into the
+ * repository.  It only marshals flat arrays (layouts of oracle/mosfhet_oracle.h) into the
+ * reference's pointer-based structs (include/mosfhet.h:32-133) and calls its public functions,
+ * so tests can pin the oracle against the reference and bench.py can time the reference's own
+ * bootstrap as the CPU baseline (cpu_baseline.kind = "reference").
+ */
+#include <mosfhet.h>
+#include <sys/time.h>
+
+/* ---------- marshalling helpers ---------- */
+static TRLWE trlwe_from_flat(const Torus *flat, int k, int N) {
+  TRLWE c = trlwe_alloc_new_sample(k, N);
+  for (int p = 0; p < k; p++) memcpy(c->a[p]->coeffs, flat + (size_t)p * N, sizeof(Torus) * N);
+  memcpy(c->b->coeffs, flat + (size_t)k * N, sizeof(Torus) * N);
+  return c;
+}
+
+static void trlwe_to_flat(Torus *flat, TRLWE c, int N) {
+  for (int p = 0; p < c->k; p++) memcpy(flat + (size_t)p * N, c->a[p]->coeffs, sizeof(Torus) * N);
+  memcpy(flat + (size_t)c->k * N, c->b->coeffs, sizeof(Torus) * N);
+}
+
+static TLWE tlwe_from_flat(const Torus *flat, int n) {
+  TLWE c = tlwe_alloc_sample(n);
+  memcpy(c->a, flat, sizeof(Torus) * n);
+  c->b = flat[n];
+  return c;
+}
+
+static void tlwe_to_flat(Torus *flat, TLWE c) {
+  memcpy(flat, c->a, sizeof(Torus) * c->n);
+  flat[c->n] = c->b;
+}
+
+static TorusPolynomial poly_from_flat(const Torus *flat, int N) {
+  TorusPolynomial p = polynomial_new_torus_polynomial(N);
+  memcpy(p->coeffs, flat, sizeof(Torus) * N);
+  return p;
+}
+
+/* ---------- scalars ---------- */
+uint64_t ref_torus2int(uint64_t x, int log_scale) { return torus2int(x, log_scale); }
+uint64_t ref_double2torus(double x) { return double2torus(x); }
+const char *ref_backend(void) {
+#if defined(USE_SPQLIOS) && defined(AVX512_OPT)
+  return "spqlios_avx512";
+#elif defined(USE_SPQLIOS)
+  return "spqlios_fma";
+#else
+  return "ffnt";
+#endif
+}
+void ref_init(int N) { init_fft(N); }
+
+/* ---------- integer polynomial ops ---------- */
+void ref_poly_decompose_i(Torus *out, const Torus *in, int N, int Bg_bit, int l, int i) {
+  TorusPolynomial pi = poly_from_flat(in, N), po = polynomial_new_torus_polynomial(N);
+  polynomial_decompose_i(po, pi, Bg_bit, l, i);
+  memcpy(out, po->coeffs, sizeof(Torus) * N);
+  free_polynomial(pi);
+  free_polynomial(po);
+}
+
+void ref_poly_decompose(Torus *out, const Torus *in, int N, int Bg_bit, int l) {
+  TorusPolynomial pi = poly_from_flat(in, N);
+  TorusPolynomial *po = polynomial_new_array_of_torus_polynomials(N, l);
+  polynomial_decompose(po, pi, Bg_bit, l);
+  for (int i = 0; i < l; i++) memcpy(out + (size_t)i * N, po[i]->coeffs, sizeof(Torus) * N);
+  free_polynomial(pi);
+  free_array_of_polynomials((void *)po, l);
+}
+
+/* which: 0 = mul_by_xai, 1 = mul_by_xai_addto (out preloaded), 2 = mul_by_xai_minus_1 */
+void ref_poly_mul_by_xai(Torus *out, const Torus *in, int N, int a, int which) {
+  TorusPolynomial pi = poly_from_flat(in, N), po = poly_from_flat(out, N);
+  if (which == 0) torus_polynomial_mul_by_xai(po, pi, a);
+  else if (which == 1) torus_polynomial_mul_by_xai_addto(po, pi, a);
+  else torus_polynomial_mul_by_xai_minus_1(po, pi, a);
+  memcpy(out, po->coeffs, sizeof(Torus) * N);
+  free_polynomial(pi);
+  free_polynomial(po);
+}
+
+void ref_poly_permute(Torus *out, const Torus *in, int N, uint64_t gen) {
+  TorusPolynomial pi = poly_from_flat(in, N), po = polynomial_new_torus_polynomial(N);
+  polynomial_permute(po, pi, gen);
+  memcpy(out, po->coeffs, sizeof(Torus) * N);
+  free_polynomial(pi);
+  free_polynomial(po);
+}
+
+void ref_poly_naive_mul(Torus *out, const Torus *a, const Torus *b, int N) {
+  TorusPolynomial pa = poly_from_flat(a, N), pb = poly_from_flat(b, N), po = polynomial_new_torus_polynomial(N);
+  polynomial_naive_mul_torus(po, pa, pb);
+  memcpy(out, po->coeffs, sizeof(Torus) * N);
+  free_polynomial(pa);
+  free_polynomial(pb);
+  free_polynomial(po);
+}
+
+/* FFT product: polynomial_mul_torus (src/polynomial.c:276) */
+void ref_poly_mul_fft(Torus *out, const Torus *a, const Torus *b, int N) {
+  TorusPolynomial pa = poly_from_flat(a, N), pb = poly_from_flat(b, N), po = polynomial_new_torus_polynomial(N);
+  polynomial_mul_torus(po, pa, pb);
+  memcpy(out, po->coeffs, sizeof(Torus) * N);
+  free_polynomial(pa);
+  free_polynomial(pb);
+  free_polynomial(po);
+}
+
+/* Torus -> DFT -> Torus round trip (test_poly_DFT, test/tests.c:231-242) */
+void ref_poly_dft_roundtrip(Torus *out, const Torus *in, int N) {
+  TorusPolynomial pi = poly_from_flat(in, N), po = polynomial_new_torus_polynomial(N);
+  DFT_Polynomial d = polynomial_new_DFT_polynomial(N);
+  polynomial_torus_to_DFT(d, pi);
+  polynomial_DFT_to_torus(po, d);
+  memcpy(out, po->coeffs, sizeof(Torus) * N);
+  free_polynomial(pi);
+  free_polynomial(po);
+  free_DFT_polynomial(d);
+}
+
+void ref_trlwe_extract_tlwe(Torus *out, const Torus *in, int k, int N, int idx) {
+  TRLWE c = trlwe_from_flat(in, k, N);
+  TLWE o = tlwe_alloc_sample(k * N);
+  trlwe_extract_tlwe(o, c, idx);
+  tlwe_to_flat(out, o);
+  free_trlwe(c);
+  free_tlwe(o);
+}
+
+void ref_trlwe_torus_packing(Torus *out, Torus *lut, int k, int N, int size) {
+  TRLWE c = trlwe_alloc_new_sample(k, N);
+  trlwe_torus_packing(c, lut, size);
+  trlwe_to_flat(out, c, N);
+  free_trlwe(c);
+}
+
+Torus ref_tlwe_phase(const Torus *c, Torus *s, int n) {
+  TLWE ct = tlwe_from_flat(c, n);
+  struct _TLWE_Key key = {.s = s, .n = n, .sigma = 0};
+  Torus r = tlwe_phase(ct, &key);
+  free_tlwe(ct);
+  return r;
+}
+
+/* ---------- TRGSW / bootstrap key ---------- */
+static TRGSW_DFT trgsw_dft_from_flat(const Torus *flat, int k, int N, int l, int Bg_bit) {
+  TRGSW g = trgsw_alloc_new_sample(l, Bg_bit, k, N);
+  const size_t row = (size_t)(k + 1) * N;
+  for (int q = 0; q < (k + 1) * l; q++) {
+    for (int p = 0; p < k; p++) memcpy(g->samples[q]->a[p]->coeffs, flat + q * row + (size_t)p * N, sizeof(Torus) * N);
+    memcpy(g->samples[q]->b->coeffs, flat + q * row + (size_t)k * N, sizeof(Torus) * N);
+  }
+  TRGSW_DFT gd = trgsw_alloc_new_DFT_sample(l, Bg_bit, k, N);
+  trgsw_to_DFT(gd, g);
+  free_trgsw(g);
+  return gd;
+}
+
+/* out = TRGSW (.) in, back in the torus domain: trgsw_mul_trlwe_DFT + trlwe_from_DFT */
+void ref_external_product(Torus *out, const Torus *in, const Torus *trgsw_flat, int k, int N, int l, int Bg_bit) {
+  TRGSW_DFT gd = trgsw_dft_from_flat(trgsw_flat, k, N, l, Bg_bit);
+  TRLWE ci = trlwe_from_flat(in, k, N), co = trlwe_alloc_new_sample(k, N);
+  TRLWE_DFT tmp = trlwe_alloc_new_DFT_sample(k, N);
+  trgsw_mul_trlwe_DFT(tmp, ci, gd);
+  trlwe_from_DFT(co, tmp);
+  trlwe_to_flat(out, co, N);
+  free_trlwe(ci);
+  free_trlwe(co);
+  free_trlwe(tmp);
+  free_trgsw(gd);
+}
+
+/* Bootstrap_Key from torus-domain rows u64[n][(k+1)l][k+1][N] (what new_bootstrap_key builds at
+ * src/bootstrap.c:14-18, minus the non-reproducible encryption) */
+void *ref_bk_new(const Torus *bk_flat, int n, int k, int N, int l, int Bg_bit) {
+  Bootstrap_Key res = (Bootstrap_Key)safe_malloc(sizeof(*res));
+  res->s = (TRGSW_DFT *)safe_malloc(sizeof(TRGSW_DFT) * n);
+  res->su = NULL;
+  res->n = n;
+  res->k = k;
+  res->l = l;
+  res->N = N;
+  res->Bg_bit = Bg_bit;
+  res->unfolding = 1;
+  const size_t sz = (size_t)(k + 1) * l * (k + 1) * N;
+  for (int i = 0; i < n; i++) res->s[i] = trgsw_dft_from_flat(bk_flat + i * sz, k, N, l, Bg_bit);
+  return res;
+}
+
+void ref_bk_free(void *h) { free_bootstrap_key((Bootstrap_Key)h); }
+
+void ref_blind_rotate(Torus *acc, const Torus *a, void *h) {
+  Bootstrap_Key bk = (Bootstrap_Key)h;
+  TRLWE c = trlwe_from_flat(acc, bk->k, bk->N);
+  blind_rotate(c, (Torus *)a, bk->s, bk->n);
+  trlwe_to_flat(acc, c, bk->N);
+  free_trlwe(c);
+}
+
+void ref_functional_bootstrap_wo_extract(Torus *out, const Torus *tv, const Torus *in, void *h, int torus_base) {
+  Bootstrap_Key bk = (Bootstrap_Key)h;
+  TRLWE t = trlwe_from_flat(tv, bk->k, bk->N), o = trlwe_alloc_new_sample(bk->k, bk->N);
+  TLWE c = tlwe_from_flat(in, bk->n);
+  functional_bootstrap_wo_extract(o, t, c, bk, torus_base);
+  trlwe_to_flat(out, o, bk->N);
+  free_trlwe(t);
+  free_trlwe(o);
+  free_tlwe(c);
+}
+
+void ref_functional_bootstrap(Torus *out, const Torus *tv, const Torus *in, void *h, int torus_base) {
+  Bootstrap_Key bk = (Bootstrap_Key)h;
+  TRLWE t = trlwe_from_flat(tv, bk->k, bk->N);
+  TLWE c = tlwe_from_flat(in, bk->n), o = tlwe_alloc_sample(bk->k * bk->N);
+  functional_bootstrap(o, t, c, bk, torus_base);
+  tlwe_to_flat(out, o);
+  free_trlwe(t);
+  free_tlwe(c);
+  free_tlwe(o);
+}
+
+void ref_programmable_bootstrap(Torus *out, const Torus *tv, const Torus *in, void *h, int precision, int kappa, int theta) {
+  Bootstrap_Key bk = (Bootstrap_Key)h;
+  TRLWE t = trlwe_from_flat(tv, bk->k, bk->N);
+  TLWE c = tlwe_from_flat(in, bk->n), o = tlwe_alloc_sample(bk->k * bk->N);
+  programmable_bootstrap(o, t, c, bk, precision, kappa, theta);
+  tlwe_to_flat(out, o);
+  free_trlwe(t);
+  free_tlwe(c);
+  free_tlwe(o);
+}
+
+/* ---------- LWE key switch ---------- */
+void *ref_ksk_new(const Torus *flat, int n_in, int n_out, int t, int base_bit) {
+  const int base = 1 << base_bit;
+  TLWE_KS_Key res = (TLWE_KS_Key)safe_malloc(sizeof(*res));
+  res->base_bit = base_bit;
+  res->t = t;
+  res->n = n_in;
+  res->s = (TLWE ***)safe_malloc(sizeof(TLWE **) * n_in);
+  const size_t row = (size_t)n_out + 1;
+  for (int i = 0; i < n_in; i++) {
+    res->s[i] = (TLWE **)safe_malloc(sizeof(TLWE *) * t);
+    for (int j = 0; j < t; j++) {
+      res->s[i][j] = (TLWE *)safe_malloc(sizeof(TLWE) * (base - 1));
+      for (int v = 0; v < base - 1; v++)
+        res->s[i][j][v] = tlwe_from_flat(flat + (((size_t)i * t + j) * (base - 1) + v) * row, n_out);
+    }
+  }
+  return res;
+}
+
+void ref_ksk_free(void *h) { free_tlwe_ks_key((TLWE_KS_Key)h); }
+
+void ref_tlwe_keyswitch(Torus *out, const Torus *in, void *h, int n_out) {
+  TLWE_KS_Key ks = (TLWE_KS_Key)h;
+  TLWE c = tlwe_from_flat(in, ks->n), o = tlwe_alloc_sample(n_out);
+  tlwe_keyswitch(o, c, ks);
+  tlwe_to_flat(out, o);
+  free_tlwe(c);
+  free_tlwe(o);
+}
+
+/* ---------- CPU baseline: time `reps` reference programmable bootstraps on the calling thread.
+ * Re-entrant across threads once ref_init(N) has run on the main thread (FFT processors are
+ * __thread, src/polynomial.c:338-349). Returns elapsed seconds. ---------- */
+double ref_bench_programmable_bootstrap(const Torus *tv, const Torus *in, void *h, int precision, int reps) {
+  Bootstrap_Key bk = (Bootstrap_Key)h;
+  TRLWE t = trlwe_from_flat(tv, bk->k, bk->N);
+  TLWE c = tlwe_from_flat(in, bk->n), o = tlwe_alloc_sample(bk->k * bk->N);
+  struct timeval t0, t1;
+  gettimeofday(&t0, NULL);
+  for (int r = 0; r < reps; r++) programmable_bootstrap(o, t, c, bk, precision, 0, 0);
+  gettimeofday(&t1, NULL);
+  free_trlwe(t);
+  free_tlwe(c);
+  free_tlwe(o);
+  return (double)(t1.tv_sec - t0.tv_sec) + 1e-6 * (double)(t1.tv_usec - t0.tv_usec);
+}

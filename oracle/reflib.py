@@ -1,0 +1,190 @@
+"""ctypes binding of oracle/_ref/libmosfhet_ref_*.so -- the REAL reference library built from
+/root/reference by oracle/ref/Makefile plus our flat-buffer shim (oracle/ref/ref_harness.c).
+
+TEST INFRASTRUCTURE ONLY.  Used to pin the oracle (tests/test_oracle_vs_reference.py), to
+generate tests/golden (tests/golden/make_golden.py) and as bench.py's cpu_baseline
+(kind = "reference").  The .so files are git-ignored build products; they travel to the GPU box
+with the snapshot, /root/reference itself does not.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REF_DIR = os.path.join(_HERE, "_ref")
+U64P = C.POINTER(C.c_uint64)
+
+
+def cpu_flags():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    return set(line.split(":", 1)[1].split())
+    except OSError:
+        pass
+    return set()
+
+
+def avx512_ok():
+    need = {"avx512f", "avx512dq", "avx512bw", "avx512vl", "avx512cd", "vaes", "aes", "rdrand", "fma", "pclmulqdq"}
+    return need <= cpu_flags()
+
+
+def build():
+    """(Re)build oracle/_ref from /root/reference when that tree is present (this container only)."""
+    if os.path.isdir("/root/reference/src"):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "ref")])
+        return True
+    return False
+
+
+def available(backend):
+    return os.path.exists(os.path.join(REF_DIR, "libmosfhet_ref_%s.so" % backend)) and (
+        backend != "avx512" or avx512_ok())
+
+
+def _u(a):
+    assert a.dtype == np.uint64 and a.flags.c_contiguous
+    return a.ctypes.data_as(U64P)
+
+
+class Ref:
+    """One loaded reference build ("avx512" = SPQLIOS AVX-512, "ffnt" = portable pure C)."""
+
+    def __init__(self, backend):
+        path = os.path.join(REF_DIR, "libmosfhet_ref_%s.so" % backend)
+        # RTLD_LOCAL: the reference exports the mosfhet.h symbol names; keep them private
+        self.l = C.CDLL(path, mode=os.RTLD_LOCAL | os.RTLD_NOW)
+        self.backend = backend
+        L = self.l
+        L.ref_torus2int.restype = C.c_uint64
+        L.ref_torus2int.argtypes = [C.c_uint64, C.c_int]
+        L.ref_double2torus.restype = C.c_uint64
+        L.ref_double2torus.argtypes = [C.c_double]
+        L.ref_backend.restype = C.c_char_p
+        L.ref_tlwe_phase.restype = C.c_uint64
+        L.ref_bk_new.restype = C.c_void_p
+        L.ref_ksk_new.restype = C.c_void_p
+        L.ref_bench_programmable_bootstrap.restype = C.c_double
+
+    def init(self, N):
+        self.l.ref_init(N)
+
+    def torus2int(self, x, ls):
+        return self.l.ref_torus2int(C.c_uint64(int(x)), ls)
+
+    def double2torus(self, x):
+        return self.l.ref_double2torus(C.c_double(x))
+
+    def poly_decompose_i(self, p, Bg_bit, l, i):
+        out = np.empty_like(p)
+        self.l.ref_poly_decompose_i(_u(out), _u(p), C.c_int(p.size), Bg_bit, l, i)
+        return out
+
+    def poly_decompose(self, p, Bg_bit, l):
+        out = np.empty((l, p.size), dtype=np.uint64)
+        self.l.ref_poly_decompose(_u(out), _u(p), C.c_int(p.size), Bg_bit, l)
+        return out
+
+    def poly_mul_by_xai(self, p, a, which=0, acc=None):
+        out = acc.copy() if acc is not None else np.zeros_like(p)
+        self.l.ref_poly_mul_by_xai(_u(out), _u(p), C.c_int(p.size), C.c_int(a), which)
+        return out
+
+    def poly_permute(self, p, gen):
+        out = np.empty_like(p)
+        self.l.ref_poly_permute(_u(out), _u(p), C.c_int(p.size), C.c_uint64(gen))
+        return out
+
+    def poly_naive_mul(self, a, b):
+        out = np.empty_like(a)
+        self.l.ref_poly_naive_mul(_u(out), _u(a), _u(b), C.c_int(a.size))
+        return out
+
+    def poly_mul_fft(self, a, b):
+        out = np.empty_like(a)
+        self.l.ref_poly_mul_fft(_u(out), _u(a), _u(b), C.c_int(a.size))
+        return out
+
+    def poly_dft_roundtrip(self, a):
+        out = np.empty_like(a)
+        self.l.ref_poly_dft_roundtrip(_u(out), _u(a), C.c_int(a.size))
+        return out
+
+    def trlwe_extract_tlwe(self, c, idx):
+        k1, N = c.shape
+        out = np.empty((k1 - 1) * N + 1, dtype=np.uint64)
+        self.l.ref_trlwe_extract_tlwe(_u(out), _u(c), k1 - 1, N, idx)
+        return out
+
+    def trlwe_torus_packing(self, lut, k, N):
+        lut = np.ascontiguousarray(lut, dtype=np.uint64)
+        out = np.empty((k + 1, N), dtype=np.uint64)
+        self.l.ref_trlwe_torus_packing(_u(out), _u(lut), k, N, C.c_int(lut.size))
+        return out
+
+    def tlwe_phase(self, c, s):
+        return self.l.ref_tlwe_phase(_u(c), _u(s), C.c_int(s.size))
+
+    def external_product(self, c, g, l, Bg_bit):
+        k1, N = c.shape
+        out = np.empty_like(c)
+        self.l.ref_external_product(_u(out), _u(c), _u(g), k1 - 1, N, l, Bg_bit)
+        return out
+
+    def bk_new(self, bk, k, l, Bg_bit):
+        n, _, _, N = bk.shape
+        return C.c_void_p(self.l.ref_bk_new(_u(bk), n, k, N, l, Bg_bit))
+
+    def bk_free(self, h):
+        self.l.ref_bk_free(h)
+
+    def blind_rotate(self, acc, a, h):
+        out = acc.copy()
+        self.l.ref_blind_rotate(_u(out), _u(a), h)
+        return out
+
+    def functional_bootstrap_wo_extract(self, tv, c, h, torus_base):
+        out = np.empty_like(tv)
+        self.l.ref_functional_bootstrap_wo_extract(_u(out), _u(tv), _u(c), h, torus_base)
+        return out
+
+    def functional_bootstrap(self, tv, c, h, torus_base):
+        k1, N = tv.shape
+        out = np.empty((k1 - 1) * N + 1, dtype=np.uint64)
+        self.l.ref_functional_bootstrap(_u(out), _u(tv), _u(c), h, torus_base)
+        return out
+
+    def programmable_bootstrap(self, tv, c, h, precision, kappa, theta):
+        k1, N = tv.shape
+        out = np.empty((k1 - 1) * N + 1, dtype=np.uint64)
+        self.l.ref_programmable_bootstrap(_u(out), _u(tv), _u(c), h, precision, kappa, theta)
+        return out
+
+    def ksk_new(self, ksk, base_bit):
+        n_in, t, _, row = ksk.shape
+        return C.c_void_p(self.l.ref_ksk_new(_u(ksk), n_in, row - 1, t, base_bit))
+
+    def ksk_free(self, h):
+        self.l.ref_ksk_free(h)
+
+    def tlwe_keyswitch(self, c, h, n_out):
+        out = np.empty(n_out + 1, dtype=np.uint64)
+        self.l.ref_tlwe_keyswitch(_u(out), _u(c), h, n_out)
+        return out
+
+    def bench_programmable_bootstrap(self, tv, c, h, precision, reps):
+        """Seconds for `reps` programmable_bootstrap calls on the calling thread (GIL released)."""
+        return self.l.ref_bench_programmable_bootstrap(_u(tv), _u(c), h, precision, reps)
+
+
+_cache = {}
+
+
+def get(backend):
+    if backend not in _cache:
+        _cache[backend] = Ref(backend)
+    return _cache[backend]
