@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- programmable bootstraps / second on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch: `--batch` (default 4096) independent
+programmable_bootstrap calls at SET_1 (n=585, N=1024, k=1, l=2, Bg=2^8: BASELINE.json configs[1]) on each
+GPU, inputs and the bootstrap key already resident in HBM.  With --gpus N > 1 (launched by
+torch.distributed.run, one rank per GPU) every rank bootstraps its own batch against its own replica of the
+key -- no collective on the data path (weak scaling); the only collectives are the barrier and the
+max-over-ranks of the timed region.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     : algorithmic bytes per launch (38,367,832 B per bootstrap at SET_1) over the
+                 kernel's average launch duration measured with hipEvents on the launch stream;
+  cpu_baseline : the reference's own programmable_bootstrap (oracle/_ref, built from /root/reference) timed on
+                 this box's host cores on a bounded sample (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED = 0x4D4F5346
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+
+
+def algorithmic_bytes_per_bootstrap(P):
+    """bootstrap key streamed once per ciphertext + LWE in + test vector + LWE out."""
+    k, N, n, l = P["k"], P["N"], P["n"], P["l"]
+    return n * (k + 1) ** 2 * l * N * 8 + (n + 1) * 8 + (k + 1) * N * 8 + (k * N + 1) * 8
+
+
+def cpu_baseline(P, bk, tv, cts, target_seconds):
+    """Time the reference's programmable_bootstrap on the host cores (checker infrastructure, oracle/)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import reflib
+    threads = usable_cores()
+    backend = "avx512" if reflib.available("avx512") else ("ffnt" if reflib.available("ffnt") else None)
+    if backend is None:
+        # no reference build shipped: fall back to timing the oracle port on one core
+        from oracle import oracle as O
+        bk_dft = O.bk_to_dft(bk, P["k"], P["l"])
+        t0 = time.time()
+        reps = 0
+        while time.time() - t0 < target_seconds / 2:
+            O.programmable_bootstrap(tv, cts[reps % len(cts)], bk_dft, P["l"], P["Bg_bit"], 3, 0, 0)
+            reps += 1
+        dt = time.time() - t0
+        return dict(value=reps / dt, unit="bootstraps/s", cores=1, kind="port",
+                    sample="%d programmable_bootstrap calls of the C oracle, 1 thread, %.1f s" % (reps, dt))
+    ref = reflib.get(backend)
+    ref.init(P["N"])
+    h = ref.bk_new(bk, P["k"], P["l"], P["Bg_bit"])
+    # every usable core loops over small chunks of calls until a common deadline: bounded wall time whatever
+    # the core count (ctypes releases the GIL; the reference's FFT state is per thread, src/polynomial.c:338-349)
+    t1 = ref.bench_programmable_bootstrap(tv, cts[0], h, 3, 2) / 2
+    chunk = max(1, int(0.25 / max(t1, 1e-4)))
+    counts = [0] * threads
+    t0 = time.time()
+    deadline = t0 + target_seconds
+
+    def worker(i):
+        while time.time() < deadline:
+            ref.bench_programmable_bootstrap(tv, cts[i % len(cts)], h, 3, chunk)
+            counts[i] += chunk
+
+    with ThreadPoolExecutor(threads) as pool:
+        list(pool.map(worker, range(threads)))
+    dt = time.time() - t0
+    ref.bk_free(h)
+    total = sum(counts)
+    return dict(value=total / dt, unit="bootstraps/s", cores=threads, kind="reference",
+                sample="%d programmable_bootstrap calls of MOSFHET (%s build of /root/reference) over %d threads in "
+                       "%.1f s wall; one call alone takes %.2f ms" % (total, backend, threads, dt, 1e3 * t1))
+
+
+def usable_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4096, help="bootstraps per GPU per step")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall budget of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: mosfhet_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import mosfhet_amd as ma
+    from mosfhet_amd import host, build
+    build.build()
+    P = dict(ma.PARAMS_SET1)
+    B = args.batch
+
+    # ---- synthetic keys and ciphertexts; same seed on every rank = replicated key
+    host.seed(SEED)
+    lk = host.LweKey(P["n"], P["lwe_sigma"])
+    rk = host.RlweKey(P["N"], P["k"], P["rlwe_sigma"])
+    bk = host.gen_bootstrap_key(rk, lk, P["l"], P["Bg_bit"])
+    eng = ma.Engine(local_rank)
+    bsk = eng.load_bootstrap_key(bk, P["k"], P["l"], P["Bg_bit"])
+    host.seed(SEED + 1 + rank)  # different ciphertexts per rank
+    lut = np.array([host.double2torus(x) for x in (0.05, 0.30, -0.20, 0.45)], dtype=np.uint64)
+    tv = host.torus_packing(lut, P["k"], P["N"])
+    msgs = [host.double2torus((b % 4) / 8.0) for b in range(B)]
+    cts = host.tlwe_samples(msgs, lk)
+    d_tv = ma.to_device(tv[None], eng.device)
+    d_ct = ma.to_device(cts, eng.device)
+    d_out = eng.empty(B, P["k"] * P["N"] + 1)
+
+    def step():
+        eng.programmable_bootstrap(bsk, d_tv, d_ct, 3, 0, 0, out=d_out)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    # correctness of what is being timed: every output decrypts to its LUT slot (2^58, test/tests.c:1560)
+    ph = host.tlwe_phase(ma.to_numpy(d_out), rk.extracted_lwe_key().s)
+    err = np.abs((ph - lut[np.arange(B) % 4]).astype(np.int64).astype(np.float64)).max()
+    if not err < 2.0 ** 58:
+        sys.exit("bench.py: bootstrap outputs do not decrypt (max phase error 2^%.1f)" % np.log2(err + 1))
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel: average launch duration by hipEvents on the launch stream
+    kernel_ms = eng.time_programmable_bootstrap(bsk, d_tv, d_ct, 3, max(3, min(args.steps, 10)), out=d_out)
+    bytes_per_launch = algorithmic_bytes_per_bootstrap(P) * B
+    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(P, bk, tv, cts[:64], args.cpu_seconds)
+
+    if rank == 0:
+        total = world * args.steps * B
+        line = {
+            "metric": "programmable bootstraps/sec (whole node), N=1024 k=1",
+            "value": total / elapsed,
+            "unit": "bootstraps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "batch of %d programmable bootstraps per GPU, SET_1 n=585 N=1024 k=1 l=2 Bg=2^8 "
+                                   "(BASELINE.json configs[1])" % B,
+                       "batch_per_gpu": B, "parallelism": "batch sharded over %d GPU(s), bootstrap key replicated, "
+                                                          "no collective on the data path" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "pbs_kernel_1024<2>", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": bytes_per_launch},
+            "cpu_baseline": cpu,
+            "max_phase_error_log2": float(np.log2(err + 1)),
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

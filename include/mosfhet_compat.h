@@ -1,0 +1,127 @@
+/*
+ * mosfhet_compat.h -- MOSFHET-compatible host API of the MI355X bootstrap engine (hot-path subset).
+ *
+ * Plain C.  The types below have the SAME field order and meaning as the torus-domain types of the
+ * reference's include/mosfhet.h (lines cited per type), because reference callers poke the fields directly
+ * (e.g. `lut->b->coeffs[i]`, `ct->b -= x`, test/tests.c:1453, src/bootstrap.c:409).  The functions keep the
+ * reference's names, argument order and error behaviour (void; abort with a message on failure, as the
+ * reference's assert / safe_malloc do, src/misc.c:104-128), so a program written against mosfhet.h for this
+ * path re-links against libmosfhet_hip.so unchanged.  What differs, by design:
+ *   - DFT-domain objects are device resident: Bootstrap_Key.s is an opaque token for the engine's key
+ *     (reference: array of host TRGSW_DFT, include/mosfhet.h:129-133), and TLWE_KS_Key additionally owns a
+ *     device copy of its table;
+ *   - every bootstrap / key switch runs on the GPU through include/mosfhet_hip.h; there is no CPU path;
+ *   - new *_batch entry points take arrays of samples (the reference has no batching API; its callers loop,
+ *     e.g. applications/multi-ciphertext-arith/src/lut.c:12-17);
+ *   - randomness comes from a seedable generator (mosfhet_seed); the reference seeds from RDRAND and is not
+ *     reproducible (src/misc.c:34-49).
+ * Functions of mosfhet.h outside the programmable-bootstrap path are not provided (scope).
+ */
+#ifndef MOSFHET_COMPAT_H
+#define MOSFHET_COMPAT_H
+#include <stdint.h>
+#include <stdio.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint64_t Torus;            /* mosfhet.h:27 */
+typedef Torus Integer;             /* mosfhet.h:48 */
+
+typedef struct _TorusPolynomial { Torus *coeffs; int N; } *TorusPolynomial;          /* mosfhet.h:32-35 */
+typedef TorusPolynomial IntPolynomial;                                               /* mosfhet.h:47 */
+typedef struct _DFT_Polynomial { double *coeffs; int N; } *DFT_Polynomial;           /* mosfhet.h:37-40 */
+
+typedef struct _TLWE { Torus *a, b; int n; } *TLWE;                                  /* mosfhet.h:51-54 */
+typedef struct _TLWE_Key { Integer *s; int n; double sigma; } *TLWE_Key;             /* mosfhet.h:56-60 */
+typedef struct _TLWE_KS_Key { TLWE ***s; int base_bit, t, n;                         /* mosfhet.h:62-65 */
+                              void *device; } *TLWE_KS_Key;                          /* + engine handle (appended) */
+
+typedef struct _TRLWE { TorusPolynomial *a, b; int k; } *TRLWE;                      /* mosfhet.h:73-76 */
+typedef struct _TRLWE_Key { IntPolynomial *s; DFT_Polynomial *s_dft; int k; double sigma; } *TRLWE_Key; /* mosfhet.h:83-88 */
+
+typedef struct _TRGSW { TRLWE *samples; int l, Bg_bit; } *TRGSW;                     /* mosfhet.h:106-109 */
+typedef struct _TRGSW_DFT *TRGSW_DFT;                                                /* opaque: device resident */
+typedef struct _TRGSW_Key { TRLWE_Key trlwe_key; int l, Bg_bit; } *TRGSW_Key;        /* mosfhet.h:116-119 */
+
+typedef struct _Bootstrap_Key { TRGSW_DFT *s; TRGSW *su; int n, k, N, Bg_bit, l, unfolding; } *Bootstrap_Key; /* mosfhet.h:129-133 */
+
+/* ---- engine control (new) ---- */
+void mosfhet_seed(uint64_t seed);              /* reseed the host generator used by all *_sample / *_key functions */
+void mosfhet_set_device(int device);           /* GPU used by this process (default: env MOSFHET_HIP_DEVICE or 0) */
+void *mosfhet_engine_ctx(void);                /* the mosfhet_hip_ctx_t behind the compat layer */
+void *mosfhet_bootstrap_key_device(Bootstrap_Key key);   /* the mosfhet_hip_bsk_t behind a Bootstrap_Key */
+
+/* ---- torus scalars (src/misc.c:13-28) ---- */
+double torus2double(Torus x);
+Torus double2torus(double x);
+uint64_t torus2int(Torus x, int log_scale);
+Torus int2torus(uint64_t x, int log_scale);
+
+/* ---- polynomials (src/polynomial.c:3-53) ---- */
+TorusPolynomial polynomial_new_torus_polynomial(int N);
+void free_polynomial(void *p);
+
+/* ---- TLWE (src/tlwe.c) ---- */
+TLWE_Key tlwe_alloc_key(int n, double sigma);                     /* :60-67 */
+TLWE_Key tlwe_new_binary_key(int n, double sigma);                /* :81-83 */
+void free_tlwe_key(TLWE_Key key);                                 /* :102-105 */
+TLWE tlwe_alloc_sample(int n);                                    /* :3-10 */
+TLWE *tlwe_alloc_sample_array(int count, int n);                  /* :12-19 */
+void free_tlwe(TLWE p);
+void free_tlwe_array(TLWE *p, int count);
+void tlwe_noiseless_trivial_sample(TLWE out, Torus m);            /* :32-35 */
+void tlwe_sample(TLWE out, Torus m, TLWE_Key key);                /* :106-115 */
+TLWE tlwe_new_sample(Torus m, TLWE_Key key);                      /* :122-133 */
+Torus tlwe_phase(TLWE c, TLWE_Key key);                           /* :135-141 */
+void tlwe_copy(TLWE out, TLWE in);                                /* :117-120 */
+TLWE_KS_Key tlwe_new_KS_key(TLWE_Key out_key, TLWE_Key in_key, int t, int base_bit);   /* :193-212 */
+void free_tlwe_ks_key(TLWE_KS_Key key);                           /* :232-245 */
+void tlwe_keyswitch(TLWE out, TLWE in, TLWE_KS_Key ks_key);       /* :289-303  -> GPU */
+
+/* ---- TRLWE (src/trlwe.c) ---- */
+TRLWE_Key trlwe_alloc_key(int N, int k, double sigma);            /* :104-116 */
+TRLWE_Key trlwe_new_binary_key(int N, int k, double sigma);       /* :132-134 */
+void free_trlwe_key(TRLWE_Key key);
+TRLWE trlwe_alloc_new_sample(int k, int N);                       /* :3-13 */
+void free_trlwe(void *p);                                         /* :86-94 */
+void trlwe_noiseless_trivial_sample(TRLWE out, TorusPolynomial m);/* :273-283 */
+TRLWE trlwe_new_noiseless_trivial_sample(TorusPolynomial m, int k, int N);
+void trlwe_sample(TRLWE out, TorusPolynomial m, TRLWE_Key key);   /* :296-316 */
+void trlwe_phase(TorusPolynomial out, TRLWE in, TRLWE_Key key);   /* :324-331 (exact product here) */
+void trlwe_torus_packing(TRLWE out, Torus *in, int size);         /* :662-667 */
+void trlwe_extract_tlwe_key(TLWE_Key out, TRLWE_Key in);          /* :531-538 */
+void trlwe_extract_tlwe(TLWE out, TRLWE in, int idx);             /* :540-552 (host) */
+
+/* ---- TRGSW (src/trgsw.c) ---- */
+TRGSW_Key trgsw_new_key(TRLWE_Key trlwe_key, int l, int Bg_bit);  /* :20-27 */
+void free_trgsw_key(TRGSW_Key key);
+TRGSW trgsw_alloc_new_sample(int l, int Bg_bit, int k, int N);    /* :48-59 */
+void free_trgsw(void *p);
+void trgsw_monomial_sample(TRGSW out, int64_t m, int e, TRGSW_Key key);   /* :152-168 */
+
+/* ---- bootstrap (src/bootstrap.c)  -> GPU ---- */
+Bootstrap_Key new_bootstrap_key(TRGSW_Key out_key, TLWE_Key in_key, int unfolding);   /* :3-48 (unfolding must be 1) */
+void free_bootstrap_key(Bootstrap_Key key);                                            /* :51-61 */
+void blind_rotate(TRLWE tv, Torus *a, TRGSW_DFT *s, int size);                         /* :107-122 */
+void functional_bootstrap_wo_extract(TRLWE out, TRLWE tv, TLWE in, Bootstrap_Key key, int torus_base);  /* :192-198 */
+void functional_bootstrap(TLWE out, TRLWE tv, TLWE in, Bootstrap_Key key, int torus_base);              /* :200-206 */
+void programmable_bootstrap(TLWE out, TRLWE tv, TLWE in, Bootstrap_Key key, int precision, int kappa, int theta); /* :208-220 */
+
+/* ---- batch extensions (new): arrays of `count` samples, one shared test vector ---- */
+void functional_bootstrap_batch(TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_Key key, int torus_base);
+void programmable_bootstrap_batch(TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_Key key,
+                                  int precision, int kappa, int theta);
+void tlwe_keyswitch_batch(TLWE *out, TLWE *in, int count, TLWE_KS_Key ks_key);
+
+/* ---- flat helpers used by the Python binding and bench.py (new) ----
+ * Generate a whole bootstrap / key-switch key in the flat torus-domain layouts of mosfhet_hip.h. */
+void mosfhet_gen_bootstrap_key_flat(Torus *out /*[n][(k+1)l][k+1][N]*/, TRGSW_Key out_key, TLWE_Key in_key);
+void mosfhet_gen_tlwe_ks_key_flat(Torus *out /*[n_in][t][2^bb-1][n_out+1]*/, TLWE_Key out_key, TLWE_Key in_key,
+                                  int t, int base_bit);
+void mosfhet_tlwe_sample_flat(Torus *out /*[n+1]*/, Torus m, TLWE_Key key);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,134 @@
+/*
+ * mosfhet_hip.h -- C ABI of the MI355X (gfx950) TFHE bootstrap engine.
+ *
+ * This is the thin device layer that a MOSFHET build links instead of its CPU hot path
+ * (src/bootstrap.c, src/trgsw.c, src/polynomial.c with the src/fft back-ends, src/tlwe.c key switch).  Plain C: opaque
+ * handles, raw pointers and sizes, no C++ / torch types.  Each entry point names the reference
+ * function(s) of antoniocgj/MOSFHET it replaces (file:line in that repository); INTEGRATION.md shows
+ * the reference-side binding.  The MOSFHET-compatible struct API (TLWE, TRLWE, Bootstrap_Key,
+ * functional_bootstrap(), ...) built on top of this layer is declared in mosfhet_compat.h.
+ *
+ * Conventions
+ *   Torus            uint64_t, arithmetic mod 2^64                         (include/mosfhet.h:27)
+ *   TLWE(n)          Torus[n+1]:  a[0..n-1], b                             (mosfhet.h:51-54, flattened)
+ *   TRLWE(k,N)       Torus[k+1][N]: a[0..k-1], b                           (mosfhet.h:73-76, flattened)
+ *   TRGSW(k,N,l)     Torus[(k+1)l][k+1][N], row p*l+j                      (mosfhet.h:106-109, src/trgsw.c:152-168)
+ *   batches          arrays of the above, densely packed, batch index outermost
+ *   d_* parameters   DEVICE pointers (hipMalloc / torch CUDA storage); h_* parameters host pointers
+ *   stream           a hipStream_t passed as void*; NULL = HIP's default (null) stream, as in every HIP API
+ *                    (torch's default stream is that NULL handle).  Calls are asynchronous on the stream
+ *                    and never synchronise the device unless documented
+ *   return value     0 on success, a negative MOSFHET_HIP_E* code otherwise; mosfhet_hip_last_error()
+ *                    returns a thread-local message.  The legacy void API of mosfhet_compat.h aborts on
+ *                    error, like the reference's assert/exit behaviour (src/misc.c:104-128).
+ *   supported        k = 1; N = 1024 (more ring degrees are added per round);
+ *                    any l, Bg_bit with l*Bg_bit < 64; any n.
+ * DFT-domain data (bootstrap key) is device-resident in the engine's own slot order and never leaves it,
+ * as in the reference where the element order is private to the FFT back-end (src/polynomial.c:336-357).
+ */
+#ifndef MOSFHET_HIP_H
+#define MOSFHET_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOSFHET_HIP_OK 0
+#define MOSFHET_HIP_EINVAL (-1)      /* bad argument / unsupported parameter set */
+#define MOSFHET_HIP_EHIP (-2)        /* a HIP runtime call failed (message has the hipError string) */
+#define MOSFHET_HIP_ENODEV (-3)      /* no usable gfx950 device */
+
+typedef struct mosfhet_hip_ctx *mosfhet_hip_ctx_t;     /* one per (process, device) */
+typedef struct mosfhet_hip_bsk *mosfhet_hip_bsk_t;     /* device-resident DFT bootstrap key */
+typedef struct mosfhet_hip_ksk *mosfhet_hip_ksk_t;     /* device-resident LWE key-switch key */
+
+const char *mosfhet_hip_last_error(void);
+const char *mosfhet_hip_version(void);
+
+/* Context: selects `device` and creates the twiddle tables (replaces the lazy per-thread
+ * FFT-processor set-up of init_fft, src/polynomial.c:336-357). */
+int mosfhet_hip_ctx_create(mosfhet_hip_ctx_t *out, int device);
+int mosfhet_hip_ctx_destroy(mosfhet_hip_ctx_t ctx);
+int mosfhet_hip_ctx_sync(mosfhet_hip_ctx_t ctx, void *stream);          /* hipStreamSynchronize */
+int mosfhet_hip_device_count(void);
+
+/* The twiddle table the engine uses for ring degree N: (re, im) pairs, N/2 - 1 of them (host copy;
+ * lets tests check it is bit-identical to the oracle's). */
+int mosfhet_hip_twiddles(int N, double *h_out);
+
+/* Bootstrap key.  Takes the key in the TORUS domain, h_bk = Torus[n][(k+1)l][k+1][N] with
+ * BK_i = TRGSW(s_i) -- what new_bootstrap_key holds in `tmp` before trgsw_to_DFT (src/bootstrap.c:14-18)
+ * -- uploads it and runs the engine's own forward transform over every polynomial
+ * (replaces trgsw_to_DFT, src/trgsw.c:345-349).  Synchronous. */
+int mosfhet_hip_bsk_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t *out, const uint64_t *h_bk,
+                           int n, int k, int N, int l, int Bg_bit);
+/* Same from a device-resident torus-domain key (e.g. generated on the GPU or received over xGMI). */
+int mosfhet_hip_bsk_create_from_device(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t *out, const uint64_t *d_bk,
+                                       int n, int k, int N, int l, int Bg_bit, void *stream);
+int mosfhet_hip_bsk_destroy(mosfhet_hip_bsk_t bsk);
+size_t mosfhet_hip_bsk_bytes(mosfhet_hip_bsk_t bsk);                     /* device bytes of the DFT key */
+/* Copy the DFT-domain key back in ORACLE slot order (natural recursion index, interleaved re/im),
+ * double[n][(k+1)l][k+1][N]; test hook only. */
+int mosfhet_hip_bsk_export_dft(mosfhet_hip_bsk_t bsk, double *h_out);
+
+/* programmable_bootstrap over a batch (src/bootstrap.c:208-220): for every b < count
+ *   d_out[b] = TLWE(kN) = SampleExtract_0( BlindRotate( tv_b * X^{-round(2N b'/2^64)}, a', BK ) )
+ * with (a', b') = ((x << kappa) + 2^(63-log2(2N)+theta)) & ~(2^(64-log2(2N)+theta) - 1) and
+ * torus_base = 2^(precision-1).  d_tv holds tv_count test vectors; tv_count == 1 shares one test
+ * vector across the batch (the reference's callers pass one LUT per call), tv_count == count gives
+ * each ciphertext its own. */
+int mosfhet_hip_programmable_bootstrap_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk,
+                                             uint64_t *d_out /*[count][kN+1]*/, const uint64_t *d_tv /*[tv_count][k+1][N]*/,
+                                             int tv_count, const uint64_t *d_in /*[count][n+1]*/, int count,
+                                             int precision, int kappa, int theta, void *stream);
+
+/* functional_bootstrap over a batch (src/bootstrap.c:200-206). */
+int mosfhet_hip_functional_bootstrap_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk,
+                                           uint64_t *d_out /*[count][kN+1]*/, const uint64_t *d_tv, int tv_count,
+                                           const uint64_t *d_in /*[count][n+1]*/, int count, int torus_base, void *stream);
+
+/* functional_bootstrap_wo_extract over a batch (src/bootstrap.c:192-198): writes the rotated TRLWE. */
+int mosfhet_hip_functional_bootstrap_wo_extract_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk,
+                                                      uint64_t *d_out /*[count][k+1][N]*/, const uint64_t *d_tv, int tv_count,
+                                                      const uint64_t *d_in, int count, int torus_base, void *stream);
+
+/* blind_rotate over a batch (src/bootstrap.c:107-122): d_acc[b] is rotated IN PLACE by the n mask
+ * words of d_in[b] (the b word of d_in is ignored). */
+int mosfhet_hip_blind_rotate_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_acc /*[count][k+1][N]*/,
+                                   const uint64_t *d_in /*[count][n+1]*/, int count, void *stream);
+
+/* trgsw_mul_trlwe_DFT + trlwe_from_DFT over a batch (src/trgsw.c:385-423, src/trlwe.c:629-634):
+ * d_out[b] = BK[key_index] (.) d_in[b], result back in the torus domain. */
+int mosfhet_hip_external_product_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, int key_index,
+                                       uint64_t *d_out /*[count][k+1][N]*/, const uint64_t *d_in /*[count][k+1][N]*/,
+                                       int count, void *stream);
+
+/* polynomial_torus_to_DFT / polynomial_DFT_to_torus / polynomial_mul_DFT / polynomial_mul_addto_DFT over
+ * flat arrays of polynomials (src/polynomial.c:359-426).  DFT polynomials are N doubles (N/2 complex,
+ * interleaved, engine slot order). */
+int mosfhet_hip_torus_to_dft_batch(mosfhet_hip_ctx_t ctx, double *d_out, const uint64_t *d_in, int N, int count, void *stream);
+int mosfhet_hip_dft_to_torus_batch(mosfhet_hip_ctx_t ctx, uint64_t *d_out, const double *d_in, int N, int count, void *stream);
+int mosfhet_hip_dft_mul_batch(mosfhet_hip_ctx_t ctx, double *d_out, const double *d_a, const double *d_b,
+                              int N, int count, int addto, void *stream);
+
+/* LWE key switch.  Key layout Torus[n_in][t][2^base_bit - 1][n_out + 1], entry [i][j][v-1] =
+ * TLWE_out(s_in[i] * v * 2^(64-(j+1)base_bit)) -- tlwe_new_KS_key's table (src/tlwe.c:193-212) flattened. */
+int mosfhet_hip_ksk_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t *out, const uint64_t *h_ksk,
+                           int n_in, int n_out, int t, int base_bit);
+int mosfhet_hip_ksk_destroy(mosfhet_hip_ksk_t ksk);
+/* tlwe_keyswitch over a batch (src/tlwe.c:289-303), bit-exact. */
+int mosfhet_hip_tlwe_keyswitch_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t ksk, uint64_t *d_out /*[count][n_out+1]*/,
+                                     const uint64_t *d_in /*[count][n_in+1]*/, int count, void *stream);
+
+/* Timing hook for bench.py: runs `reps` launches of the programmable-bootstrap kernel on `stream`
+ * bracketed by hipEvents ON THAT STREAM and returns the average kernel time in milliseconds
+ * (synchronises the stream). */
+int mosfhet_hip_time_programmable_bootstrap(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_out,
+                                            const uint64_t *d_tv, int tv_count, const uint64_t *d_in, int count,
+                                            int precision, int reps, void *stream, float *ms_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,69 @@
+"""Builds the in-tree native library mosfhet_amd/libmosfhet_hip.so for gfx950.
+
+hipcc cross-compiles without a GPU, so this runs in the CPU-only build container too.  The .so is
+git-ignored but travels to the GPU box with the snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmosfhet_hip.so")
+
+HIP_SOURCES = ["capi.hip"]
+HOST_C_SOURCES = ["host/mosfhet_compat.c"]
+DEPS = ["negacyclic_fft.h", "bootstrap_kernels.h", "keyswitch_kernels.h", "../../include/mosfhet_hip.h",
+        "../../include/mosfhet_compat.h"]
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value",
+               "-Wno-comment"]
+CC_FLAGS = ["-O2", "-std=gnu11", "-fPIC", "-ffp-contract=off", "-Wall"]
+
+
+def _hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    files = HIP_SOURCES + HOST_C_SOURCES + DEPS
+    return any(os.path.exists(os.path.join(CSRC, f)) and os.path.getmtime(os.path.join(CSRC, f)) > t for f in files)
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/*.hip (device + C ABI) and csrc/host/*.c (MOSFHET-compatible host layer) into one .so."""
+    if not force and not _stale():
+        return LIB
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    for src in HOST_C_SOURCES:
+        path = os.path.join(CSRC, src)
+        if not os.path.exists(path):
+            continue
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        cmd = ["gcc"] + CC_FLAGS + ["-I", os.path.join(HERE, "..", "include"), "-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    for src in HIP_SOURCES:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        cmd = [_hipcc()] + HIPCC_FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lm"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,447 @@
+// capi.hip -- C ABI of the gfx950 bootstrap engine (declared in include/mosfhet_hip.h).
+// Host-side glue only: argument checks, device buffers, kernel launches.  No CPU fallback: every compute
+// entry point fails with MOSFHET_HIP_ENODEV / MOSFHET_HIP_EHIP when the device path is unavailable.
+#include "../../include/mosfhet_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "bootstrap_kernels.h"
+#include "keyswitch_kernels.h"
+
+using namespace mosfhet;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(MOSFHET_HIP_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+struct mosfhet_hip_ctx {
+  int device;
+  d2 *tw1024;  // device twiddle table for N = 1024
+};
+
+struct mosfhet_hip_bsk {
+  mosfhet_hip_ctx_t ctx;
+  d2 *d_bk;  // [n][(k+1)l][k+1][P][lanes]
+  int n, k, N, l, Bg_bit;
+  size_t bytes;
+};
+
+struct mosfhet_hip_ksk {
+  mosfhet_hip_ctx_t ctx;
+  uint64_t *d_ksk;
+  int n_in, n_out, t, base_bit;
+  size_t bytes;
+};
+
+extern "C" const char *mosfhet_hip_last_error(void) { return g_err; }
+extern "C" const char *mosfhet_hip_version(void) { return "mosfhet_amd 0.1 (gfx950)"; }
+
+extern "C" int mosfhet_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// ---- twiddle table (same definition as oracle_fft.c:orc_fft_make_twiddles; own code) ----
+static unsigned bit_reverse(unsigned x, int bits) {
+  unsigned r = 0;
+  for (int i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; }
+  return r;
+}
+
+static void make_twiddles(int N, std::vector<double> &tw) {
+  const int M = N / 2;
+  int logM = 0;
+  while ((1 << logM) < M) logM++;
+  tw.assign(2 * (size_t)(M - 1), 0.0);
+  const long double two_pi = 6.283185307179586476925286766559005768L;
+  for (int lev = 0; lev < logM; lev++)
+    for (unsigned nu = 0; nu < (1u << lev); nu++) {
+      double *e = tw.data() + 2 * ((size_t)(1u << lev) - 1 + nu);
+      if (nu & 1) {  // i * sibling, exact
+        e[0] = -e[-1];
+        e[1] = e[-2];
+      } else {
+        const long double frac = (long double)(4 * bit_reverse(nu, lev) + 1) / (long double)(1ull << (lev + 3));
+        e[0] = (double)cosl(two_pi * frac);
+        e[1] = (double)sinl(two_pi * frac);
+      }
+    }
+}
+
+extern "C" int mosfhet_hip_twiddles(int N, double *h_out) {
+  if (N < 8 || (N & (N - 1)) || !h_out) return fail(MOSFHET_HIP_EINVAL, "twiddles: bad N=%d", N);
+  std::vector<double> tw;
+  make_twiddles(N, tw);
+  memcpy(h_out, tw.data(), tw.size() * sizeof(double));
+  return MOSFHET_HIP_OK;
+}
+
+extern "C" int mosfhet_hip_ctx_create(mosfhet_hip_ctx_t *out, int device) {
+  if (!out) return fail(MOSFHET_HIP_EINVAL, "ctx_create: null out");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(MOSFHET_HIP_ENODEV, "no HIP device visible (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(MOSFHET_HIP_EINVAL, "ctx_create: device %d of %d", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  mosfhet_hip_ctx *c = new mosfhet_hip_ctx();
+  c->device = device;
+  std::vector<double> tw;
+  make_twiddles(1024, tw);
+  HIP_TRY(hipMalloc((void **)&c->tw1024, tw.size() * sizeof(double)));
+  HIP_TRY(hipMemcpy(c->tw1024, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice));
+  *out = c;
+  return MOSFHET_HIP_OK;
+}
+
+extern "C" int mosfhet_hip_ctx_destroy(mosfhet_hip_ctx_t ctx) {
+  if (!ctx) return MOSFHET_HIP_OK;
+  hipSetDevice(ctx->device);
+  hipDeviceSynchronize();
+  hipFree(ctx->tw1024);
+  delete ctx;
+  return MOSFHET_HIP_OK;
+}
+
+// NULL means HIP's default (null) stream -- the same convention as every HIP API, and what torch hands out for
+// its default stream -- never a private stream, so work stays ordered with the caller's copies.
+static hipStream_t pick(mosfhet_hip_ctx_t, void *stream) { return (hipStream_t)stream; }
+
+extern "C" int mosfhet_hip_ctx_sync(mosfhet_hip_ctx_t ctx, void *stream) {
+  if (!ctx) return fail(MOSFHET_HIP_EINVAL, "ctx_sync: null ctx");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(pick(ctx, stream)));
+  return MOSFHET_HIP_OK;
+}
+
+static int check_params(const char *who, int k, int N, int l, int Bg_bit) {
+  if (k != 1) return fail(MOSFHET_HIP_EINVAL, "%s: only k = 1 is supported (got %d)", who, k);
+  if (N != 1024) return fail(MOSFHET_HIP_EINVAL, "%s: ring degree N = %d not supported yet (N = 1024)", who, N);
+  if (l < 1 || Bg_bit < 1 || l * Bg_bit >= 64) return fail(MOSFHET_HIP_EINVAL, "%s: bad gadget l=%d Bg_bit=%d", who, l, Bg_bit);
+  if (l != 1 && l != 2 && l != 3 && l != 4) return fail(MOSFHET_HIP_EINVAL, "%s: l = %d not instantiated (1..4)", who, l);
+  return MOSFHET_HIP_OK;
+}
+
+// ---- bootstrap key ----
+extern "C" int mosfhet_hip_bsk_create_from_device(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t *out, const uint64_t *d_bk,
+                                                  int n, int k, int N, int l, int Bg_bit, void *stream) {
+  if (!ctx || !out || !d_bk || n < 1) return fail(MOSFHET_HIP_EINVAL, "bsk_create: bad argument");
+  int rc = check_params("bsk_create", k, N, l, Bg_bit);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(ctx->device));
+  mosfhet_hip_bsk *b = new mosfhet_hip_bsk();
+  b->ctx = ctx; b->n = n; b->k = k; b->N = N; b->l = l; b->Bg_bit = Bg_bit;
+  const size_t polys = (size_t)n * (k + 1) * l * (k + 1);
+  b->bytes = polys * N * sizeof(double);
+  HIP_TRY(hipMalloc((void **)&b->d_bk, b->bytes));
+  hipLaunchKernelGGL(torus_to_dft_kernel_1024, dim3((unsigned)polys), dim3(64), 0, pick(ctx, stream), d_bk, b->d_bk, ctx->tw1024);
+  HIP_TRY(hipGetLastError());
+  *out = b;
+  return MOSFHET_HIP_OK;
+}
+
+extern "C" int mosfhet_hip_bsk_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t *out, const uint64_t *h_bk,
+                                      int n, int k, int N, int l, int Bg_bit) {
+  if (!ctx || !out || !h_bk || n < 1) return fail(MOSFHET_HIP_EINVAL, "bsk_create: bad argument");
+  int rc = check_params("bsk_create", k, N, l, Bg_bit);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t bytes = (size_t)n * (k + 1) * l * (k + 1) * N * sizeof(uint64_t);
+  uint64_t *d_tmp = nullptr;
+  HIP_TRY(hipMalloc((void **)&d_tmp, bytes));
+  hipError_t e = hipMemcpy(d_tmp, h_bk, bytes, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { hipFree(d_tmp); return fail(MOSFHET_HIP_EHIP, "bsk upload: %s", hipGetErrorString(e)); }
+  rc = mosfhet_hip_bsk_create_from_device(ctx, out, d_tmp, n, k, N, l, Bg_bit, nullptr);
+  hipStreamSynchronize(nullptr);
+  hipFree(d_tmp);
+  return rc;
+}
+
+extern "C" int mosfhet_hip_bsk_destroy(mosfhet_hip_bsk_t bsk) {
+  if (!bsk) return MOSFHET_HIP_OK;
+  hipSetDevice(bsk->ctx->device);
+  hipFree(bsk->d_bk);
+  delete bsk;
+  return MOSFHET_HIP_OK;
+}
+
+extern "C" size_t mosfhet_hip_bsk_bytes(mosfhet_hip_bsk_t bsk) { return bsk ? bsk->bytes : 0; }
+
+extern "C" int mosfhet_hip_bsk_export_dft(mosfhet_hip_bsk_t bsk, double *h_out) {
+  if (!bsk || !h_out) return fail(MOSFHET_HIP_EINVAL, "bsk_export: bad argument");
+  HIP_TRY(hipSetDevice(bsk->ctx->device));
+  std::vector<double> tmp(bsk->bytes / sizeof(double));
+  HIP_TRY(hipMemcpy(tmp.data(), bsk->d_bk, bsk->bytes, hipMemcpyDeviceToHost));
+  const int M = bsk->N / 2;
+  const size_t polys = bsk->bytes / sizeof(double) / bsk->N;
+  for (size_t q = 0; q < polys; q++)
+    for (int j = 0; j < M; j++) {  // oracle index j = lane*8 + m  <->  device index m*64 + lane
+      const int dev = (j & 7) * 64 + (j >> 3);
+      h_out[q * bsk->N + 2 * j] = tmp[q * bsk->N + 2 * dev];
+      h_out[q * bsk->N + 2 * j + 1] = tmp[q * bsk->N + 2 * dev + 1];
+    }
+  return MOSFHET_HIP_OK;
+}
+
+// ---- bootstrap launches ----
+template <int L>
+static void launch_pbs(const PbsParams &p, int count, hipStream_t s) {
+  hipLaunchKernelGGL(pbs_kernel_1024<L>, dim3((unsigned)count), dim3(64), 0, s, p);
+}
+
+static int launch_pbs_l(int l, const PbsParams &p, int count, hipStream_t s) {
+  switch (l) {
+    case 1: launch_pbs<1>(p, count, s); break;
+    case 2: launch_pbs<2>(p, count, s); break;
+    case 3: launch_pbs<3>(p, count, s); break;
+    case 4: launch_pbs<4>(p, count, s); break;
+    default: return fail(MOSFHET_HIP_EINVAL, "l = %d not instantiated", l);
+  }
+  HIP_TRY(hipGetLastError());
+  return MOSFHET_HIP_OK;
+}
+
+static int bootstrap_common(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_out,
+                            const uint64_t *d_tv, int tv_count, const uint64_t *d_in, int count, int pre, int kappa,
+                            int theta, int torus_base, int extract, int skip_init, void *stream) {
+  if (!ctx || !bsk || !d_out || !d_in || count < 0) return fail(MOSFHET_HIP_EINVAL, "%s: bad argument", who);
+  if (!skip_init && (!d_tv || (tv_count != 1 && tv_count != count)))
+    return fail(MOSFHET_HIP_EINVAL, "%s: tv_count must be 1 or count (got %d, count %d)", who, tv_count, count);
+  if (!skip_init && torus_base < 1) return fail(MOSFHET_HIP_EINVAL, "%s: torus_base %d", who, torus_base);
+  if (pre && (kappa < 0 || kappa > 63 || theta < 0 || theta > 52)) return fail(MOSFHET_HIP_EINVAL, "%s: kappa/theta out of range", who);
+  if (count == 0) return MOSFHET_HIP_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  PbsParams p;
+  p.bk = bsk->d_bk;
+  p.tw = ctx->tw1024;
+  p.in = d_in;
+  p.tv = d_tv;
+  p.out = d_out;
+  p.tv_stride = (tv_count == 1) ? 0 : (long long)(bsk->k + 1) * bsk->N;
+  p.n = bsk->n;
+  p.Bg_bit = bsk->Bg_bit;
+  p.pre = pre;
+  p.kappa = kappa;
+  p.theta = theta;
+  // src/misc.c:13-15 double2torus(1 / (4 torus_base))
+  p.prec_offset = skip_init ? 0 : (uint64_t)((int64_t)(18446744073709551616.0 * (1. / (4 * (double)torus_base))));
+  p.extract = extract;
+  p.skip_init = skip_init;
+  return launch_pbs_l(bsk->l, p, count, pick(ctx, stream));
+}
+
+extern "C" int mosfhet_hip_programmable_bootstrap_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_out,
+                                                        const uint64_t *d_tv, int tv_count, const uint64_t *d_in, int count,
+                                                        int precision, int kappa, int theta, void *stream) {
+  if (precision < 1 || precision > 30) return fail(MOSFHET_HIP_EINVAL, "programmable_bootstrap: precision %d", precision);
+  return bootstrap_common("programmable_bootstrap", ctx, bsk, d_out, d_tv, tv_count, d_in, count, 1, kappa, theta,
+                          1 << (precision - 1), 1, 0, stream);
+}
+
+extern "C" int mosfhet_hip_functional_bootstrap_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_out,
+                                                      const uint64_t *d_tv, int tv_count, const uint64_t *d_in, int count,
+                                                      int torus_base, void *stream) {
+  return bootstrap_common("functional_bootstrap", ctx, bsk, d_out, d_tv, tv_count, d_in, count, 0, 0, 0, torus_base, 1, 0, stream);
+}
+
+extern "C" int mosfhet_hip_functional_bootstrap_wo_extract_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_out,
+                                                                 const uint64_t *d_tv, int tv_count, const uint64_t *d_in,
+                                                                 int count, int torus_base, void *stream) {
+  return bootstrap_common("functional_bootstrap_wo_extract", ctx, bsk, d_out, d_tv, tv_count, d_in, count, 0, 0, 0, torus_base, 0, 0, stream);
+}
+
+extern "C" int mosfhet_hip_blind_rotate_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_acc,
+                                              const uint64_t *d_in, int count, void *stream) {
+  return bootstrap_common("blind_rotate", ctx, bsk, d_acc, nullptr, 0, d_in, count, 0, 0, 0, 1, 0, 1, stream);
+}
+
+// external product = one CMUX-less step: out = BK_i (.) in.  Implemented with the same device code.
+template <int L>
+__global__ __launch_bounds__(64) void external_product_kernel_1024(const d2 *__restrict__ bkrow, const d2 *__restrict__ tw,
+                                                                  const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
+                                                                  int Bg_bit) {
+  constexpr int N = 1024, M = 512;
+  __shared__ __attribute__((aligned(16))) uint64_t src[2][N];
+  __shared__ __attribute__((aligned(16))) d2 xch[512];
+  const int lane = threadIdx.x;
+  const uint64_t *ct = in + (size_t)blockIdx.x * 2 * N;
+  Fft1024 fft;
+  fft.init(tw, lane);
+  for (int c = 0; c < 2; c++)
+    for (int i = lane; i < N; i += 64) src[c][i] = ct[c * N + i];
+  wave_lds_sync();
+  uint64_t off = 1ull << (63 - L * Bg_bit);
+#pragma unroll
+  for (int i = 0; i < L; i++) off += 1ull << (63 - i * Bg_bit);
+  const uint64_t mask = (1ull << Bg_bit) - 1;
+  const int half = 1 << (Bg_bit - 1);
+  double o_re[2][8], o_im[2][8];
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int m = 0; m < 8; m++) { o_re[c][m] = 0.0; o_im[c][m] = 0.0; }
+#pragma unroll
+  for (int p = 0; p < 2; p++)
+#pragma unroll
+    for (int lv = 0; lv < L; lv++) {
+      const d2 *__restrict__ row = bkrow + (size_t)(p * L + lv) * (2 * M);
+      const int shift = 64 - (lv + 1) * Bg_bit;
+      double re[8], im[8];
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const int j = m * 64 + lane;
+        re[m] = (double)((int)(((src[p][j] + off) >> shift) & mask) - half);
+        im[m] = (double)((int)(((src[p][j + M] + off) >> shift) & mask) - half);
+      }
+      fft.forward(re, im, xch, lane);
+#pragma unroll
+      for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          const d2 kv = row[c * M + m * 64 + lane];
+          o_re[c][m] = __builtin_fma(-im[m], kv.y, __builtin_fma(re[m], kv.x, o_re[c][m]));
+          o_im[c][m] = __builtin_fma(im[m], kv.x, __builtin_fma(re[m], kv.y, o_im[c][m]));
+        }
+    }
+  const double scale = 0x1p-64 / (double)M;
+  uint64_t *dst = out + (size_t)blockIdx.x * 2 * N;
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    fft.inverse(o_re[c], o_im[c], xch, lane);
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      dst[c * N + m * 64 + lane] = round_mod_2_64(o_re[c][m], scale);
+      dst[c * N + m * 64 + lane + M] = round_mod_2_64(o_im[c][m], scale);
+    }
+  }
+}
+
+extern "C" int mosfhet_hip_external_product_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, int key_index, uint64_t *d_out,
+                                                  const uint64_t *d_in, int count, void *stream) {
+  if (!ctx || !bsk || !d_out || !d_in || count < 0 || key_index < 0 || key_index >= bsk->n)
+    return fail(MOSFHET_HIP_EINVAL, "external_product: bad argument");
+  if (count == 0) return MOSFHET_HIP_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  const d2 *row = bsk->d_bk + (size_t)key_index * (2 * bsk->l * 2 * 512);
+  hipStream_t s = pick(ctx, stream);
+  switch (bsk->l) {
+    case 1: hipLaunchKernelGGL(external_product_kernel_1024<1>, dim3(count), dim3(64), 0, s, row, ctx->tw1024, d_in, d_out, bsk->Bg_bit); break;
+    case 2: hipLaunchKernelGGL(external_product_kernel_1024<2>, dim3(count), dim3(64), 0, s, row, ctx->tw1024, d_in, d_out, bsk->Bg_bit); break;
+    case 3: hipLaunchKernelGGL(external_product_kernel_1024<3>, dim3(count), dim3(64), 0, s, row, ctx->tw1024, d_in, d_out, bsk->Bg_bit); break;
+    case 4: hipLaunchKernelGGL(external_product_kernel_1024<4>, dim3(count), dim3(64), 0, s, row, ctx->tw1024, d_in, d_out, bsk->Bg_bit); break;
+    default: return fail(MOSFHET_HIP_EINVAL, "l = %d not instantiated", bsk->l);
+  }
+  HIP_TRY(hipGetLastError());
+  return MOSFHET_HIP_OK;
+}
+
+// ---- polynomial-level entry points ----
+extern "C" int mosfhet_hip_torus_to_dft_batch(mosfhet_hip_ctx_t ctx, double *d_out, const uint64_t *d_in, int N, int count, void *stream) {
+  if (!ctx || !d_out || !d_in || count < 0) return fail(MOSFHET_HIP_EINVAL, "torus_to_dft: bad argument");
+  if (N != 1024) return fail(MOSFHET_HIP_EINVAL, "torus_to_dft: N = %d not supported yet", N);
+  if (count == 0) return MOSFHET_HIP_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(torus_to_dft_kernel_1024, dim3(count), dim3(64), 0, pick(ctx, stream), d_in, (d2 *)d_out, ctx->tw1024);
+  HIP_TRY(hipGetLastError());
+  return MOSFHET_HIP_OK;
+}
+
+extern "C" int mosfhet_hip_dft_to_torus_batch(mosfhet_hip_ctx_t ctx, uint64_t *d_out, const double *d_in, int N, int count, void *stream) {
+  if (!ctx || !d_out || !d_in || count < 0) return fail(MOSFHET_HIP_EINVAL, "dft_to_torus: bad argument");
+  if (N != 1024) return fail(MOSFHET_HIP_EINVAL, "dft_to_torus: N = %d not supported yet", N);
+  if (count == 0) return MOSFHET_HIP_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(dft_to_torus_kernel_1024, dim3(count), dim3(64), 0, pick(ctx, stream), (const d2 *)d_in, d_out, ctx->tw1024);
+  HIP_TRY(hipGetLastError());
+  return MOSFHET_HIP_OK;
+}
+
+extern "C" int mosfhet_hip_dft_mul_batch(mosfhet_hip_ctx_t ctx, double *d_out, const double *d_a, const double *d_b, int N,
+                                         int count, int addto, void *stream) {
+  if (!ctx || !d_out || !d_a || !d_b || count < 0 || N < 2) return fail(MOSFHET_HIP_EINVAL, "dft_mul: bad argument");
+  if (count == 0) return MOSFHET_HIP_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t total = (size_t)count * (N / 2);
+  hipLaunchKernelGGL(dft_mul_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, pick(ctx, stream), (d2 *)d_out,
+                     (const d2 *)d_a, (const d2 *)d_b, total, addto);
+  HIP_TRY(hipGetLastError());
+  return MOSFHET_HIP_OK;
+}
+
+// ---- LWE key switch ----
+extern "C" int mosfhet_hip_ksk_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t *out, const uint64_t *h_ksk, int n_in, int n_out,
+                                      int t, int base_bit) {
+  if (!ctx || !out || !h_ksk || n_in < 1 || n_out < 1 || t < 1 || base_bit < 1 || base_bit > 8 || t * base_bit >= 64)
+    return fail(MOSFHET_HIP_EINVAL, "ksk_create: bad argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  mosfhet_hip_ksk *k = new mosfhet_hip_ksk();
+  k->ctx = ctx; k->n_in = n_in; k->n_out = n_out; k->t = t; k->base_bit = base_bit;
+  k->bytes = (size_t)n_in * t * ((1u << base_bit) - 1) * (n_out + 1) * sizeof(uint64_t);
+  HIP_TRY(hipMalloc((void **)&k->d_ksk, k->bytes));
+  HIP_TRY(hipMemcpy(k->d_ksk, h_ksk, k->bytes, hipMemcpyHostToDevice));
+  *out = k;
+  return MOSFHET_HIP_OK;
+}
+
+extern "C" int mosfhet_hip_ksk_destroy(mosfhet_hip_ksk_t ksk) {
+  if (!ksk) return MOSFHET_HIP_OK;
+  hipSetDevice(ksk->ctx->device);
+  hipFree(ksk->d_ksk);
+  delete ksk;
+  return MOSFHET_HIP_OK;
+}
+
+extern "C" int mosfhet_hip_tlwe_keyswitch_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t ksk, uint64_t *d_out, const uint64_t *d_in,
+                                                int count, void *stream) {
+  if (!ctx || !ksk || !d_out || !d_in || count < 0) return fail(MOSFHET_HIP_EINVAL, "tlwe_keyswitch: bad argument");
+  if (count == 0) return MOSFHET_HIP_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  launch_tlwe_keyswitch(ksk->d_ksk, d_out, d_in, count, ksk->n_in, ksk->n_out, ksk->t, ksk->base_bit, pick(ctx, stream));
+  HIP_TRY(hipGetLastError());
+  return MOSFHET_HIP_OK;
+}
+
+// ---- timing hook ----
+extern "C" int mosfhet_hip_time_programmable_bootstrap(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_out,
+                                                       const uint64_t *d_tv, int tv_count, const uint64_t *d_in, int count,
+                                                       int precision, int reps, void *stream, float *ms_per_launch) {
+  if (!ms_per_launch || reps < 1) return fail(MOSFHET_HIP_EINVAL, "time_pbs: bad argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = pick(ctx, stream);
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e0, s));
+  for (int r = 0; r < reps; r++) {
+    int rc = mosfhet_hip_programmable_bootstrap_batch(ctx, bsk, d_out, d_tv, tv_count, d_in, count, precision, 0, 0, s);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipEventRecord(e1, s));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  *ms_per_launch = ms / (float)reps;
+  return MOSFHET_HIP_OK;
+}

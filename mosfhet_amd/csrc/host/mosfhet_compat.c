@@ -1,0 +1,615 @@
+/*
+ * mosfhet_compat.c -- host side (plain C) of the MOSFHET-compatible API, include/mosfhet_compat.h.
+ *
+ * Host-only work lives here: allocation, key and sample generation, phases, LUT packing, marshalling of the
+ * reference's pointer-based structs into the flat batches the device layer takes.  Everything on the hot path
+ * (bootstraps, key switch) is forwarded to the C ABI of include/mosfhet_hip.h -- there is no CPU implementation
+ * of those in this library.  Reference file:line citations are in the header next to each prototype.
+ */
+#define _GNU_SOURCE
+#include "mosfhet_compat.h"
+#include "mosfhet_hip.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* HIP runtime entry points used for staging buffers (declared here to keep this file plain C) */
+extern int hipMalloc(void **ptr, size_t size);
+extern int hipFree(void *ptr);
+extern int hipMemcpy(void *dst, const void *src, size_t size, int kind);
+#define HIP_H2D 1
+#define HIP_D2H 2
+
+#define W 64
+
+static void die(const char *what) {
+  fprintf(stderr, "mosfhet_amd: %s: %s\n", what, mosfhet_hip_last_error());
+  abort();
+}
+
+static void *xmalloc(size_t sz) {
+  void *p = NULL;
+  if (posix_memalign(&p, 64, sz ? sz : 64)) {
+    perror("mosfhet_amd: allocation failed");
+    exit(EXIT_FAILURE);
+  }
+  return p;
+}
+
+/* ------------------------------------------------------------------ engine singleton */
+static mosfhet_hip_ctx_t g_ctx = NULL;
+static int g_device = -1;
+
+void mosfhet_set_device(int device) {
+  if (g_ctx && device != g_device) {
+    fprintf(stderr, "mosfhet_amd: mosfhet_set_device after the engine was created\n");
+    abort();
+  }
+  g_device = device;
+}
+
+void *mosfhet_engine_ctx(void) {
+  if (!g_ctx) {
+    if (g_device < 0) {
+      const char *e = getenv("MOSFHET_HIP_DEVICE");
+      g_device = e ? atoi(e) : 0;
+    }
+    if (mosfhet_hip_ctx_create(&g_ctx, g_device)) die("engine start-up");
+  }
+  return g_ctx;
+}
+
+/* ------------------------------------------------------------------ randomness: xoshiro256** */
+static uint64_t g_rng[4];
+static int g_rng_ready = 0;
+
+static uint64_t splitmix(uint64_t *x) {
+  uint64_t z = (*x += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+void mosfhet_seed(uint64_t seed) {
+  for (int i = 0; i < 4; i++) g_rng[i] = splitmix(&seed);
+  g_rng_ready = 1;
+}
+
+static inline uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+
+static uint64_t rnd64(void) {
+  if (!g_rng_ready) {
+    uint64_t seed = 0;
+    FILE *f = fopen("/dev/urandom", "rb");
+    if (!f || fread(&seed, sizeof(seed), 1, f) != 1) seed = 0x4D4F5346ull;
+    if (f) fclose(f);
+    mosfhet_seed(seed);
+  }
+  const uint64_t r = rotl(g_rng[1] * 5, 7) * 9, t = g_rng[1] << 17;
+  g_rng[2] ^= g_rng[0];
+  g_rng[3] ^= g_rng[1];
+  g_rng[1] ^= g_rng[2];
+  g_rng[0] ^= g_rng[3];
+  g_rng[2] ^= t;
+  g_rng[3] = rotl(g_rng[3], 45);
+  return r;
+}
+
+static double rnd_normal(double sigma) { /* Box-Muller, as src/misc.c:87-91 */
+  const double u1 = ((double)(rnd64() >> 11) + 0.5) * 0x1p-53, u2 = ((double)(rnd64() >> 11) + 0.5) * 0x1p-53;
+  return cos(2. * M_PI * u1) * sqrt(-2. * log(u2)) * sigma;
+}
+
+/* ------------------------------------------------------------------ torus scalars */
+double torus2double(Torus x) { return (double)x / 18446744073709551616.0; }
+Torus double2torus(double x) { return (Torus)((int64_t)(18446744073709551616.0 * x)); }
+uint64_t torus2int(Torus x, int log_scale) { return (x + ((Torus)1 << (W - log_scale - 1))) >> (W - log_scale); }
+Torus int2torus(uint64_t x, int log_scale) { return x << (W - log_scale); }
+
+/* ------------------------------------------------------------------ polynomials */
+TorusPolynomial polynomial_new_torus_polynomial(int N) {
+  TorusPolynomial p = (TorusPolynomial)xmalloc(sizeof(*p));
+  p->coeffs = (Torus *)xmalloc(sizeof(Torus) * (size_t)N);
+  p->N = N;
+  return p;
+}
+
+void free_polynomial(void *p) {
+  if (!p) return;
+  free(((TorusPolynomial)p)->coeffs);
+  free(p);
+}
+
+/* exact negacyclic out += a * s; fast path for 0/1 coefficients of s */
+static void negacyclic_mul_addto(Torus *out, const Torus *a, const Torus *s, int N) {
+  for (int i = 0; i < N; i++) {
+    const Torus m = s[i];
+    if (!m) continue;
+    if (m == 1) {
+      for (int j = i; j < N; j++) out[j] += a[j - i];
+      for (int j = 0; j < i; j++) out[j] -= a[N + j - i];
+    } else {
+      for (int j = i; j < N; j++) out[j] += a[j - i] * m;
+      for (int j = 0; j < i; j++) out[j] -= a[N + j - i] * m;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ TLWE */
+TLWE_Key tlwe_alloc_key(int n, double sigma) {
+  TLWE_Key k = (TLWE_Key)xmalloc(sizeof(*k));
+  k->n = n;
+  k->sigma = sigma;
+  k->s = (Integer *)xmalloc(sizeof(Integer) * (size_t)n);
+  return k;
+}
+
+TLWE_Key tlwe_new_binary_key(int n, double sigma) {
+  TLWE_Key k = tlwe_alloc_key(n, sigma);
+  for (int i = 0; i < n; i++) k->s[i] = rnd64() & 1;
+  return k;
+}
+
+void free_tlwe_key(TLWE_Key key) {
+  if (!key) return;
+  free(key->s);
+  free(key);
+}
+
+TLWE tlwe_alloc_sample(int n) {
+  TLWE c = (TLWE)xmalloc(sizeof(*c));
+  c->a = (Torus *)xmalloc(sizeof(Torus) * (size_t)n);
+  c->n = n;
+  c->b = 0;
+  return c;
+}
+
+TLWE *tlwe_alloc_sample_array(int count, int n) {
+  TLWE *r = (TLWE *)xmalloc(sizeof(TLWE) * (size_t)count);
+  for (int i = 0; i < count; i++) r[i] = tlwe_alloc_sample(n);
+  return r;
+}
+
+void free_tlwe(TLWE p) {
+  if (!p) return;
+  free(p->a);
+  free(p);
+}
+
+void free_tlwe_array(TLWE *p, int count) {
+  for (int i = 0; i < count; i++) free_tlwe(p[i]);
+  free(p);
+}
+
+void tlwe_noiseless_trivial_sample(TLWE out, Torus m) {
+  memset(out->a, 0, sizeof(Torus) * (size_t)out->n);
+  out->b = m;
+}
+
+void mosfhet_tlwe_sample_flat(Torus *out, Torus m, TLWE_Key key) {
+  Torus b = m;
+  for (int i = 0; i < key->n; i++) {
+    out[i] = rnd64();
+    b += key->s[i] * out[i];
+  }
+  out[key->n] = b + double2torus(rnd_normal(key->sigma));
+}
+
+void tlwe_sample(TLWE out, Torus m, TLWE_Key key) {
+  Torus b = m;
+  for (int i = 0; i < key->n; i++) {
+    out->a[i] = rnd64();
+    b += key->s[i] * out->a[i];
+  }
+  out->b = b + double2torus(rnd_normal(key->sigma));
+}
+
+TLWE tlwe_new_sample(Torus m, TLWE_Key key) {
+  TLWE c = tlwe_alloc_sample(key->n);
+  tlwe_sample(c, m, key);
+  return c;
+}
+
+Torus tlwe_phase(TLWE c, TLWE_Key key) {
+  Torus acc = 0;
+  for (int i = 0; i < key->n; i++) acc += key->s[i] * c->a[i];
+  return c->b - acc;
+}
+
+void tlwe_copy(TLWE out, TLWE in) {
+  memcpy(out->a, in->a, sizeof(Torus) * (size_t)in->n);
+  out->b = in->b;
+}
+
+/* ------------------------------------------------------------------ TRLWE */
+TRLWE_Key trlwe_alloc_key(int N, int k, double sigma) {
+  TRLWE_Key key = (TRLWE_Key)xmalloc(sizeof(*key));
+  key->k = k;
+  key->sigma = sigma;
+  key->s = (IntPolynomial *)xmalloc(sizeof(IntPolynomial) * (size_t)k);
+  key->s_dft = NULL; /* DFT-domain data is device resident in this engine */
+  for (int i = 0; i < k; i++) key->s[i] = polynomial_new_torus_polynomial(N);
+  return key;
+}
+
+TRLWE_Key trlwe_new_binary_key(int N, int k, double sigma) {
+  TRLWE_Key key = trlwe_alloc_key(N, k, sigma);
+  for (int i = 0; i < k; i++)
+    for (int j = 0; j < N; j++) key->s[i]->coeffs[j] = rnd64() & 1;
+  return key;
+}
+
+void free_trlwe_key(TRLWE_Key key) {
+  if (!key) return;
+  for (int i = 0; i < key->k; i++) free_polynomial(key->s[i]);
+  free(key->s);
+  free(key);
+}
+
+TRLWE trlwe_alloc_new_sample(int k, int N) {
+  TRLWE c = (TRLWE)xmalloc(sizeof(*c));
+  c->a = (TorusPolynomial *)xmalloc(sizeof(TorusPolynomial) * (size_t)k);
+  for (int i = 0; i < k; i++) c->a[i] = polynomial_new_torus_polynomial(N);
+  c->b = polynomial_new_torus_polynomial(N);
+  c->k = k;
+  return c;
+}
+
+void free_trlwe(void *pv) {
+  TRLWE p = (TRLWE)pv;
+  if (!p) return;
+  for (int i = 0; i < p->k; i++) free_polynomial(p->a[i]);
+  free_polynomial(p->b);
+  free(p->a);
+  free(p);
+}
+
+void trlwe_noiseless_trivial_sample(TRLWE out, TorusPolynomial m) {
+  const int N = out->b->N;
+  for (int i = 0; i < out->k; i++) memset(out->a[i]->coeffs, 0, sizeof(Torus) * (size_t)N);
+  if (m) memcpy(out->b->coeffs, m->coeffs, sizeof(Torus) * (size_t)N);
+  else memset(out->b->coeffs, 0, sizeof(Torus) * (size_t)N);
+}
+
+TRLWE trlwe_new_noiseless_trivial_sample(TorusPolynomial m, int k, int N) {
+  TRLWE c = trlwe_alloc_new_sample(k, N);
+  trlwe_noiseless_trivial_sample(c, m);
+  return c;
+}
+
+void trlwe_sample(TRLWE out, TorusPolynomial m, TRLWE_Key key) {
+  const int N = key->s[0]->N;
+  for (int i = 0; i < key->k; i++)
+    for (int j = 0; j < N; j++) out->a[i]->coeffs[j] = rnd64();
+  for (int j = 0; j < N; j++) out->b->coeffs[j] = double2torus(rnd_normal(key->sigma));
+  for (int i = 0; i < key->k; i++) negacyclic_mul_addto(out->b->coeffs, out->a[i]->coeffs, key->s[i]->coeffs, N);
+  if (m)
+    for (int j = 0; j < N; j++) out->b->coeffs[j] += m->coeffs[j];
+}
+
+void trlwe_phase(TorusPolynomial out, TRLWE in, TRLWE_Key key) {
+  const int N = key->s[0]->N;
+  memset(out->coeffs, 0, sizeof(Torus) * (size_t)N);
+  for (int i = 0; i < in->k; i++) negacyclic_mul_addto(out->coeffs, in->a[i]->coeffs, key->s[i]->coeffs, N);
+  for (int j = 0; j < N; j++) out->coeffs[j] = in->b->coeffs[j] - out->coeffs[j];
+}
+
+void trlwe_torus_packing(TRLWE out, Torus *in, int size) {
+  const int N = out->b->N;
+  trlwe_noiseless_trivial_sample(out, NULL);
+  for (int i = 0; i < N; i++) out->b->coeffs[i] = in[i / (N / size)];
+}
+
+void trlwe_extract_tlwe_key(TLWE_Key out, TRLWE_Key in) {
+  const int N = in->s[0]->N;
+  for (int i = 0; i < in->k; i++) memcpy(out->s + (size_t)i * N, in->s[i]->coeffs, sizeof(Torus) * (size_t)N);
+}
+
+void trlwe_extract_tlwe(TLWE out, TRLWE in, int idx) {
+  const int N = in->b->N;
+  for (int p = 0; p < in->k; p++) {
+    const Torus *ap = in->a[p]->coeffs;
+    for (int j = 0; j <= idx; j++) out->a[p * N + j] = ap[idx - j];
+    for (int j = idx + 1; j < N; j++) out->a[p * N + j] = (Torus)0 - ap[N + idx - j];
+  }
+  out->b = in->b->coeffs[idx];
+}
+
+/* ------------------------------------------------------------------ TRGSW */
+TRGSW_Key trgsw_new_key(TRLWE_Key trlwe_key, int l, int Bg_bit) {
+  TRGSW_Key k = (TRGSW_Key)xmalloc(sizeof(*k));
+  k->trlwe_key = trlwe_key;
+  k->l = l;
+  k->Bg_bit = Bg_bit;
+  return k;
+}
+
+void free_trgsw_key(TRGSW_Key key) { free(key); }
+
+TRGSW trgsw_alloc_new_sample(int l, int Bg_bit, int k, int N) {
+  TRGSW g = (TRGSW)xmalloc(sizeof(*g));
+  g->samples = (TRLWE *)xmalloc(sizeof(TRLWE) * (size_t)l * (k + 1));
+  for (int i = 0; i < l * (k + 1); i++) g->samples[i] = trlwe_alloc_new_sample(k, N);
+  g->l = l;
+  g->Bg_bit = Bg_bit;
+  return g;
+}
+
+void free_trgsw(void *pv) {
+  TRGSW p = (TRGSW)pv;
+  if (!p) return;
+  const int rows = p->l * (p->samples[0]->k + 1);
+  for (int i = 0; i < rows; i++) free_trlwe(p->samples[i]);
+  free(p->samples);
+  free(p);
+}
+
+void trgsw_monomial_sample(TRGSW out, int64_t m, int e, TRGSW_Key key) {
+  const int l = key->l, k = key->trlwe_key->k, N = key->trlwe_key->s[0]->N;
+  if (e & N) m = -m;
+  e &= N - 1;
+  for (int q = 0; q < l * (k + 1); q++) trlwe_sample(out->samples[q], NULL, key->trlwe_key);
+  for (int j = 0; j < l; j++) {
+    const Torus h = (Torus)1 << (W - (j + 1) * key->Bg_bit);
+    for (int p = 0; p < k; p++) out->samples[p * l + j]->a[p]->coeffs[e] += (Torus)m * h;
+    out->samples[k * l + j]->b->coeffs[e] += (Torus)m * h;
+  }
+}
+
+/* ------------------------------------------------------------------ flat marshalling */
+static void trlwe_to_flat(Torus *flat, TRLWE c) {
+  const int N = c->b->N;
+  for (int p = 0; p < c->k; p++) memcpy(flat + (size_t)p * N, c->a[p]->coeffs, sizeof(Torus) * (size_t)N);
+  memcpy(flat + (size_t)c->k * N, c->b->coeffs, sizeof(Torus) * (size_t)N);
+}
+
+static void trlwe_from_flat(TRLWE c, const Torus *flat) {
+  const int N = c->b->N;
+  for (int p = 0; p < c->k; p++) memcpy(c->a[p]->coeffs, flat + (size_t)p * N, sizeof(Torus) * (size_t)N);
+  memcpy(c->b->coeffs, flat + (size_t)c->k * N, sizeof(Torus) * (size_t)N);
+}
+
+static void tlwe_array_to_flat(Torus *flat, TLWE *c, int count, int n) {
+  for (int i = 0; i < count; i++) {
+    memcpy(flat + (size_t)i * (n + 1), c[i]->a, sizeof(Torus) * (size_t)n);
+    flat[(size_t)i * (n + 1) + n] = c[i]->b;
+  }
+}
+
+static void tlwe_array_from_flat(TLWE *c, const Torus *flat, int count, int n) {
+  for (int i = 0; i < count; i++) {
+    memcpy(c[i]->a, flat + (size_t)i * (n + 1), sizeof(Torus) * (size_t)n);
+    c[i]->b = flat[(size_t)i * (n + 1) + n];
+  }
+}
+
+static void *dev_alloc(size_t bytes) {
+  void *p = NULL;
+  if (hipMalloc(&p, bytes ? bytes : 8)) {
+    fprintf(stderr, "mosfhet_amd: hipMalloc(%zu) failed\n", bytes);
+    abort();
+  }
+  return p;
+}
+
+static void dev_copy(void *dst, const void *src, size_t bytes, int kind) {
+  if (bytes && hipMemcpy(dst, src, bytes, kind)) {
+    fprintf(stderr, "mosfhet_amd: hipMemcpy failed\n");
+    abort();
+  }
+}
+
+/* ------------------------------------------------------------------ bootstrap key */
+void mosfhet_gen_bootstrap_key_flat(Torus *out, TRGSW_Key out_key, TLWE_Key in_key) {
+  const int l = out_key->l, k = out_key->trlwe_key->k, N = out_key->trlwe_key->s[0]->N;
+  const size_t row = (size_t)(k + 1) * N, sz = (size_t)(k + 1) * l * row;
+  TRGSW tmp = trgsw_alloc_new_sample(l, out_key->Bg_bit, k, N);
+  for (int i = 0; i < in_key->n; i++) {
+    trgsw_monomial_sample(tmp, (int64_t)in_key->s[i], 0, out_key);
+    for (int q = 0; q < (k + 1) * l; q++) trlwe_to_flat(out + (size_t)i * sz + q * row, tmp->samples[q]);
+  }
+  free_trgsw(tmp);
+}
+
+/* registry so that blind_rotate(tv, a, key->s, n) can find the key behind the `s` token */
+#define MAX_KEYS 64
+static Bootstrap_Key g_keys[MAX_KEYS];
+
+static void remember_key(Bootstrap_Key key) {
+  for (int i = 0; i < MAX_KEYS; i++)
+    if (g_keys[i] == key) return;
+  for (int i = 0; i < MAX_KEYS; i++)
+    if (!g_keys[i]) { g_keys[i] = key; return; }
+}
+
+static void forget_key(Bootstrap_Key key) {
+  for (int i = 0; i < MAX_KEYS; i++)
+    if (g_keys[i] == key) g_keys[i] = NULL;
+}
+
+/* Bootstrap_Key.s is an opaque token: a one-element array holding the device key handle. */
+void *mosfhet_bootstrap_key_device(Bootstrap_Key key) { return key && key->s ? (void *)key->s[0] : NULL; }
+
+Bootstrap_Key new_bootstrap_key(TRGSW_Key out_key, TLWE_Key in_key, int unfolding) {
+  if (unfolding != 1) {
+    fprintf(stderr, "mosfhet_amd: new_bootstrap_key: blind-rotate unfolding is not provided (unfolding = %d)\n", unfolding);
+    abort();
+  }
+  const int l = out_key->l, k = out_key->trlwe_key->k, N = out_key->trlwe_key->s[0]->N, n = in_key->n;
+  Bootstrap_Key res = (Bootstrap_Key)xmalloc(sizeof(*res));
+  res->n = n; res->k = k; res->l = l; res->N = N; res->Bg_bit = out_key->Bg_bit; res->unfolding = 1;
+  res->su = NULL;
+  const size_t words = (size_t)n * (k + 1) * l * (k + 1) * N;
+  Torus *flat = (Torus *)xmalloc(sizeof(Torus) * words);
+  mosfhet_gen_bootstrap_key_flat(flat, out_key, in_key);
+  mosfhet_hip_bsk_t dev = NULL;
+  if (mosfhet_hip_bsk_create((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, flat, n, k, N, l, out_key->Bg_bit)) die("new_bootstrap_key");
+  free(flat);
+  res->s = (TRGSW_DFT *)xmalloc(sizeof(TRGSW_DFT));
+  res->s[0] = (TRGSW_DFT)dev;
+  remember_key(res);
+  return res;
+}
+
+void free_bootstrap_key(Bootstrap_Key key) {
+  if (!key) return;
+  forget_key(key);
+  mosfhet_hip_bsk_destroy((mosfhet_hip_bsk_t)mosfhet_bootstrap_key_device(key));
+  free(key->s);
+  free(key);
+}
+
+/* ------------------------------------------------------------------ bootstraps (GPU) */
+enum { MODE_FUNCTIONAL, MODE_PROGRAMMABLE, MODE_WO_EXTRACT };
+
+static void bootstrap_many(int mode, TLWE *out, TRLWE out_trlwe, TRLWE tv, TLWE *in, int count, Bootstrap_Key key,
+                           int a0, int kappa, int theta) {
+  mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
+  mosfhet_hip_bsk_t bsk = (mosfhet_hip_bsk_t)mosfhet_bootstrap_key_device(key);
+  const int n = key->n, N = key->N, k = key->k;
+  const size_t in_w = (size_t)count * (n + 1), tv_w = (size_t)(k + 1) * N;
+  const size_t out_w = (mode == MODE_WO_EXTRACT) ? (size_t)count * tv_w : (size_t)count * (k * N + 1);
+  Torus *h = (Torus *)xmalloc(sizeof(Torus) * (in_w + tv_w + out_w));
+  tlwe_array_to_flat(h, in, count, n);
+  trlwe_to_flat(h + in_w, tv);
+  Torus *d = (Torus *)dev_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
+  dev_copy(d, h, sizeof(Torus) * (in_w + tv_w), HIP_H2D);
+  int rc;
+  if (mode == MODE_PROGRAMMABLE)
+    rc = mosfhet_hip_programmable_bootstrap_batch(ctx, bsk, d + in_w + tv_w, d + in_w, 1, d, count, a0, kappa, theta, NULL);
+  else if (mode == MODE_FUNCTIONAL)
+    rc = mosfhet_hip_functional_bootstrap_batch(ctx, bsk, d + in_w + tv_w, d + in_w, 1, d, count, a0, NULL);
+  else
+    rc = mosfhet_hip_functional_bootstrap_wo_extract_batch(ctx, bsk, d + in_w + tv_w, d + in_w, 1, d, count, a0, NULL);
+  if (rc || mosfhet_hip_ctx_sync(ctx, NULL)) die("bootstrap");
+  dev_copy(h + in_w + tv_w, d + in_w + tv_w, sizeof(Torus) * out_w, HIP_D2H);
+  if (mode == MODE_WO_EXTRACT) trlwe_from_flat(out_trlwe, h + in_w + tv_w);
+  else tlwe_array_from_flat(out, h + in_w + tv_w, count, k * N);
+  hipFree(d);
+  free(h);
+}
+
+void functional_bootstrap_batch(TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_Key key, int torus_base) {
+  bootstrap_many(MODE_FUNCTIONAL, out, NULL, tv, in, count, key, torus_base, 0, 0);
+}
+
+void programmable_bootstrap_batch(TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_Key key, int precision, int kappa, int theta) {
+  bootstrap_many(MODE_PROGRAMMABLE, out, NULL, tv, in, count, key, precision, kappa, theta);
+}
+
+void functional_bootstrap(TLWE out, TRLWE tv, TLWE in, Bootstrap_Key key, int torus_base) {
+  bootstrap_many(MODE_FUNCTIONAL, &out, NULL, tv, &in, 1, key, torus_base, 0, 0);
+}
+
+void programmable_bootstrap(TLWE out, TRLWE tv, TLWE in, Bootstrap_Key key, int precision, int kappa, int theta) {
+  bootstrap_many(MODE_PROGRAMMABLE, &out, NULL, tv, &in, 1, key, precision, kappa, theta);
+}
+
+void functional_bootstrap_wo_extract(TRLWE out, TRLWE tv, TLWE in, Bootstrap_Key key, int torus_base) {
+  bootstrap_many(MODE_WO_EXTRACT, NULL, out, tv, &in, 1, key, torus_base, 0, 0);
+}
+
+void blind_rotate(TRLWE tv, Torus *a, TRGSW_DFT *s, int size) {
+  Bootstrap_Key key = NULL;
+  for (int i = 0; i < MAX_KEYS; i++)
+    if (g_keys[i] && g_keys[i]->s == s) key = g_keys[i];
+  if (!key || size != key->n) {
+    fprintf(stderr, "mosfhet_amd: blind_rotate: `s` must be the .s member of a Bootstrap_Key made by new_bootstrap_key "
+                    "and size its n (device-resident key)\n");
+    abort();
+  }
+  mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
+  const int n = key->n, N = key->N, k = key->k;
+  const size_t acc_w = (size_t)(k + 1) * N;
+  Torus *h = (Torus *)xmalloc(sizeof(Torus) * (acc_w + n + 1));
+  trlwe_to_flat(h, tv);
+  memcpy(h + acc_w, a, sizeof(Torus) * (size_t)n);
+  h[acc_w + n] = 0;
+  Torus *d = (Torus *)dev_alloc(sizeof(Torus) * (acc_w + n + 1));
+  dev_copy(d, h, sizeof(Torus) * (acc_w + n + 1), HIP_H2D);
+  if (mosfhet_hip_blind_rotate_batch(ctx, (mosfhet_hip_bsk_t)mosfhet_bootstrap_key_device(key), d, d + acc_w, 1, NULL) ||
+      mosfhet_hip_ctx_sync(ctx, NULL))
+    die("blind_rotate");
+  dev_copy(h, d, sizeof(Torus) * acc_w, HIP_D2H);
+  trlwe_from_flat(tv, h);
+  hipFree(d);
+  free(h);
+}
+
+/* ------------------------------------------------------------------ LWE key switch */
+void mosfhet_gen_tlwe_ks_key_flat(Torus *out, TLWE_Key out_key, TLWE_Key in_key, int t, int base_bit) {
+  const int base = 1 << base_bit;
+  const size_t row = (size_t)out_key->n + 1;
+  for (int i = 0; i < in_key->n; i++)
+    for (int j = 0; j < t; j++)
+      for (int v = 1; v < base; v++)
+        mosfhet_tlwe_sample_flat(out + (((size_t)i * t + j) * (base - 1) + (v - 1)) * row,
+                                 in_key->s[i] * (Torus)v * ((Torus)1 << (W - (j + 1) * base_bit)), out_key);
+}
+
+TLWE_KS_Key tlwe_new_KS_key(TLWE_Key out_key, TLWE_Key in_key, int t, int base_bit) {
+  const int base = 1 << base_bit;
+  const size_t row = (size_t)out_key->n + 1, words = (size_t)in_key->n * t * (base - 1) * row;
+  TLWE_KS_Key res = (TLWE_KS_Key)xmalloc(sizeof(*res));
+  res->base_bit = base_bit;
+  res->t = t;
+  res->n = in_key->n;
+  Torus *flat = (Torus *)xmalloc(sizeof(Torus) * words);
+  mosfhet_gen_tlwe_ks_key_flat(flat, out_key, in_key, t, base_bit);
+  /* host view with the reference's shape s[i][j][v] (mosfhet.h:62-65): TLWE headers aliasing the flat table */
+  res->s = (TLWE ***)xmalloc(sizeof(TLWE **) * (size_t)in_key->n);
+  for (int i = 0; i < in_key->n; i++) {
+    res->s[i] = (TLWE **)xmalloc(sizeof(TLWE *) * (size_t)t);
+    for (int j = 0; j < t; j++) {
+      res->s[i][j] = (TLWE *)xmalloc(sizeof(TLWE) * (size_t)(base - 1));
+      for (int v = 0; v < base - 1; v++) {
+        Torus *r = flat + (((size_t)i * t + j) * (base - 1) + v) * row;
+        TLWE c = (TLWE)xmalloc(sizeof(*c));
+        c->a = r;
+        c->b = r[out_key->n];
+        c->n = out_key->n;
+        res->s[i][j][v] = c;
+      }
+    }
+  }
+  mosfhet_hip_ksk_t dev = NULL;
+  if (mosfhet_hip_ksk_create((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, flat, in_key->n, out_key->n, t, base_bit)) die("tlwe_new_KS_key");
+  res->device = dev;
+  return res;
+}
+
+void free_tlwe_ks_key(TLWE_KS_Key key) {
+  if (!key) return;
+  const int base = 1 << key->base_bit;
+  Torus *flat = key->s[0][0][0]->a;
+  for (int i = 0; i < key->n; i++) {
+    for (int j = 0; j < key->t; j++) {
+      for (int v = 0; v < base - 1; v++) free(key->s[i][j][v]);
+      free(key->s[i][j]);
+    }
+    free(key->s[i]);
+  }
+  free(key->s);
+  free(flat);
+  mosfhet_hip_ksk_destroy((mosfhet_hip_ksk_t)key->device);
+  free(key);
+}
+
+void tlwe_keyswitch_batch(TLWE *out, TLWE *in, int count, TLWE_KS_Key ks) {
+  mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
+  const int n_in = ks->n, n_out = out[0]->n;
+  const size_t in_w = (size_t)count * (n_in + 1), out_w = (size_t)count * (n_out + 1);
+  Torus *h = (Torus *)xmalloc(sizeof(Torus) * (in_w + out_w));
+  tlwe_array_to_flat(h, in, count, n_in);
+  Torus *d = (Torus *)dev_alloc(sizeof(Torus) * (in_w + out_w));
+  dev_copy(d, h, sizeof(Torus) * in_w, HIP_H2D);
+  if (mosfhet_hip_tlwe_keyswitch_batch(ctx, (mosfhet_hip_ksk_t)ks->device, d + in_w, d, count, NULL) || mosfhet_hip_ctx_sync(ctx, NULL))
+    die("tlwe_keyswitch");
+  dev_copy(h + in_w, d + in_w, sizeof(Torus) * out_w, HIP_D2H);
+  tlwe_array_from_flat(out, h + in_w, count, n_out);
+  hipFree(d);
+  free(h);
+}
+
+void tlwe_keyswitch(TLWE out, TLWE in, TLWE_KS_Key ks_key) { tlwe_keyswitch_batch(&out, &in, 1, ks_key); }

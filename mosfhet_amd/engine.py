@@ -1,0 +1,255 @@
+"""ctypes binding of the C ABI in include/mosfhet_hip.h.
+
+Torus64 buffers are torch.int64 CUDA tensors (same bits as uint64; torch has no full uint64 support).
+Every function launches on torch's current stream of the engine's device.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+# parameter sets of the reference's benchmarks (test/benchmark.c:53-54 and :64-75)
+PARAMS_SET1 = dict(n=585, N=1024, k=1, l=2, Bg_bit=8, t=5, base_bit=2,
+                   lwe_sigma=9.141776004202573e-5, rlwe_sigma=2.989040792967434e-8)
+PARAMS_LVL2 = dict(n=632, N=2048, k=1, l=4, Bg_bit=9, t=8, base_bit=4,
+                   lwe_sigma=2.0 ** -15, rlwe_sigma=2.0 ** -44)
+
+
+class MosfhetHipError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "libmosfhet_hip.so")
+
+
+def lib():
+    """Load the native library; fail loudly if it has not been built (no fallback path exists)."""
+    global _LIB
+    if _LIB is None:
+        # torch bundles its own HIP runtime (torch/lib/libamdhip64.so, same SONAME as /opt/rocm's).  Import it
+        # first so this process holds ONE runtime: loading ours first would bind torch to a second, mismatched
+        # runtime/HSA pair and the device disappears ("no HIP device visible").
+        import torch  # noqa: F401
+        path = lib_path()
+        if not os.path.exists(path):
+            raise MosfhetHipError(
+                "native library %s is missing: run `python -m mosfhet_amd.build` (or __graft_entry__.build())" % path)
+        L = C.CDLL(path)
+        L.mosfhet_hip_last_error.restype = C.c_char_p
+        L.mosfhet_hip_version.restype = C.c_char_p
+        L.mosfhet_hip_bsk_bytes.restype = C.c_size_t
+        L.mosfhet_hip_bsk_bytes.argtypes = [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        raise MosfhetHipError("mosfhet_hip error %d: %s" % (rc, lib().mosfhet_hip_last_error().decode()))
+
+
+def to_device(a, device):
+    """numpy uint64 array -> torch.int64 CUDA tensor with the same bits."""
+    import torch
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return torch.from_numpy(a.view(np.int64)).to(device)
+
+
+def to_numpy(t):
+    """torch.int64 tensor -> numpy uint64 array with the same bits."""
+    return t.detach().cpu().numpy().view(np.uint64)
+
+
+def _ptr(t):
+    assert t.is_cuda and t.is_contiguous(), "expected a contiguous CUDA tensor"
+    return C.c_void_p(t.data_ptr())
+
+
+class BootstrapKey:
+    def __init__(self, engine, handle, n, k, N, l, Bg_bit):
+        self.engine, self.h = engine, handle
+        self.n, self.k, self.N, self.l, self.Bg_bit = n, k, N, l, Bg_bit
+
+    @property
+    def nbytes(self):
+        return lib().mosfhet_hip_bsk_bytes(self.h)
+
+    def export_dft(self):
+        out = np.empty((self.n, (self.k + 1) * self.l, self.k + 1, self.N), dtype=np.float64)
+        _check(lib().mosfhet_hip_bsk_export_dft(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def free(self):
+        if self.h:
+            lib().mosfhet_hip_bsk_destroy(self.h)
+            self.h = None
+
+
+class KeySwitchKey:
+    def __init__(self, engine, handle, n_in, n_out, t, base_bit):
+        self.engine, self.h = engine, handle
+        self.n_in, self.n_out, self.t, self.base_bit = n_in, n_out, t, base_bit
+
+    def free(self):
+        if self.h:
+            lib().mosfhet_hip_ksk_destroy(self.h)
+            self.h = None
+
+
+class Engine:
+    """One engine per (process, GPU): wraps mosfhet_hip_ctx_t."""
+
+    def __init__(self, device=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise MosfhetHipError("no GPU visible: mosfhet_amd has no CPU fallback")
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        self.h = C.c_void_p()
+        _check(lib().mosfhet_hip_ctx_create(C.byref(self.h), int(device)))
+
+    def close(self):
+        if self.h:
+            lib().mosfhet_hip_ctx_destroy(self.h)
+            self.h = None
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def empty(self, *shape):
+        return self.torch.empty(*shape, dtype=self.torch.int64, device=self.device)
+
+    # ---- keys ----
+    def load_bootstrap_key(self, bk_torus, k, l, Bg_bit):
+        """bk_torus: numpy uint64 [n][(k+1)l][k+1][N] (torus domain) -> device DFT key."""
+        bk_torus = np.ascontiguousarray(bk_torus, dtype=np.uint64)
+        n, rows, k1, N = bk_torus.shape
+        assert rows == (k + 1) * l and k1 == k + 1
+        h = C.c_void_p()
+        _check(lib().mosfhet_hip_bsk_create(self.h, C.byref(h), bk_torus.ctypes.data_as(C.c_void_p), n, k, N, l, Bg_bit))
+        return BootstrapKey(self, h, n, k, N, l, Bg_bit)
+
+    def load_bootstrap_key_device(self, d_bk, k, l, Bg_bit):
+        n, rows, k1, N = d_bk.shape
+        h = C.c_void_p()
+        _check(lib().mosfhet_hip_bsk_create_from_device(self.h, C.byref(h), _ptr(d_bk), n, k, N, l, Bg_bit, self._stream()))
+        self.torch.cuda.current_stream(self.device).synchronize()
+        return BootstrapKey(self, h, n, k, N, l, Bg_bit)
+
+    def load_keyswitch_key(self, ksk, base_bit):
+        ksk = np.ascontiguousarray(ksk, dtype=np.uint64)
+        n_in, t, per_j, row = ksk.shape
+        assert per_j == (1 << base_bit) - 1
+        h = C.c_void_p()
+        _check(lib().mosfhet_hip_ksk_create(self.h, C.byref(h), ksk.ctypes.data_as(C.c_void_p), n_in, row - 1, t, base_bit))
+        return KeySwitchKey(self, h, n_in, row - 1, t, base_bit)
+
+    # ---- bootstraps ----
+    def _tv(self, tv, bsk, count):
+        assert tv.dim() == 3 and tv.shape[1] == bsk.k + 1 and tv.shape[2] == bsk.N, tv.shape
+        assert tv.shape[0] in (1, count)
+        return tv.shape[0]
+
+    def programmable_bootstrap(self, bsk, tv, ct, precision, kappa=0, theta=0, out=None):
+        count = ct.shape[0]
+        assert ct.shape[1] == bsk.n + 1
+        if out is None:
+            out = self.empty(count, bsk.k * bsk.N + 1)
+        _check(lib().mosfhet_hip_programmable_bootstrap_batch(self.h, bsk.h, _ptr(out), _ptr(tv), self._tv(tv, bsk, count),
+                                                              _ptr(ct), count, precision, kappa, theta, self._stream()))
+        return out
+
+    def functional_bootstrap(self, bsk, tv, ct, torus_base, out=None):
+        count = ct.shape[0]
+        assert ct.shape[1] == bsk.n + 1
+        if out is None:
+            out = self.empty(count, bsk.k * bsk.N + 1)
+        _check(lib().mosfhet_hip_functional_bootstrap_batch(self.h, bsk.h, _ptr(out), _ptr(tv), self._tv(tv, bsk, count),
+                                                            _ptr(ct), count, torus_base, self._stream()))
+        return out
+
+    def functional_bootstrap_wo_extract(self, bsk, tv, ct, torus_base, out=None):
+        count = ct.shape[0]
+        if out is None:
+            out = self.empty(count, bsk.k + 1, bsk.N)
+        _check(lib().mosfhet_hip_functional_bootstrap_wo_extract_batch(
+            self.h, bsk.h, _ptr(out), _ptr(tv), self._tv(tv, bsk, count), _ptr(ct), count, torus_base, self._stream()))
+        return out
+
+    def blind_rotate_(self, bsk, acc, ct):
+        """In place: acc[b] <- blind_rotate(acc[b], ct[b].a, BK)."""
+        count = ct.shape[0]
+        assert acc.shape == (count, bsk.k + 1, bsk.N)
+        _check(lib().mosfhet_hip_blind_rotate_batch(self.h, bsk.h, _ptr(acc), _ptr(ct), count, self._stream()))
+        return acc
+
+    def external_product(self, bsk, key_index, ct, out=None):
+        count = ct.shape[0]
+        if out is None:
+            out = self.empty(count, bsk.k + 1, bsk.N)
+        _check(lib().mosfhet_hip_external_product_batch(self.h, bsk.h, key_index, _ptr(out), _ptr(ct), count, self._stream()))
+        return out
+
+    # ---- polynomial level ----
+    def torus_to_dft(self, polys):
+        count, N = polys.shape
+        out = self.torch.empty(count, N, dtype=self.torch.float64, device=self.device)
+        _check(lib().mosfhet_hip_torus_to_dft_batch(self.h, _ptr(out), _ptr(polys), N, count, self._stream()))
+        return out
+
+    def dft_to_torus(self, dfts):
+        count, N = dfts.shape
+        out = self.empty(count, N)
+        _check(lib().mosfhet_hip_dft_to_torus_batch(self.h, _ptr(out), _ptr(dfts), N, count, self._stream()))
+        return out
+
+    def dft_mul(self, a, b, out=None, addto=False):
+        count, N = a.shape
+        if out is None:
+            assert not addto
+            out = self.torch.empty_like(a)
+        _check(lib().mosfhet_hip_dft_mul_batch(self.h, _ptr(out), _ptr(a), _ptr(b), N, count, int(addto), self._stream()))
+        return out
+
+    # ---- key switch ----
+    def tlwe_keyswitch(self, ksk, ct, out=None):
+        count = ct.shape[0]
+        assert ct.shape[1] == ksk.n_in + 1
+        if out is None:
+            out = self.empty(count, ksk.n_out + 1)
+        _check(lib().mosfhet_hip_tlwe_keyswitch_batch(self.h, ksk.h, _ptr(out), _ptr(ct), count, self._stream()))
+        return out
+
+    # ---- measurement ----
+    def time_programmable_bootstrap(self, bsk, tv, ct, precision, reps, out=None):
+        """Average milliseconds per kernel launch, hipEvents on the launch stream."""
+        count = ct.shape[0]
+        if out is None:
+            out = self.empty(count, bsk.k * bsk.N + 1)
+        ms = C.c_float()
+        _check(lib().mosfhet_hip_time_programmable_bootstrap(self.h, bsk.h, _ptr(out), _ptr(tv), self._tv(tv, bsk, count),
+                                                             _ptr(ct), count, precision, reps, self._stream(), C.byref(ms)))
+        return ms.value
+
+    def sync(self):
+        self.torch.cuda.current_stream(self.device).synchronize()
+
+
+def twiddles(N):
+    out = np.empty(2 * (N // 2 - 1), dtype=np.float64)
+    _check(lib().mosfhet_hip_twiddles(N, out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def slot_order_to_oracle(dft, N):
+    """Engine slot order (index m*64 + lane) -> oracle order (index lane*8 + m) for N = 1024 polynomials."""
+    assert N == 1024
+    M = N // 2
+    j = np.arange(M)
+    dev = (j & 7) * 64 + (j >> 3)
+    z = dft.reshape(-1, M, 2)
+    return z[:, dev, :].reshape(dft.shape)
