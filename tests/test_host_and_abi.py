@@ -1,0 +1,100 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every symbol the headers declare, the
+MOSFHET-compatible host layer (key / sample generation, phases, packing) is correct, and compute calls fail
+loudly without a GPU (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}]*\)\s*;", text)
+    return sorted(set(n for n in names if n not in ("defined",)))
+
+
+@pytest.mark.parametrize("header", ["mosfhet_hip.h", "mosfhet_compat.h"])
+def test_library_exports_every_declared_symbol(native_lib, header):
+    names = declared_functions(header)
+    assert len(names) > 15, names
+    missing = [n for n in names if not hasattr(native_lib, n)]
+    assert not missing, "declared in include/%s but not exported by libmosfhet_hip.so: %s" % (header, missing)
+
+
+def test_no_cpu_fallback(native_lib):
+    import torch
+    import mosfhet_amd as ma
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(ma.MosfhetHipError):
+        ma.Engine(0)
+    import ctypes as C
+    h = C.c_void_p()
+    assert native_lib.mosfhet_hip_ctx_create(C.byref(h), 0) != 0
+    assert b"no HIP device" in native_lib.mosfhet_hip_last_error() or b"failed" in native_lib.mosfhet_hip_last_error()
+
+
+def test_product_does_not_reference_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/."""
+    pkg = os.path.join(ROOT, "mosfhet_amd")
+    for d, _, files in os.walk(pkg):
+        if os.path.basename(d) in ("build", "__pycache__"):
+            continue
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hip")):
+                text = open(os.path.join(d, f), errors="ignore").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle|#include\s+[\"<].*oracle|liboracle", text, flags=re.M), \
+                    os.path.join(d, f)
+
+
+def test_twiddles_match_oracle(native_lib, oracle):
+    from mosfhet_amd import engine
+    for N in (512, 1024, 2048, 4096):
+        assert (engine.twiddles(N) == oracle.plan(N).twiddles()).all(), N
+
+
+def test_host_keygen_decrypts_under_the_oracle(native_lib, oracle):
+    """Keys and samples from the product's seeded host generator are valid TFHE objects: TRGSW rows decrypt to the
+    gadget, TLWE samples to their message, and the LWE key-switch key to s_i * v * 2^(64-(j+1)bb)."""
+    from mosfhet_amd import host
+    host.seed(42)
+    n, N, l, Bg = 6, 1024, 2, 8
+    lk, rk = host.LweKey(n, 2.0 ** -30), host.RlweKey(N, 1, 2.0 ** -40)
+    assert set(np.unique(lk.s)) <= {0, 1} and set(np.unique(rk.s)) <= {0, 1}
+    bk = host.gen_bootstrap_key(rk, lk, l, Bg)
+    assert bk.shape == (n, 2 * l, 2, N)
+    for i in range(n):
+        for p in range(2):
+            for j in range(l):
+                ph = oracle.trlwe_phase(np.ascontiguousarray(bk[i, p * l + j]), rk.s)
+                want = np.zeros(N, dtype=np.uint64)
+                # row p*l+j carries s_i * 2^(64-(j+1)Bg) on component p: phase = -s*(that) for p = a, +that for p = b
+                h = (int(lk.s[i]) << (64 - (j + 1) * Bg)) % 2 ** 64
+                if p == 1:
+                    want[0] = h
+                    assert oracle.torus_dist(ph, want).max() < 2.0 ** 30
+                else:
+                    neg_s = (np.uint64(0) - rk.s[0] * np.uint64(h))
+                    assert oracle.torus_dist(ph, neg_s).max() < 2.0 ** 30
+    msgs = [host.double2torus(m / 8.0) for m in range(8)]
+    cts = host.tlwe_samples(msgs, lk)
+    assert oracle.torus_dist(host.tlwe_phase(cts, lk.s), np.array(msgs, dtype=np.uint64)).max() < 2.0 ** 40
+    assert (host.tlwe_phase(cts, lk.s) == np.array([oracle.tlwe_phase(c, lk.s) for c in cts], dtype=np.uint64)).all()
+    out_key = rk.extracted_lwe_key()
+    assert (out_key.s == rk.s.reshape(-1)).all()
+    ksk = host.gen_tlwe_ks_key(lk, out_key, 3, 2)
+    assert ksk.shape == (N, 3, 3, n + 1)
+    for i in (0, 5, N - 1):
+        for j in range(3):
+            for v in (1, 2, 3):
+                want = (int(out_key.s[i]) * v << (64 - (j + 1) * 2)) % 2 ** 64
+                assert oracle.torus_dist(oracle.tlwe_phase(np.ascontiguousarray(ksk[i, j, v - 1]), lk.s), want) < 2.0 ** 40
+    lut = np.array([1, 2, 3, 4], dtype=np.uint64)
+    assert (host.torus_packing(lut, 1, N) == oracle.trlwe_torus_packing(lut, 1, N)).all()
+    # seeded generator is reproducible
+    host.seed(42)
+    assert (host.LweKey(n, 2.0 ** -30).s == lk.s).all()

@@ -1,0 +1,88 @@
+"""Live comparison of the oracle with the reference build in oracle/_ref (compiled from /root/reference by
+oracle/ref/Makefile; the .so travels with the snapshot).  Skipped where that build product is absent.
+Fresh random inputs every run (seeded from the test id), complementing the fixed golden vectors."""
+import numpy as np
+import pytest
+
+from oracle import reflib
+
+BACKENDS = [b for b in ("avx512", "ffnt") if reflib.available(b)]
+pytestmark = pytest.mark.skipif(not BACKENDS, reason="oracle/_ref not built (needs /root/reference)")
+
+
+@pytest.fixture(params=BACKENDS)
+def ref(request):
+    r = reflib.get(request.param)
+    r.init(1024)
+    r.init(2048)
+    return r
+
+
+def test_integer_ops_random(oracle, ref):
+    rng = oracle.Rng(0xABC)
+    for N, Bg, l in ((1024, 8, 2), (2048, 9, 4), (1024, 23, 1), (512, 6, 3)):
+        p, acc = oracle.u64(rng.words(N)), oracle.u64(rng.words(N))
+        for i in range(l):
+            assert (ref.poly_decompose_i(p, Bg, l, i) == oracle.poly_decompose_i(p, Bg, l, i)).all()
+        assert (ref.poly_decompose(p, Bg, l) == oracle.poly_decompose(p, Bg, l)).all()
+        for a in [0, 1, N - 1, N, N + 1, 2 * N - 1] + [int(x % (4 * N)) for x in rng.words(6)]:
+            assert (ref.poly_mul_by_xai(p, a, 0) == oracle.poly_mul_by_xai(p, a)).all()
+            assert (ref.poly_mul_by_xai(p, a, 2) == oracle.poly_mul_by_xai_minus_1(p, a)).all()
+            assert (ref.poly_mul_by_xai(p, a, 1, acc=acc) == oracle.poly_mul_by_xai_addto(acc, p, a)).all()
+        for gen in (1, 3, 2 * N - 1, int(rng.next() % (2 * N)) | 1):
+            assert (ref.poly_permute(p, gen) == oracle.poly_permute(p, gen)).all()
+        c = oracle.u64(rng.words(2 * N)).reshape(2, N)
+        for idx in (0, N // 3, N - 1):
+            assert (ref.trlwe_extract_tlwe(c, idx) == oracle.trlwe_extract_tlwe(c, idx)).all()
+    for x in rng.words(32):
+        for ls in (10, 11, 12):
+            assert ref.torus2int(x, ls) == oracle.torus2int(x, ls)
+
+
+def test_fft_and_external_product_random(oracle, ref):
+    rng = oracle.Rng(0xDEF)
+    for N, l, Bg, sigma in ((1024, 2, 8, 2.98e-8), (2048, 4, 9, 2.0 ** -44)):
+        a = oracle.u64(rng.words(N))
+        b = (oracle.u64(rng.words(N)) % np.uint64(1024)) - np.uint64(512)
+        exact = oracle.poly_naive_mul(a, b)
+        assert (ref.poly_naive_mul(a, b) == exact).all()
+        assert oracle.torus_dist(oracle.poly_mul_fft(a, b), exact).max() < 2.0 ** 40
+        assert oracle.torus_dist(oracle.poly_mul_fft(a, b), ref.poly_mul_fft(a, b)).max() < 2.0 ** 32
+        s = oracle.gen_binary_key(rng, N).reshape(1, N)
+        g = oracle.trgsw_monomial_sample(rng, 1, 7, s, l, Bg, sigma)
+        c = oracle.trlwe_sample(rng, a, s, sigma)
+        mine = oracle.external_product(c, oracle.trgsw_to_dft(g, 1, l), l, Bg)
+        assert oracle.torus_dist(mine, ref.external_product(c, g, l, Bg)).max() < 2.0 ** 32
+
+
+def test_keyswitch_random(oracle, ref):
+    rng = oracle.Rng(0x123)
+    n_in, n_out, t, bb = 80, 20, 5, 2
+    s_in, s_out = oracle.gen_binary_key(rng, n_in), oracle.gen_binary_key(rng, n_out)
+    ksk = oracle.gen_tlwe_ks_key(rng, s_in, s_out, t, bb, 2.0 ** -40)
+    h = ref.ksk_new(ksk, bb)
+    for m in range(5):
+        c = oracle.tlwe_sample(rng, oracle.double2torus(m / 8.0), s_in, 2.0 ** -40)
+        assert (ref.tlwe_keyswitch(c, h, n_out) == oracle.tlwe_keyswitch(c, ksk, n_out, t, bb)).all()
+    ref.ksk_free(h)
+
+
+def test_blind_rotate_and_bootstrap_short_key(oracle, ref):
+    """n = 12 CMUX steps at SET_1 ring parameters: ciphertext-level agreement (no divergence yet)."""
+    rng = oracle.Rng(0x777)
+    N, l, Bg, sigma, n = 1024, 2, 8, 2.98e-8, 12
+    lwe_s = oracle.gen_binary_key(rng, n)
+    rlwe_s = oracle.gen_binary_key(rng, N).reshape(1, N)
+    bk = oracle.gen_bootstrap_key(rng, lwe_s, rlwe_s, l, Bg, sigma)
+    bk_dft = oracle.bk_to_dft(bk, 1, l)
+    h = ref.bk_new(bk, 1, l, Bg)
+    tv = oracle.trlwe_torus_packing(oracle.u64(rng.words(4)), 1, N)
+    c = oracle.tlwe_sample(rng, oracle.double2torus(0.125), lwe_s, 9.1e-5)
+    acc = oracle.u64(rng.words(2 * N)).reshape(2, N)
+    a = np.ascontiguousarray(c[:-1])
+    assert oracle.torus_dist(oracle.blind_rotate(acc, a, bk_dft, l, Bg), ref.blind_rotate(acc, a, h)).max() < 2.0 ** 38
+    got = oracle.programmable_bootstrap(tv, c, bk_dft, l, Bg, 3, 0, 0)
+    assert oracle.torus_dist(got, ref.programmable_bootstrap(tv, c, h, 3, 0, 0)).max() < 2.0 ** 38
+    got = oracle.programmable_bootstrap(tv, c, bk_dft, l, Bg, 4, 2, 1)
+    assert oracle.torus_dist(got, ref.programmable_bootstrap(tv, c, h, 4, 2, 1)).max() < 2.0 ** 38
+    ref.bk_free(h)
