@@ -204,19 +204,21 @@ extern "C" int mosfhet_hip_bsk_export_dft(mosfhet_hip_bsk_t bsk, double *h_out) 
 }
 
 // ---- bootstrap launches ----
-template <int L>
+template <int L, int BG>
 static void launch_pbs(const PbsParams &p, int count, hipStream_t s) {
-  hipLaunchKernelGGL(pbs_kernel_1024<L>, dim3((unsigned)count), dim3(64), 0, s, p);
+  hipLaunchKernelGGL((pbs_kernel_1024<L, BG>), dim3((unsigned)count), dim3(64), 0, s, p);
 }
 
-static int launch_pbs_l(int l, const PbsParams &p, int count, hipStream_t s) {
-  switch (l) {
-    case 1: launch_pbs<1>(p, count, s); break;
-    case 2: launch_pbs<2>(p, count, s); break;
-    case 3: launch_pbs<3>(p, count, s); break;
-    case 4: launch_pbs<4>(p, count, s); break;
-    default: return fail(MOSFHET_HIP_EINVAL, "l = %d not instantiated", l);
-  }
+// Gadget bases of the reference's parameter sets get a compile-time instantiation (test/benchmark.c:53-75,
+// test/tests.c:37-62); anything else runs the run-time-Bg variant.
+static int launch_pbs_l(int l, int Bg_bit, const PbsParams &p, int count, hipStream_t s) {
+  if (l == 2 && Bg_bit == 8) launch_pbs<2, 8>(p, count, s);
+  else if (l == 4 && Bg_bit == 9) launch_pbs<4, 9>(p, count, s);
+  else if (l == 1) launch_pbs<1, 0>(p, count, s);
+  else if (l == 2) launch_pbs<2, 0>(p, count, s);
+  else if (l == 3) launch_pbs<3, 0>(p, count, s);
+  else if (l == 4) launch_pbs<4, 0>(p, count, s);
+  else return fail(MOSFHET_HIP_EINVAL, "l = %d not instantiated", l);
   HIP_TRY(hipGetLastError());
   return MOSFHET_HIP_OK;
 }
@@ -247,7 +249,7 @@ static int bootstrap_common(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hip_
   p.prec_offset = skip_init ? 0 : (uint64_t)((int64_t)(18446744073709551616.0 * (1. / (4 * (double)torus_base))));
   p.extract = extract;
   p.skip_init = skip_init;
-  return launch_pbs_l(bsk->l, p, count, pick(ctx, stream));
+  return launch_pbs_l(bsk->l, bsk->Bg_bit, p, count, pick(ctx, stream));
 }
 
 extern "C" int mosfhet_hip_programmable_bootstrap_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_out,
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(64) void external_product_kernel_1024(const d2 *__r
                                                                   int Bg_bit) {
   constexpr int N = 1024, M = 512;
   __shared__ __attribute__((aligned(16))) uint64_t src[2][N];
-  __shared__ __attribute__((aligned(16))) d2 xch[512];
+  __shared__ __attribute__((aligned(16))) d2 xch[Fft1024::XCH_SLOTS];
   const int lane = threadIdx.x;
   const uint64_t *ct = in + (size_t)blockIdx.x * 2 * N;
   Fft1024 fft;

@@ -16,8 +16,8 @@
 //     pass A: register = j[8:6], lane = j[5:0]                 levels 0-2, twiddles in SGPRs
 //     pass B: register = j[5:3], lane = (j[8:6], j[2:0])       levels 3-5, 4 twiddles per lane
 //     pass C: register = j[2:0], lane = j[8:3]                 levels 6-8, 4 twiddles per lane
-// with two LDS transposes (ds_write_b128 / ds_read_b128, XOR-swizzled so both sides are
-// bank-conflict free under the gfx950 lane-group rules; tools/lds_conflicts.py checks them).
+// with two LDS transposes (ds_write_b128 / ds_read_b128 through padded layouts that are bank-conflict free on
+// both sides under the gfx950 lane-group rules and addressable as lane base + immediate; tools/lds_conflicts.py).
 // The inverse runs the passes backwards with (u, v) -> (u + v, (u - v) conj(s)).
 //
 // The floating-point operation order is FIXED and identical to oracle/oracle_fft.c, so results are
@@ -122,51 +122,58 @@ struct Fft1024 {
     wc = load_pass_tw(tw, 6, lane);
   }
 
-  // physical 16-byte slot of element j for each exchange (see tools/lds_conflicts.py)
-  static __device__ __forceinline__ int slot_ab(int j) { return j ^ (((j >> 6) & 7) << 3); }
-  static __device__ __forceinline__ int slot_bc(int j) { return j ^ ((j >> 4) & 7); }
-  static __device__ __forceinline__ int slot_cb(int j) {
-    return (j & 0x100) | (((j >> 6) & 1) << 7) | ((j & 7) << 4) | (((j >> 7) & 1) << 3) | (((j >> 3) & 7) ^ (j & 7));
-  }
-  // index of register m of this lane in each layout
-  static __device__ __forceinline__ int idx_a(int lane, int m) { return (m << 6) | lane; }
-  static __device__ __forceinline__ int idx_b(int lane, int m) { return ((lane >> 3) << 6) | (m << 3) | (lane & 7); }
-  static __device__ __forceinline__ int idx_c(int lane, int m) { return (lane << 3) | m; }
+  // LDS transposes.  Physical 16-byte slot of element j:  A<->B exchanges use f1(j) = j + 8 (j >> 6),
+  // B<->C exchanges use f2(j) = j + (j >> 3)  (both 576 slots = 9 KiB).  Both are bank-conflict free for the
+  // ds_write_b128 and the ds_read_b128 side under gfx950's lane groups AND additive in the register index, so
+  // every access is `lane base + immediate offset` (tools/lds_conflicts.py verifies both properties):
+  //   layout A (reg m = j[8:6], lane = j[5:0]):            f1 = lane + 72 m
+  //   layout B (reg m = j[5:3], lane = (h = j[8:6], lo)):  f1 = 72 h + lo + 8 m ;  f2 = 72 h + lo + 9 m
+  //   layout C (reg m = j[2:0], lane = j[8:3]):            f2 = 9 lane + m
+  static constexpr int XCH_SLOTS = 576;
 
-  // forward: input in layout A, output in layout C ("slot order": slot = lane*8 + m)
-  __device__ __forceinline__ void forward(double (&re)[8], double (&im)[8], d2 *xch, int lane) const {
+  // forward: input in layout A, output in layout C ("slot order": slot = lane*8 + m).
+  // Split in two so the caller can issue the bootstrap-key loads between passes B and C.
+  __device__ __forceinline__ void forward_ab(double (&re)[8], double (&im)[8], d2 *xch, int lane) const {
+    d2 *pa = xch + lane, *pb = xch + 72 * (lane >> 3) + (lane & 7), *pc = xch + 9 * lane;
     pass_fwd(re, im, wa);
 #pragma unroll
-    for (int m = 0; m < 8; m++) xch[slot_ab(idx_a(lane, m))] = d2{re[m], im[m]};
+    for (int m = 0; m < 8; m++) pa[72 * m] = d2{re[m], im[m]};
     wave_lds_sync();
 #pragma unroll
-    for (int m = 0; m < 8; m++) { const d2 v = xch[slot_ab(idx_b(lane, m))]; re[m] = v.x; im[m] = v.y; }
+    for (int m = 0; m < 8; m++) { const d2 v = pb[8 * m]; re[m] = v.x; im[m] = v.y; }
     pass_fwd(re, im, wb);
     wave_lds_sync();
 #pragma unroll
-    for (int m = 0; m < 8; m++) xch[slot_bc(idx_b(lane, m))] = d2{re[m], im[m]};
+    for (int m = 0; m < 8; m++) pb[9 * m] = d2{re[m], im[m]};
     wave_lds_sync();
 #pragma unroll
-    for (int m = 0; m < 8; m++) { const d2 v = xch[slot_bc(idx_c(lane, m))]; re[m] = v.x; im[m] = v.y; }
+    for (int m = 0; m < 8; m++) { const d2 v = pc[m]; re[m] = v.x; im[m] = v.y; }
+  }
+  __device__ __forceinline__ void forward_c(double (&re)[8], double (&im)[8]) const {
     pass_fwd(re, im, wc);
     wave_lds_sync();
+  }
+  __device__ __forceinline__ void forward(double (&re)[8], double (&im)[8], d2 *xch, int lane) const {
+    forward_ab(re, im, xch, lane);
+    forward_c(re, im);
   }
 
   // inverse: input in layout C, output in layout A, UNSCALED (caller multiplies by 1/M)
   __device__ __forceinline__ void inverse(double (&re)[8], double (&im)[8], d2 *xch, int lane) const {
+    d2 *pa = xch + lane, *pb = xch + 72 * (lane >> 3) + (lane & 7), *pc = xch + 9 * lane;
     pass_inv(re, im, wc);
 #pragma unroll
-    for (int m = 0; m < 8; m++) xch[slot_cb(idx_c(lane, m))] = d2{re[m], im[m]};
+    for (int m = 0; m < 8; m++) pc[m] = d2{re[m], im[m]};
     wave_lds_sync();
 #pragma unroll
-    for (int m = 0; m < 8; m++) { const d2 v = xch[slot_cb(idx_b(lane, m))]; re[m] = v.x; im[m] = v.y; }
+    for (int m = 0; m < 8; m++) { const d2 v = pb[9 * m]; re[m] = v.x; im[m] = v.y; }
     pass_inv(re, im, wb);
     wave_lds_sync();
 #pragma unroll
-    for (int m = 0; m < 8; m++) xch[idx_b(lane, m)] = d2{re[m], im[m]};
+    for (int m = 0; m < 8; m++) pb[8 * m] = d2{re[m], im[m]};
     wave_lds_sync();
 #pragma unroll
-    for (int m = 0; m < 8; m++) { const d2 v = xch[idx_a(lane, m)]; re[m] = v.x; im[m] = v.y; }
+    for (int m = 0; m < 8; m++) { const d2 v = pa[72 * m]; re[m] = v.x; im[m] = v.y; }
     pass_inv(re, im, wa);
     wave_lds_sync();
   }
@@ -175,13 +182,16 @@ struct Fft1024 {
 // double -> Torus64, round to nearest, mod 2^64 (values reach ~2^84).  `scale` = 2^-64 / M.
 // Same arithmetic as oracle_fft.c:round_mod_2_64 (the two exact power-of-two scalings are merged);
 // semantics of the reference's AVX-512 path, fft_processor_spqlios.c:155-165.
+//   f = frac part of v*scale in [-1/2, 1/2]; g = rint(f 2^64) in [-2^63, 2^63]; split g = hf 2^32 + lo with
+//   hf = floor(g 2^-32) in [-2^31, 2^31], lo in [0, 2^32); the high word is (int32)hf, saturated at 2^31 - 1
+//   (only g = +2^63 exactly, an exact tie of probability ~2^-53, is affected; the oracle does the same).
 __device__ __forceinline__ uint64_t round_mod_2_64(double v, double scale) {
   double f = v * scale;
   f = f - __builtin_rint(f);
   const double g = __builtin_rint(f * 0x1p64);
-  double hi = __builtin_floor(g * 0x1p-32);
-  const double lo = __builtin_fma(-hi, 0x1p32, g);
-  if (hi < 0.0) hi += 0x1p32;
+  const double hf = __builtin_floor(g * 0x1p-32);
+  const double lo = __builtin_fma(-hf, 0x1p32, g);
+  const int32_t hi = (int32_t)__builtin_fmin(hf, 2147483647.0);
   return ((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo;
 }
 

@@ -41,3 +41,25 @@ check("inv B->A identity", layB, layA, ident)
 check("fwd A->B identity", layA, layB, ident)
 check("fwd B->C identity", layB, layC, ident)
 check("inv C->B sigma2", layC, layB, sig2)
+
+# ---- padded (additive) layouts: address = lane base + m * constant, so every DS access uses an immediate offset
+def f1(j): return j + 8 * (j >> 6)        # A <-> B   (576 slots)
+def f2(j): return j + (j >> 3)            # B <-> C   (576 slots)
+
+def check2(name, wl, rl, f, size):
+    img = [f(j) for j in range(512)]
+    assert len(set(img)) == 512 and max(img) < size, name
+    w = max(ways([f(wl(t, m)) for t in g], 32) for m in range(8) for g in WG)
+    r = max(ways([f(rl(t, m)) for t in g], 64) for m in range(8) for g in RG)
+    # additivity in the register index on both sides
+    for lay in (wl, rl):
+        for t in range(64):
+            d = [f(lay(t, m)) - f(lay(t, 0)) for m in range(8)]
+            assert d == [m * d[1] for m in range(8)], (name, "not additive", d)
+    print("%-28s write %d-way  read %d-way  (additive, %d slots)" % (name, w, r, size))
+
+print()
+check2("fwd A->B padded f1", layA, layB, f1, 576)
+check2("inv B->A padded f1", layB, layA, f1, 576)
+check2("fwd B->C padded f2", layB, layC, f2, 576)
+check2("inv C->B padded f2", layC, layB, f2, 576)
