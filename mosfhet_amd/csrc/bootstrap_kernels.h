@@ -32,7 +32,7 @@
 namespace mosfhet {
 
 struct PbsParams {
-  const d2 *__restrict__ bk;         // [n][(k+1)l][k+1][8][64] complex, slot order
+  const d2 *__restrict__ bk;         // [n][(k+1)l][k+1][8][T] complex, slot order (T = 64 or 128 threads)
   const d2 *__restrict__ tw;         // twiddle table, M - 1 entries
   const uint64_t *__restrict__ in;   // [B][n+1] input TLWE samples (a..., b)
   const uint64_t *__restrict__ tv;   // [tv_count][k+1][N] test vectors
@@ -69,21 +69,50 @@ __device__ __forceinline__ uint64_t rot_coeff(const uint64_t *poly, int i, int a
   return neg ? (0 - v) : v;
 }
 
-// Gadget decomposition state of one coefficient: the top L*Bg bits of (d + offset), from which digit j is a
-// bit-field (src/polynomial.c:74-89: digit_j = ((d + off) >> (64 - (j+1) Bg)) & (2^Bg - 1)) - 2^(Bg-1)).
-// With Bg known at compile time and L*Bg <= 32 it is one 32-bit register; otherwise the full 64-bit word is kept.
+// Gadget decomposition state of a lane's coefficient pair (j, j + M): the top L*Bg bits of (d + offset), from
+// which digit lv is a bit-field (src/polynomial.c:74-89: ((d + off) >> (64 - (lv+1) Bg)) & (2^Bg - 1)) - 2^(Bg-1)).
+//   mode PACKED (Bg compile-time, L*Bg <= 32): one 32-bit word per coefficient holding exactly those bits;
+//   mode SPLIT  (Bg compile-time, L*Bg  > 32, at most 16 bits of digits reach below bit 32): the high dword per
+//               coefficient plus one shared 32-bit word with the low-level digits of both coefficients;
+//   mode WIDE   (run-time Bg or anything else): the full 64-bit words.
 template <int L, int BG>
 struct Digits {
-  static constexpr bool kPacked = (BG > 0) && (L * BG <= 32);
-  using word_t = typename std::conditional<kPacked, uint32_t, uint64_t>::type;
-  static __device__ __forceinline__ word_t pack(uint64_t dd, int Bg_bit) {
-    if constexpr (kPacked) return (uint32_t)(dd >> (64 - L * BG));
-    else return dd;
+  static constexpr int lo_levels() {
+    int n = 0;
+    for (int lv = 0; lv < L; lv++) n += (BG > 0 && 64 - (lv + 1) * BG < 32) ? 1 : 0;
+    return n;
   }
-  // signed digit `lv` as a double (exact)
-  static __device__ __forceinline__ double digit(word_t w, int lv, int Bg_bit) {
+  static constexpr bool kPacked = (BG > 0) && (L * BG <= 32);
+  static constexpr bool kSplit = (BG > 0) && !kPacked && (lo_levels() * BG <= 16);
+  static constexpr int kLo = lo_levels(), kHi = L - lo_levels();
+  using word_t = typename std::conditional<kPacked || kSplit, uint32_t, uint64_t>::type;
+
+  static __device__ __forceinline__ void pack(word_t &w_lo, word_t &w_hi, uint32_t &ext, uint64_t dd_lo, uint64_t dd_hi) {
+    if constexpr (kPacked) {
+      w_lo = (uint32_t)(dd_lo >> (64 - L * BG));
+      w_hi = (uint32_t)(dd_hi >> (64 - L * BG));
+      ext = 0;
+    } else if constexpr (kSplit) {
+      w_lo = (uint32_t)(dd_lo >> 32);
+      w_hi = (uint32_t)(dd_hi >> 32);
+      // bits [64 - L*BG, 64 - kHi*BG) of each word: the kLo low-level digits, kLo*BG <= 16 bits
+      constexpr uint32_t m = (1u << (kLo * BG)) - 1;
+      ext = ((uint32_t)(dd_lo >> (64 - L * BG)) & m) | (((uint32_t)(dd_hi >> (64 - L * BG)) & m) << 16);
+    } else {
+      w_lo = dd_lo;
+      w_hi = dd_hi;
+      ext = 0;
+    }
+  }
+  // signed digit `lv` of the coefficient (half = 0: j, 1: j + M) as a double (exact)
+  static __device__ __forceinline__ double digit(word_t w, uint32_t ext, int half, int lv, int Bg_bit) {
     if constexpr (kPacked) {
       const uint32_t u = (w >> ((L - 1 - lv) * BG)) & ((1u << BG) - 1);
+      return (double)((int)u - (1 << (BG - 1)));
+    } else if constexpr (kSplit) {
+      uint32_t u;
+      if (lv < kHi) u = (w >> (32 - (lv + 1) * BG)) & ((1u << BG) - 1);
+      else u = (ext >> (16 * half + (L - 1 - lv) * BG)) & ((1u << BG) - 1);
       return (double)((int)u - (1 << (BG - 1)));
     } else {
       const int bg = BG > 0 ? BG : Bg_bit;
@@ -93,48 +122,50 @@ struct Digits {
   }
 };
 
-// Digit words of one accumulator component.  `home` != nullptr: the component lives in LDS (al / ah unused);
-// otherwise it lives in registers (al, ah) and is staged through the transpose buffer for the rotation.
-template <int L, int BG>
-__device__ __forceinline__ void cmux_digits_r(typename Digits<L, BG>::word_t (&w_lo)[8], typename Digits<L, BG>::word_t (&w_hi)[8],
-                                              const uint64_t (&al)[8], const uint64_t (&ah)[8], const uint64_t *home, d2 *xch,
-                                              int a_lo, bool flip, uint64_t off, int Bg_bit, int lane) {
-  constexpr int N = 1024, M = 512;
+// Digit words of one accumulator component for this thread's 8 coefficient pairs.  `home` != nullptr: the component
+// lives in LDS (al / ah unused); otherwise it lives in registers (al, ah) and is staged through the transpose
+// buffer for the rotation.  F = Fft1024 (one wavefront) or Fft2048 (two wavefronts, workgroup barriers).
+template <class F, int L, int BG>
+__device__ __forceinline__ void cmux_digits(typename Digits<L, BG>::word_t (&w_lo)[8], typename Digits<L, BG>::word_t (&w_hi)[8],
+                                            uint32_t (&ext)[8], const uint64_t (&al)[8], const uint64_t (&ah)[8],
+                                            const uint64_t *home, d2 *xch, int a_lo, bool flip, uint64_t off, int t) {
+  constexpr int N = F::N, M = F::M, T = F::THREADS;
   using D = Digits<L, BG>;
   // keep the rotated LDS addresses from being hoisted out of the component loop (they would be spilled there)
   asm volatile("" : "+s"(a_lo));
   if (home) {
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-      const int j = m * 64 + lane;
-      w_lo[m] = D::pack(rot_coeff<N>(home, j, a_lo, flip) - home[j] + off, Bg_bit);
-      w_hi[m] = D::pack(rot_coeff<N>(home, j + M, a_lo, flip) - home[j + M] + off, Bg_bit);
+      const int j = m * T + t;
+      D::pack(w_lo[m], w_hi[m], ext[m], rot_coeff<N>(home, j, a_lo, flip) - home[j] + off,
+              rot_coeff<N>(home, j + M, a_lo, flip) - home[j + M] + off);
     }
   } else {
-    // stage the component (8 KiB) and read it back rotated by abar
+    // stage the component and read it back rotated by abar
     uint64_t *st = reinterpret_cast<uint64_t *>(xch);
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-      st[m * 64 + lane] = al[m];
-      st[M + m * 64 + lane] = ah[m];
+      st[m * T + t] = al[m];
+      st[M + m * T + t] = ah[m];
     }
-    wave_lds_sync();
+    F::sync();
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-      const int j = m * 64 + lane;
-      w_lo[m] = D::pack(rot_coeff<N>(st, j, a_lo, flip) - al[m] + off, Bg_bit);
-      w_hi[m] = D::pack(rot_coeff<N>(st, j + M, a_lo, flip) - ah[m] + off, Bg_bit);
+      const int j = m * T + t;
+      D::pack(w_lo[m], w_hi[m], ext[m], rot_coeff<N>(st, j, a_lo, flip) - al[m] + off,
+              rot_coeff<N>(st, j + M, a_lo, flip) - ah[m] + off);
     }
-    wave_lds_sync();
+    F::sync();
   }
 }
 
 // The L rows of component p: digits -> forward transform -> MAC against key rows p*L .. p*L+L-1.
-template <int L, int BG, bool KVHALF = false>
+// The key row's component 0 is loaded under the last transform pass, component 1 under the MAC of component 0.
+template <class F, int L, int BG>
 __device__ __forceinline__ void cmux_rows(const typename Digits<L, BG>::word_t (&w_lo)[8], const typename Digits<L, BG>::word_t (&w_hi)[8],
-                                          int p, double (&o_re)[2][8], double (&o_im)[2][8], d2 *xch, const Fft1024 &fft,
-                                          const d2 *__restrict__ bkrow, int Bg_bit, int lane) {
-  constexpr int M = 512;
+                                          const uint32_t (&ext)[8], int p, double (&o_re)[2][8], double (&o_im)[2][8], d2 *xch,
+                                          const F &fft, const d2 *__restrict__ bkrow, int Bg_bit, int t) {
+  constexpr int M = F::M, T = F::THREADS;
   using D = Digits<L, BG>;
 #pragma unroll 1
   for (int lv = 0; lv < L; lv++) {
@@ -142,72 +173,55 @@ __device__ __forceinline__ void cmux_rows(const typename Digits<L, BG>::word_t (
     double re[8], im[8];
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-      re[m] = D::digit(w_lo[m], lv, Bg_bit);
-      im[m] = D::digit(w_hi[m], lv, Bg_bit);
+      re[m] = D::digit(w_lo[m], ext[m], 0, lv, Bg_bit);
+      im[m] = D::digit(w_hi[m], ext[m], 1, lv, Bg_bit);
     }
-    fft.forward_ab(re, im, xch, lane);
-    if constexpr (!KVHALF) {
-      d2 kv[2][8];
+    fft.forward_head(re, im, xch, t);
+    d2 k0[8], k1[8];
 #pragma unroll
-      for (int c = 0; c < 2; c++)
+    for (int m = 0; m < 8; m++) k0[m] = row[m * T + t];
+    fft.forward_tail(re, im);
 #pragma unroll
-        for (int m = 0; m < 8; m++) kv[c][m] = row[c * M + m * 64 + lane];
-      fft.forward_c(re, im);
+    for (int m = 0; m < 8; m++) {
+      k1[m] = row[M + m * T + t];
+      o_re[0][m] = __builtin_fma(-im[m], k0[m].y, __builtin_fma(re[m], k0[m].x, o_re[0][m]));
+      o_im[0][m] = __builtin_fma(im[m], k0[m].x, __builtin_fma(re[m], k0[m].y, o_im[0][m]));
+    }
 #pragma unroll
-      for (int c = 0; c < 2; c++)
-#pragma unroll
-        for (int m = 0; m < 8; m++) {
-          o_re[c][m] = __builtin_fma(-im[m], kv[c][m].y, __builtin_fma(re[m], kv[c][m].x, o_re[c][m]));
-          o_im[c][m] = __builtin_fma(im[m], kv[c][m].x, __builtin_fma(re[m], kv[c][m].y, o_im[c][m]));
-        }
-    } else {
-      // register-lean form: component 0 of the key row is loaded under pass C, component 1 under the MAC of component 0
-      d2 k0[8], k1[8];
-#pragma unroll
-      for (int m = 0; m < 8; m++) k0[m] = row[m * 64 + lane];
-      fft.forward_c(re, im);
-#pragma unroll
-      for (int m = 0; m < 8; m++) {
-        k1[m] = row[M + m * 64 + lane];
-        o_re[0][m] = __builtin_fma(-im[m], k0[m].y, __builtin_fma(re[m], k0[m].x, o_re[0][m]));
-        o_im[0][m] = __builtin_fma(im[m], k0[m].x, __builtin_fma(re[m], k0[m].y, o_im[0][m]));
-      }
-#pragma unroll
-      for (int m = 0; m < 8; m++) {
-        o_re[1][m] = __builtin_fma(-im[m], k1[m].y, __builtin_fma(re[m], k1[m].x, o_re[1][m]));
-        o_im[1][m] = __builtin_fma(im[m], k1[m].x, __builtin_fma(re[m], k1[m].y, o_im[1][m]));
-      }
+    for (int m = 0; m < 8; m++) {
+      o_re[1][m] = __builtin_fma(-im[m], k1[m].y, __builtin_fma(re[m], k1[m].x, o_re[1][m]));
+      o_im[1][m] = __builtin_fma(im[m], k1[m].x, __builtin_fma(re[m], k1[m].y, o_im[1][m]));
     }
   }
 }
 
 // The fused bootstrap kernel.  Accumulator placement: component a (acc[0]) in VGPRs in the transform's input
-// layout (lane owns coefficients m*64+lane and m*64+lane+512: 32 VGPRs), component b (acc[1]) resident in LDS
-// (8 KiB); with the 9 KiB transpose buffer that is 17 KiB of LDS and <= 256 VGPRs per wavefront, i.e. two
-// wavefronts per SIMD / eight ciphertexts per CU.  (Both components in LDS cost 25 KiB -> 6 per CU and measured
-// 22 % slower; both in registers spills.)
-template <int L, int BG>
-__global__ __launch_bounds__(64, 2) void pbs_kernel_1024(PbsParams p) {
-  constexpr int N = 1024, M = 512, LOG2N2 = 11;
-  __shared__ __attribute__((aligned(16))) d2 xch[Fft1024::XCH_SLOTS];
+// layout (thread t owns coefficients m*T+t and m*T+t+M: 32 VGPRs), component b (acc[1]) resident in LDS; with
+// the transpose buffer that is 17 KiB of LDS per wavefront and <= 256 VGPRs, i.e. two wavefronts per SIMD /
+// eight per CU.  (Both components in LDS: 25 KiB -> 6 per CU, measured 22 % slower; both in registers spills.)
+// F = Fft1024: one wavefront per ciphertext; F = Fft2048: two wavefronts (128 threads) per ciphertext.
+template <class F, int L, int BG>
+__global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
+  constexpr int N = F::N, M = F::M, T = F::THREADS, LOG2N2 = F::LOGM + 2;
+  __shared__ __attribute__((aligned(16))) d2 xch[F::XCH_SLOTS];
   __shared__ __attribute__((aligned(16))) uint64_t acc1[N];
-  const int lane = threadIdx.x;
+  const int t = threadIdx.x;
   const size_t b = blockIdx.x;
   const uint64_t *__restrict__ ct = p.in + b * (size_t)(p.n + 1);
   const int Bg_bit = BG > 0 ? BG : p.Bg_bit;
 
-  Fft1024 fft;
-  fft.init(p.tw, lane);
+  F fft;
+  fft.init(p.tw, t);
 
   uint64_t al[8], ah[8];
   if (p.skip_init) {
     const uint64_t *src = p.out + b * (size_t)(2 * N);
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-      al[m] = src[m * 64 + lane];
-      ah[m] = src[M + m * 64 + lane];
-      acc1[m * 64 + lane] = src[N + m * 64 + lane];
-      acc1[M + m * 64 + lane] = src[N + M + m * 64 + lane];
+      al[m] = src[m * T + t];
+      ah[m] = src[M + m * T + t];
+      acc1[m * T + t] = src[N + m * T + t];
+      acc1[M + m * T + t] = src[N + M + m * T + t];
     }
   } else {
     // src/bootstrap.c:194-195: acc = tv * X^(2N - bbar), gathered straight from global memory
@@ -218,19 +232,19 @@ __global__ __launch_bounds__(64, 2) void pbs_kernel_1024(PbsParams p) {
     const bool flip = (rot & N) != 0;
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-      al[m] = rot_coeff<N>(tv, m * 64 + lane, a_lo, flip);
-      ah[m] = rot_coeff<N>(tv, M + m * 64 + lane, a_lo, flip);
-      acc1[m * 64 + lane] = rot_coeff<N>(tv + N, m * 64 + lane, a_lo, flip);
-      acc1[M + m * 64 + lane] = rot_coeff<N>(tv + N, M + m * 64 + lane, a_lo, flip);
+      al[m] = rot_coeff<N>(tv, m * T + t, a_lo, flip);
+      ah[m] = rot_coeff<N>(tv, M + m * T + t, a_lo, flip);
+      acc1[m * T + t] = rot_coeff<N>(tv + N, m * T + t, a_lo, flip);
+      acc1[M + m * T + t] = rot_coeff<N>(tv + N, M + m * T + t, a_lo, flip);
     }
   }
-  wave_lds_sync();
+  F::sync();
 
   uint64_t off = 1ull << (63 - L * Bg_bit);
 #pragma unroll
   for (int i = 0; i < L; i++) off += 1ull << (63 - i * Bg_bit);
   const double scale = 0x1p-64 / (double)M;
-  const size_t row_sz = (size_t)2 * L * 2 * 512;
+  const size_t row_sz = (size_t)2 * L * 2 * M;
 
   for (int i = 0; i < p.n; i++) {
     const int abar = (int)modswitch<LOG2N2>(pbs_pre(ct[i], p, LOG2N2));
@@ -244,24 +258,25 @@ __global__ __launch_bounds__(64, 2) void pbs_kernel_1024(PbsParams p) {
 #pragma unroll
       for (int m = 0; m < 8; m++) { o_re[c][m] = 0.0; o_im[c][m] = 0.0; }
 #pragma unroll 1
-    for (int p = 0; p < 2; p++) {
+    for (int q = 0; q < 2; q++) {
       typename Digits<L, BG>::word_t w_lo[8], w_hi[8];
-      cmux_digits_r<L, BG>(w_lo, w_hi, al, ah, p ? acc1 : nullptr, xch, a_lo, flip, off, Bg_bit, lane);
-      cmux_rows<L, BG, true>(w_lo, w_hi, p, o_re, o_im, xch, fft, bkrow, Bg_bit, lane);
+      uint32_t ext[8];
+      cmux_digits<F, L, BG>(w_lo, w_hi, ext, al, ah, q ? acc1 : nullptr, xch, a_lo, flip, off, t);
+      cmux_rows<F, L, BG>(w_lo, w_hi, ext, q, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
     }
-    fft.inverse(o_re[0], o_im[0], xch, lane);
+    fft.inverse(o_re[0], o_im[0], xch, t);
 #pragma unroll
     for (int m = 0; m < 8; m++) {
       al[m] += round_mod_2_64(o_re[0][m], scale);
       ah[m] += round_mod_2_64(o_im[0][m], scale);
     }
-    fft.inverse(o_re[1], o_im[1], xch, lane);
+    fft.inverse(o_re[1], o_im[1], xch, t);
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-      acc1[m * 64 + lane] += round_mod_2_64(o_re[1][m], scale);
-      acc1[M + m * 64 + lane] += round_mod_2_64(o_im[1][m], scale);
+      acc1[m * T + t] += round_mod_2_64(o_re[1][m], scale);
+      acc1[M + m * T + t] += round_mod_2_64(o_im[1][m], scale);
     }
-    wave_lds_sync();
+    F::sync();
   }
 
   if (p.extract) {
@@ -269,66 +284,110 @@ __global__ __launch_bounds__(64, 2) void pbs_kernel_1024(PbsParams p) {
     uint64_t *st = reinterpret_cast<uint64_t *>(xch);
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-      st[m * 64 + lane] = al[m];
-      st[M + m * 64 + lane] = ah[m];
+      st[m * T + t] = al[m];
+      st[M + m * T + t] = ah[m];
     }
-    wave_lds_sync();
+    F::sync();
     uint64_t *dst = p.out + b * (size_t)(N + 1);
-    for (int j = lane; j < N; j += 64) dst[j] = (j == 0) ? st[0] : (0 - st[N - j]);
-    if (lane == 0) dst[N] = acc1[0];
+    for (int j = t; j < N; j += T) dst[j] = (j == 0) ? st[0] : (0 - st[N - j]);
+    if (t == 0) dst[N] = acc1[0];
   } else {
     uint64_t *dst = p.out + b * (size_t)(2 * N);
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-      dst[m * 64 + lane] = al[m];
-      dst[M + m * 64 + lane] = ah[m];
-      dst[N + m * 64 + lane] = acc1[m * 64 + lane];
-      dst[N + M + m * 64 + lane] = acc1[M + m * 64 + lane];
+      dst[m * T + t] = al[m];
+      dst[M + m * T + t] = ah[m];
+      dst[N + m * T + t] = acc1[m * T + t];
+      dst[N + M + m * T + t] = acc1[M + m * T + t];
     }
   }
 }
 
 // trgsw_to_DFT / polynomial_torus_to_DFT for a flat array of polynomials [src/trgsw.c:345-349,
-// src/polynomial.c:368-375]: one wavefront per polynomial, output in slot order [m][lane].
-__global__ __launch_bounds__(64) void torus_to_dft_kernel_1024(const uint64_t *__restrict__ in, d2 *__restrict__ out,
-                                                              const d2 *__restrict__ tw) {
-  constexpr int N = 1024, M = 512;
-  __shared__ __attribute__((aligned(16))) d2 xch[Fft1024::XCH_SLOTS];
-  const int lane = threadIdx.x;
+// src/polynomial.c:368-375]: one team per polynomial, output in slot order [m][thread].
+template <class F>
+__global__ __launch_bounds__(F::THREADS) void torus_to_dft_kernel(const uint64_t *__restrict__ in, d2 *__restrict__ out,
+                                                                const d2 *__restrict__ tw) {
+  constexpr int N = F::N, M = F::M, T = F::THREADS;
+  __shared__ __attribute__((aligned(16))) d2 xch[F::XCH_SLOTS];
+  const int t = threadIdx.x;
   const uint64_t *src = in + (size_t)blockIdx.x * N;
-  Fft1024 fft;
-  fft.init(tw, lane);
+  F fft;
+  fft.init(tw, t);
   double re[8], im[8];
 #pragma unroll
   for (int m = 0; m < 8; m++) {
-    re[m] = torus_to_double(src[m * 64 + lane]);
-    im[m] = torus_to_double(src[m * 64 + lane + M]);
+    re[m] = torus_to_double(src[m * T + t]);
+    im[m] = torus_to_double(src[m * T + t + M]);
   }
-  fft.forward(re, im, xch, lane);
+  fft.forward(re, im, xch, t);
   d2 *dst = out + (size_t)blockIdx.x * M;
 #pragma unroll
-  for (int m = 0; m < 8; m++) dst[m * 64 + lane] = d2{re[m], im[m]};
+  for (int m = 0; m < 8; m++) dst[m * T + t] = d2{re[m], im[m]};
 }
 
 // polynomial_DFT_to_torus for a flat array [src/polynomial.c:359-366]
-__global__ __launch_bounds__(64) void dft_to_torus_kernel_1024(const d2 *__restrict__ in, uint64_t *__restrict__ out,
-                                                              const d2 *__restrict__ tw) {
-  constexpr int N = 1024, M = 512;
-  __shared__ __attribute__((aligned(16))) d2 xch[Fft1024::XCH_SLOTS];
-  const int lane = threadIdx.x;
+template <class F>
+__global__ __launch_bounds__(F::THREADS) void dft_to_torus_kernel(const d2 *__restrict__ in, uint64_t *__restrict__ out,
+                                                                const d2 *__restrict__ tw) {
+  constexpr int N = F::N, M = F::M, T = F::THREADS;
+  __shared__ __attribute__((aligned(16))) d2 xch[F::XCH_SLOTS];
+  const int t = threadIdx.x;
   const d2 *src = in + (size_t)blockIdx.x * M;
-  Fft1024 fft;
-  fft.init(tw, lane);
+  F fft;
+  fft.init(tw, t);
   double re[8], im[8];
 #pragma unroll
-  for (int m = 0; m < 8; m++) { const d2 v = src[m * 64 + lane]; re[m] = v.x; im[m] = v.y; }
-  fft.inverse(re, im, xch, lane);
+  for (int m = 0; m < 8; m++) { const d2 v = src[m * T + t]; re[m] = v.x; im[m] = v.y; }
+  fft.inverse(re, im, xch, t);
   uint64_t *dst = out + (size_t)blockIdx.x * N;
   const double scale = 0x1p-64 / (double)M;
 #pragma unroll
   for (int m = 0; m < 8; m++) {
-    dst[m * 64 + lane] = round_mod_2_64(re[m], scale);
-    dst[m * 64 + lane + M] = round_mod_2_64(im[m], scale);
+    dst[m * T + t] = round_mod_2_64(re[m], scale);
+    dst[m * T + t + M] = round_mod_2_64(im[m], scale);
+  }
+}
+
+// trgsw_mul_trlwe_DFT + trlwe_from_DFT for a batch against ONE key entry [src/trgsw.c:385-423, src/trlwe.c:629-634]:
+// out[b] = TRGSW (.) in[b], back in the torus domain.  bkrow = start of that entry's (k+1)l rows.
+template <class F, int L>
+__global__ __launch_bounds__(F::THREADS) void external_product_kernel(const d2 *__restrict__ bkrow, const d2 *__restrict__ tw,
+                                                                    const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
+                                                                    int Bg_bit) {
+  constexpr int N = F::N, M = F::M, T = F::THREADS;
+  __shared__ __attribute__((aligned(16))) d2 xch[F::XCH_SLOTS];
+  const int t = threadIdx.x;
+  const uint64_t *ct = in + (size_t)blockIdx.x * 2 * N;
+  F fft;
+  fft.init(tw, t);
+  uint64_t off = 1ull << (63 - L * Bg_bit);
+#pragma unroll
+  for (int i = 0; i < L; i++) off += 1ull << (63 - i * Bg_bit);
+  double o_re[2][8], o_im[2][8];
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int m = 0; m < 8; m++) { o_re[c][m] = 0.0; o_im[c][m] = 0.0; }
+#pragma unroll 1
+  for (int q = 0; q < 2; q++) {
+    typename Digits<L, 0>::word_t w_lo[8], w_hi[8];
+    uint32_t ext[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++)
+      Digits<L, 0>::pack(w_lo[m], w_hi[m], ext[m], ct[q * N + m * T + t] + off, ct[q * N + M + m * T + t] + off);
+    cmux_rows<F, L, 0>(w_lo, w_hi, ext, q, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
+  }
+  const double scale = 0x1p-64 / (double)M;
+  uint64_t *dst = out + (size_t)blockIdx.x * 2 * N;
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    fft.inverse(o_re[c], o_im[c], xch, t);
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      dst[c * N + m * T + t] = round_mod_2_64(o_re[c][m], scale);
+      dst[c * N + m * T + t + M] = round_mod_2_64(o_im[c][m], scale);
+    }
   }
 }
 

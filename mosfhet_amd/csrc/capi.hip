@@ -36,7 +36,7 @@ static int fail(int code, const char *fmt, ...) {
 
 struct mosfhet_hip_ctx {
   int device;
-  d2 *tw1024;  // device twiddle table for N = 1024
+  d2 *tw1024, *tw2048;  // device twiddle tables
 };
 
 struct mosfhet_hip_bsk {
@@ -106,10 +106,13 @@ extern "C" int mosfhet_hip_ctx_create(mosfhet_hip_ctx_t *out, int device) {
   HIP_TRY(hipSetDevice(device));
   mosfhet_hip_ctx *c = new mosfhet_hip_ctx();
   c->device = device;
-  std::vector<double> tw;
-  make_twiddles(1024, tw);
-  HIP_TRY(hipMalloc((void **)&c->tw1024, tw.size() * sizeof(double)));
-  HIP_TRY(hipMemcpy(c->tw1024, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice));
+  for (int N : {1024, 2048}) {
+    std::vector<double> tw;
+    make_twiddles(N, tw);
+    d2 *&dst = (N == 1024) ? c->tw1024 : c->tw2048;
+    HIP_TRY(hipMalloc((void **)&dst, tw.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(dst, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   *out = c;
   return MOSFHET_HIP_OK;
 }
@@ -119,6 +122,7 @@ extern "C" int mosfhet_hip_ctx_destroy(mosfhet_hip_ctx_t ctx) {
   hipSetDevice(ctx->device);
   hipDeviceSynchronize();
   hipFree(ctx->tw1024);
+  hipFree(ctx->tw2048);
   delete ctx;
   return MOSFHET_HIP_OK;
 }
@@ -136,7 +140,7 @@ extern "C" int mosfhet_hip_ctx_sync(mosfhet_hip_ctx_t ctx, void *stream) {
 
 static int check_params(const char *who, int k, int N, int l, int Bg_bit) {
   if (k != 1) return fail(MOSFHET_HIP_EINVAL, "%s: only k = 1 is supported (got %d)", who, k);
-  if (N != 1024) return fail(MOSFHET_HIP_EINVAL, "%s: ring degree N = %d not supported yet (N = 1024)", who, N);
+  if (N != 1024 && N != 2048) return fail(MOSFHET_HIP_EINVAL, "%s: ring degree N = %d not supported (1024, 2048)", who, N);
   if (l < 1 || Bg_bit < 1 || l * Bg_bit >= 64) return fail(MOSFHET_HIP_EINVAL, "%s: bad gadget l=%d Bg_bit=%d", who, l, Bg_bit);
   if (l != 1 && l != 2 && l != 3 && l != 4) return fail(MOSFHET_HIP_EINVAL, "%s: l = %d not instantiated (1..4)", who, l);
   return MOSFHET_HIP_OK;
@@ -154,7 +158,8 @@ extern "C" int mosfhet_hip_bsk_create_from_device(mosfhet_hip_ctx_t ctx, mosfhet
   const size_t polys = (size_t)n * (k + 1) * l * (k + 1);
   b->bytes = polys * N * sizeof(double);
   HIP_TRY(hipMalloc((void **)&b->d_bk, b->bytes));
-  hipLaunchKernelGGL(torus_to_dft_kernel_1024, dim3((unsigned)polys), dim3(64), 0, pick(ctx, stream), d_bk, b->d_bk, ctx->tw1024);
+  if (N == 1024) hipLaunchKernelGGL(torus_to_dft_kernel<Fft1024>, dim3((unsigned)polys), dim3(64), 0, pick(ctx, stream), d_bk, b->d_bk, ctx->tw1024);
+  else hipLaunchKernelGGL(torus_to_dft_kernel<Fft2048>, dim3((unsigned)polys), dim3(128), 0, pick(ctx, stream), d_bk, b->d_bk, ctx->tw2048);
   HIP_TRY(hipGetLastError());
   *out = b;
   return MOSFHET_HIP_OK;
@@ -195,8 +200,8 @@ extern "C" int mosfhet_hip_bsk_export_dft(mosfhet_hip_bsk_t bsk, double *h_out) 
   const int M = bsk->N / 2;
   const size_t polys = bsk->bytes / sizeof(double) / bsk->N;
   for (size_t q = 0; q < polys; q++)
-    for (int j = 0; j < M; j++) {  // oracle index j = lane*8 + m  <->  device index m*64 + lane
-      const int dev = (j & 7) * 64 + (j >> 3);
+    for (int j = 0; j < M; j++) {  // oracle index j = thread*8 + m  <->  device index m*T + thread, T = N/16
+      const int dev = (j & 7) * (bsk->N / 16) + (j >> 3);
       h_out[q * bsk->N + 2 * j] = tmp[q * bsk->N + 2 * dev];
       h_out[q * bsk->N + 2 * j + 1] = tmp[q * bsk->N + 2 * dev + 1];
     }
@@ -204,20 +209,22 @@ extern "C" int mosfhet_hip_bsk_export_dft(mosfhet_hip_bsk_t bsk, double *h_out) 
 }
 
 // ---- bootstrap launches ----
-template <int L, int BG>
+template <class F, int L, int BG>
 static void launch_pbs(const PbsParams &p, int count, hipStream_t s) {
-  hipLaunchKernelGGL((pbs_kernel_1024<L, BG>), dim3((unsigned)count), dim3(64), 0, s, p);
+  hipLaunchKernelGGL((pbs_kernel<F, L, BG>), dim3((unsigned)count), dim3(F::THREADS), 0, s, p);
 }
 
-// Gadget bases of the reference's parameter sets get a compile-time instantiation (test/benchmark.c:53-75,
-// test/tests.c:37-62); anything else runs the run-time-Bg variant.
-static int launch_pbs_l(int l, int Bg_bit, const PbsParams &p, int count, hipStream_t s) {
-  if (l == 2 && Bg_bit == 8) launch_pbs<2, 8>(p, count, s);
-  else if (l == 4 && Bg_bit == 9) launch_pbs<4, 9>(p, count, s);
-  else if (l == 1) launch_pbs<1, 0>(p, count, s);
-  else if (l == 2) launch_pbs<2, 0>(p, count, s);
-  else if (l == 3) launch_pbs<3, 0>(p, count, s);
-  else if (l == 4) launch_pbs<4, 0>(p, count, s);
+template <class F>
+static int launch_pbs_f(int l, int Bg_bit, const PbsParams &p, int count, hipStream_t s) {
+  // Gadget bases of the reference's parameter sets get a compile-time instantiation (test/benchmark.c:53-75,
+  // test/tests.c:37-62,967); anything else runs the run-time-Bg variant.
+  if (l == 2 && Bg_bit == 8) launch_pbs<F, 2, 8>(p, count, s);
+  else if (l == 4 && Bg_bit == 9) launch_pbs<F, 4, 9>(p, count, s);
+  else if (l == 1 && Bg_bit == 23) launch_pbs<F, 1, 23>(p, count, s);
+  else if (l == 1) launch_pbs<F, 1, 0>(p, count, s);
+  else if (l == 2) launch_pbs<F, 2, 0>(p, count, s);
+  else if (l == 3) launch_pbs<F, 3, 0>(p, count, s);
+  else if (l == 4) launch_pbs<F, 4, 0>(p, count, s);
   else return fail(MOSFHET_HIP_EINVAL, "l = %d not instantiated", l);
   HIP_TRY(hipGetLastError());
   return MOSFHET_HIP_OK;
@@ -235,7 +242,7 @@ static int bootstrap_common(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hip_
   HIP_TRY(hipSetDevice(ctx->device));
   PbsParams p;
   p.bk = bsk->d_bk;
-  p.tw = ctx->tw1024;
+  p.tw = bsk->N == 1024 ? ctx->tw1024 : ctx->tw2048;
   p.in = d_in;
   p.tv = d_tv;
   p.out = d_out;
@@ -249,7 +256,8 @@ static int bootstrap_common(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hip_
   p.prec_offset = skip_init ? 0 : (uint64_t)((int64_t)(18446744073709551616.0 * (1. / (4 * (double)torus_base))));
   p.extract = extract;
   p.skip_init = skip_init;
-  return launch_pbs_l(bsk->l, bsk->Bg_bit, p, count, pick(ctx, stream));
+  return bsk->N == 1024 ? launch_pbs_f<Fft1024>(bsk->l, bsk->Bg_bit, p, count, pick(ctx, stream))
+                        : launch_pbs_f<Fft2048>(bsk->l, bsk->Bg_bit, p, count, pick(ctx, stream));
 }
 
 extern "C" int mosfhet_hip_programmable_bootstrap_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_out,
@@ -277,82 +285,31 @@ extern "C" int mosfhet_hip_blind_rotate_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip
   return bootstrap_common("blind_rotate", ctx, bsk, d_acc, nullptr, 0, d_in, count, 0, 0, 0, 1, 0, 1, stream);
 }
 
-// external product = one CMUX-less step: out = BK_i (.) in.  Implemented with the same device code.
-template <int L>
-__global__ __launch_bounds__(64) void external_product_kernel_1024(const d2 *__restrict__ bkrow, const d2 *__restrict__ tw,
-                                                                  const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
-                                                                  int Bg_bit) {
-  constexpr int N = 1024, M = 512;
-  __shared__ __attribute__((aligned(16))) uint64_t src[2][N];
-  __shared__ __attribute__((aligned(16))) d2 xch[Fft1024::XCH_SLOTS];
-  const int lane = threadIdx.x;
-  const uint64_t *ct = in + (size_t)blockIdx.x * 2 * N;
-  Fft1024 fft;
-  fft.init(tw, lane);
-  for (int c = 0; c < 2; c++)
-    for (int i = lane; i < N; i += 64) src[c][i] = ct[c * N + i];
-  wave_lds_sync();
-  uint64_t off = 1ull << (63 - L * Bg_bit);
-#pragma unroll
-  for (int i = 0; i < L; i++) off += 1ull << (63 - i * Bg_bit);
-  const uint64_t mask = (1ull << Bg_bit) - 1;
-  const int half = 1 << (Bg_bit - 1);
-  double o_re[2][8], o_im[2][8];
-#pragma unroll
-  for (int c = 0; c < 2; c++)
-#pragma unroll
-    for (int m = 0; m < 8; m++) { o_re[c][m] = 0.0; o_im[c][m] = 0.0; }
-#pragma unroll
-  for (int p = 0; p < 2; p++)
-#pragma unroll
-    for (int lv = 0; lv < L; lv++) {
-      const d2 *__restrict__ row = bkrow + (size_t)(p * L + lv) * (2 * M);
-      const int shift = 64 - (lv + 1) * Bg_bit;
-      double re[8], im[8];
-#pragma unroll
-      for (int m = 0; m < 8; m++) {
-        const int j = m * 64 + lane;
-        re[m] = (double)((int)(((src[p][j] + off) >> shift) & mask) - half);
-        im[m] = (double)((int)(((src[p][j + M] + off) >> shift) & mask) - half);
-      }
-      fft.forward(re, im, xch, lane);
-#pragma unroll
-      for (int c = 0; c < 2; c++)
-#pragma unroll
-        for (int m = 0; m < 8; m++) {
-          const d2 kv = row[c * M + m * 64 + lane];
-          o_re[c][m] = __builtin_fma(-im[m], kv.y, __builtin_fma(re[m], kv.x, o_re[c][m]));
-          o_im[c][m] = __builtin_fma(im[m], kv.x, __builtin_fma(re[m], kv.y, o_im[c][m]));
-        }
-    }
-  const double scale = 0x1p-64 / (double)M;
-  uint64_t *dst = out + (size_t)blockIdx.x * 2 * N;
-#pragma unroll
-  for (int c = 0; c < 2; c++) {
-    fft.inverse(o_re[c], o_im[c], xch, lane);
-#pragma unroll
-    for (int m = 0; m < 8; m++) {
-      dst[c * N + m * 64 + lane] = round_mod_2_64(o_re[c][m], scale);
-      dst[c * N + m * 64 + lane + M] = round_mod_2_64(o_im[c][m], scale);
-    }
-  }
-}
-
 extern "C" int mosfhet_hip_external_product_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, int key_index, uint64_t *d_out,
                                                   const uint64_t *d_in, int count, void *stream) {
   if (!ctx || !bsk || !d_out || !d_in || count < 0 || key_index < 0 || key_index >= bsk->n)
     return fail(MOSFHET_HIP_EINVAL, "external_product: bad argument");
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
-  const d2 *row = bsk->d_bk + (size_t)key_index * (2 * bsk->l * 2 * 512);
+  const d2 *row = bsk->d_bk + (size_t)key_index * (2 * bsk->l * 2 * (bsk->N / 2));
   hipStream_t s = pick(ctx, stream);
-  switch (bsk->l) {
-    case 1: hipLaunchKernelGGL(external_product_kernel_1024<1>, dim3(count), dim3(64), 0, s, row, ctx->tw1024, d_in, d_out, bsk->Bg_bit); break;
-    case 2: hipLaunchKernelGGL(external_product_kernel_1024<2>, dim3(count), dim3(64), 0, s, row, ctx->tw1024, d_in, d_out, bsk->Bg_bit); break;
-    case 3: hipLaunchKernelGGL(external_product_kernel_1024<3>, dim3(count), dim3(64), 0, s, row, ctx->tw1024, d_in, d_out, bsk->Bg_bit); break;
-    case 4: hipLaunchKernelGGL(external_product_kernel_1024<4>, dim3(count), dim3(64), 0, s, row, ctx->tw1024, d_in, d_out, bsk->Bg_bit); break;
-    default: return fail(MOSFHET_HIP_EINVAL, "l = %d not instantiated", bsk->l);
+#define EP_LAUNCH(F, T, TW, LL) hipLaunchKernelGGL((external_product_kernel<F, LL>), dim3(count), dim3(T), 0, s, row, TW, d_in, d_out, bsk->Bg_bit)
+  if (bsk->N == 1024) {
+    switch (bsk->l) {
+      case 1: EP_LAUNCH(Fft1024, 64, ctx->tw1024, 1); break;
+      case 2: EP_LAUNCH(Fft1024, 64, ctx->tw1024, 2); break;
+      case 3: EP_LAUNCH(Fft1024, 64, ctx->tw1024, 3); break;
+      default: EP_LAUNCH(Fft1024, 64, ctx->tw1024, 4); break;
+    }
+  } else {
+    switch (bsk->l) {
+      case 1: EP_LAUNCH(Fft2048, 128, ctx->tw2048, 1); break;
+      case 2: EP_LAUNCH(Fft2048, 128, ctx->tw2048, 2); break;
+      case 3: EP_LAUNCH(Fft2048, 128, ctx->tw2048, 3); break;
+      default: EP_LAUNCH(Fft2048, 128, ctx->tw2048, 4); break;
+    }
   }
+#undef EP_LAUNCH
   HIP_TRY(hipGetLastError());
   return MOSFHET_HIP_OK;
 }
@@ -360,20 +317,22 @@ extern "C" int mosfhet_hip_external_product_batch(mosfhet_hip_ctx_t ctx, mosfhet
 // ---- polynomial-level entry points ----
 extern "C" int mosfhet_hip_torus_to_dft_batch(mosfhet_hip_ctx_t ctx, double *d_out, const uint64_t *d_in, int N, int count, void *stream) {
   if (!ctx || !d_out || !d_in || count < 0) return fail(MOSFHET_HIP_EINVAL, "torus_to_dft: bad argument");
-  if (N != 1024) return fail(MOSFHET_HIP_EINVAL, "torus_to_dft: N = %d not supported yet", N);
+  if (N != 1024 && N != 2048) return fail(MOSFHET_HIP_EINVAL, "torus_to_dft: N = %d not supported (1024, 2048)", N);
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(torus_to_dft_kernel_1024, dim3(count), dim3(64), 0, pick(ctx, stream), d_in, (d2 *)d_out, ctx->tw1024);
+  if (N == 1024) hipLaunchKernelGGL(torus_to_dft_kernel<Fft1024>, dim3(count), dim3(64), 0, pick(ctx, stream), d_in, (d2 *)d_out, ctx->tw1024);
+  else hipLaunchKernelGGL(torus_to_dft_kernel<Fft2048>, dim3(count), dim3(128), 0, pick(ctx, stream), d_in, (d2 *)d_out, ctx->tw2048);
   HIP_TRY(hipGetLastError());
   return MOSFHET_HIP_OK;
 }
 
 extern "C" int mosfhet_hip_dft_to_torus_batch(mosfhet_hip_ctx_t ctx, uint64_t *d_out, const double *d_in, int N, int count, void *stream) {
   if (!ctx || !d_out || !d_in || count < 0) return fail(MOSFHET_HIP_EINVAL, "dft_to_torus: bad argument");
-  if (N != 1024) return fail(MOSFHET_HIP_EINVAL, "dft_to_torus: N = %d not supported yet", N);
+  if (N != 1024 && N != 2048) return fail(MOSFHET_HIP_EINVAL, "dft_to_torus: N = %d not supported (1024, 2048)", N);
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(dft_to_torus_kernel_1024, dim3(count), dim3(64), 0, pick(ctx, stream), (const d2 *)d_in, d_out, ctx->tw1024);
+  if (N == 1024) hipLaunchKernelGGL(dft_to_torus_kernel<Fft1024>, dim3(count), dim3(64), 0, pick(ctx, stream), (const d2 *)d_in, d_out, ctx->tw1024);
+  else hipLaunchKernelGGL(dft_to_torus_kernel<Fft2048>, dim3(count), dim3(128), 0, pick(ctx, stream), (const d2 *)d_in, d_out, ctx->tw2048);
   HIP_TRY(hipGetLastError());
   return MOSFHET_HIP_OK;
 }

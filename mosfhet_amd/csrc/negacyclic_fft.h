@@ -113,7 +113,8 @@ __device__ __forceinline__ PassTw load_pass_tw(const d2 *__restrict__ tw, int le
 // N = 1024: 64 lanes x 8 points.
 // ------------------------------------------------------------------------------------------------
 struct Fft1024 {
-  static constexpr int N = 1024, M = 512, LOGM = 9, LANES = 64, P = 8;
+  static constexpr int N = 1024, M = 512, LOGM = 9, THREADS = 64, P = 8;
+  static __device__ __forceinline__ void sync() { wave_lds_sync(); }
   PassTw wa, wb, wc;  // wa is lane-uniform (lives in SGPRs), wb / wc are per lane
 
   __device__ __forceinline__ void init(const d2 *__restrict__ tw, int lane) {
@@ -132,8 +133,9 @@ struct Fft1024 {
   static constexpr int XCH_SLOTS = 576;
 
   // forward: input in layout A, output in layout C ("slot order": slot = lane*8 + m).
-  // Split in two so the caller can issue the bootstrap-key loads between passes B and C.
-  __device__ __forceinline__ void forward_ab(double (&re)[8], double (&im)[8], d2 *xch, int lane) const {
+  // Split in two (head = passes A, B and both transposes; tail = pass C) so the caller can issue the bootstrap-key
+  // loads in between.
+  __device__ __forceinline__ void forward_head(double (&re)[8], double (&im)[8], d2 *xch, int lane) const {
     d2 *pa = xch + lane, *pb = xch + 72 * (lane >> 3) + (lane & 7), *pc = xch + 9 * lane;
     pass_fwd(re, im, wa);
 #pragma unroll
@@ -149,13 +151,13 @@ struct Fft1024 {
 #pragma unroll
     for (int m = 0; m < 8; m++) { const d2 v = pc[m]; re[m] = v.x; im[m] = v.y; }
   }
-  __device__ __forceinline__ void forward_c(double (&re)[8], double (&im)[8]) const {
+  __device__ __forceinline__ void forward_tail(double (&re)[8], double (&im)[8]) const {
     pass_fwd(re, im, wc);
     wave_lds_sync();
   }
   __device__ __forceinline__ void forward(double (&re)[8], double (&im)[8], d2 *xch, int lane) const {
-    forward_ab(re, im, xch, lane);
-    forward_c(re, im);
+    forward_head(re, im, xch, lane);
+    forward_tail(re, im);
   }
 
   // inverse: input in layout C, output in layout A, UNSCALED (caller multiplies by 1/M)
@@ -176,6 +178,137 @@ struct Fft1024 {
     for (int m = 0; m < 8; m++) { const d2 v = pa[72 * m]; re[m] = v.x; im[m] = v.y; }
     pass_inv(re, im, wa);
     wave_lds_sync();
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// N = 2048 (M = 1024): two wavefronts (128 threads) x 8 points share one transform.
+// Index j has 10 bits; passes of 3, 3, 3 and 1 radix-2 levels:
+//     pass A: register = j[9:7], thread = j[6:0]                       levels 0-2, twiddles in SGPRs
+//     pass B: register = j[6:4], thread = (h = j[9:7], j[3:0])         levels 3-5
+//     pass C: register = j[3:1], thread = (u = j[9:4], e = j[0]) = 2u+e levels 6-8
+//     pass D: register = j[2:0], thread = j[9:3]                       level 9 (pairs m, m+1)
+// Three LDS transposes per transform, each through its own padded layout (tools/lds_layout_search.py: conflict
+// free for ds_write_b128 and ds_read_b128 in both directions, every access = thread base + immediate):
+//     A<->B: slot = j                      B<->C: slot = j + 2 (j >> 4)         C<->D: slot = j + (j >> 3)
+// The two wavefronts hand data to each other, so every transpose is bracketed by workgroup barriers.
+// Slot order of the DFT domain = layout D: device index m * 128 + thread.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void team_sync() { __syncthreads(); }
+
+struct Fft2048 {
+  static constexpr int N = 2048, M = 1024, LOGM = 10, THREADS = 128, P = 8;
+  static constexpr int XCH_SLOTS = 1152;
+  static __device__ __forceinline__ void sync() { team_sync(); }
+  PassTw wa, wb, wc;
+  double wd0r, wd0i, wd1r, wd1i;  // level 9: nodes 4t and 4t+2 (4t+1, 4t+3 are i times those)
+
+  __device__ __forceinline__ void init(const d2 *__restrict__ tw, int t) {
+    wa = load_pass_tw(tw, 0, 0);
+    wb = load_pass_tw(tw, 3, t >> 4);
+    wc = load_pass_tw(tw, 6, t >> 1);
+    const d2 a = tw[(1 << 9) - 1 + 4 * t], b = tw[(1 << 9) - 1 + 4 * t + 2];
+    wd0r = a.x; wd0i = a.y; wd1r = b.x; wd1i = b.y;
+  }
+
+  // thread bases (in 16-byte slots) of the four layouts under the three slot maps
+  static __device__ __forceinline__ int base_a(int t) { return t; }                                  // + 128 m
+  static __device__ __forceinline__ int base_b1(int t) { return 128 * (t >> 4) + (t & 15); }         // + 16 m      (slot = j)
+  static __device__ __forceinline__ int base_b2(int t) { return 144 * (t >> 4) + (t & 15); }         // + 18 m      (j + 2 (j>>4))
+  static __device__ __forceinline__ int base_c2(int t) { return 18 * (t >> 1) + (t & 1); }           // + 2 m       (j + 2 (j>>4))
+  static __device__ __forceinline__ int base_c3(int t) { return 18 * (t >> 1) + (t & 1); }           // + off_c3[m] (j + (j>>3))
+  static __device__ __forceinline__ int base_d3(int t) { return 9 * t; }                             // + m         (j + (j>>3))
+  // layout C under slot = j + (j >> 3): j = 16u + 2m + e  ->  18u + e + 2m + (m >> 2)
+  static __device__ __forceinline__ constexpr int off_c3(int m) { return 2 * m + (m >> 2); }
+
+  __device__ __forceinline__ void pass_d_fwd(double (&re)[8], double (&im)[8]) const {
+    bf_fwd(re[0], im[0], re[1], im[1], wd0r, wd0i);
+    bf_fwd_i(re[2], im[2], re[3], im[3], wd0r, wd0i);
+    bf_fwd(re[4], im[4], re[5], im[5], wd1r, wd1i);
+    bf_fwd_i(re[6], im[6], re[7], im[7], wd1r, wd1i);
+  }
+  __device__ __forceinline__ void pass_d_inv(double (&re)[8], double (&im)[8]) const {
+    bf_inv(re[0], im[0], re[1], im[1], wd0r, wd0i);
+    bf_inv_i(re[2], im[2], re[3], im[3], wd0r, wd0i);
+    bf_inv(re[4], im[4], re[5], im[5], wd1r, wd1i);
+    bf_inv_i(re[6], im[6], re[7], im[7], wd1r, wd1i);
+  }
+
+  // forward: input in layout A, output in layout D.  forward_head leaves the data ready for pass D so the caller
+  // can issue the key loads before it.  Entry requires that nobody still reads xch (barrier at the previous exit).
+  __device__ __forceinline__ void forward_head(double (&re)[8], double (&im)[8], d2 *xch, int t) const {
+    pass_fwd(re, im, wa);
+    {
+      d2 *w = xch + base_a(t), *r = xch + base_b1(t);
+#pragma unroll
+      for (int m = 0; m < 8; m++) w[128 * m] = d2{re[m], im[m]};
+      team_sync();
+#pragma unroll
+      for (int m = 0; m < 8; m++) { const d2 v = r[16 * m]; re[m] = v.x; im[m] = v.y; }
+    }
+    pass_fwd(re, im, wb);
+    team_sync();
+    {
+      d2 *w = xch + base_b2(t), *r = xch + base_c2(t);
+#pragma unroll
+      for (int m = 0; m < 8; m++) w[18 * m] = d2{re[m], im[m]};
+      team_sync();
+#pragma unroll
+      for (int m = 0; m < 8; m++) { const d2 v = r[2 * m]; re[m] = v.x; im[m] = v.y; }
+    }
+    pass_fwd(re, im, wc);
+    team_sync();
+    {
+      d2 *w = xch + base_c3(t), *r = xch + base_d3(t);
+#pragma unroll
+      for (int m = 0; m < 8; m++) w[off_c3(m)] = d2{re[m], im[m]};
+      team_sync();
+#pragma unroll
+      for (int m = 0; m < 8; m++) { const d2 v = r[m]; re[m] = v.x; im[m] = v.y; }
+    }
+  }
+  __device__ __forceinline__ void forward_tail(double (&re)[8], double (&im)[8]) const {
+    pass_d_fwd(re, im);
+    team_sync();
+  }
+  __device__ __forceinline__ void forward(double (&re)[8], double (&im)[8], d2 *xch, int t) const {
+    forward_head(re, im, xch, t);
+    forward_tail(re, im);
+  }
+
+  // inverse: input in layout D, output in layout A, UNSCALED
+  __device__ __forceinline__ void inverse(double (&re)[8], double (&im)[8], d2 *xch, int t) const {
+    pass_d_inv(re, im);
+    {
+      d2 *w = xch + base_d3(t), *r = xch + base_c3(t);
+#pragma unroll
+      for (int m = 0; m < 8; m++) w[m] = d2{re[m], im[m]};
+      team_sync();
+#pragma unroll
+      for (int m = 0; m < 8; m++) { const d2 v = r[off_c3(m)]; re[m] = v.x; im[m] = v.y; }
+    }
+    pass_inv(re, im, wc);
+    team_sync();
+    {
+      d2 *w = xch + base_c2(t), *r = xch + base_b2(t);
+#pragma unroll
+      for (int m = 0; m < 8; m++) w[2 * m] = d2{re[m], im[m]};
+      team_sync();
+#pragma unroll
+      for (int m = 0; m < 8; m++) { const d2 v = r[18 * m]; re[m] = v.x; im[m] = v.y; }
+    }
+    pass_inv(re, im, wb);
+    team_sync();
+    {
+      d2 *w = xch + base_b1(t), *r = xch + base_a(t);
+#pragma unroll
+      for (int m = 0; m < 8; m++) w[16 * m] = d2{re[m], im[m]};
+      team_sync();
+#pragma unroll
+      for (int m = 0; m < 8; m++) { const d2 v = r[128 * m]; re[m] = v.x; im[m] = v.y; }
+    }
+    pass_inv(re, im, wa);
+    team_sync();
   }
 };
 

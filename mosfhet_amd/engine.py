@@ -246,10 +246,10 @@ def twiddles(N):
 
 
 def slot_order_to_oracle(dft, N):
-    """Engine slot order (index m*64 + lane) -> oracle order (index lane*8 + m) for N = 1024 polynomials."""
-    assert N == 1024
-    M = N // 2
+    """Engine slot order (index m*T + thread, T = N/16 threads of 8 registers) -> oracle order (index thread*8 + m)."""
+    assert N in (1024, 2048)
+    M, T = N // 2, N // 16
     j = np.arange(M)
-    dev = (j & 7) * 64 + (j >> 3)
+    dev = (j & 7) * T + (j >> 3)
     z = dft.reshape(-1, M, 2)
     return z[:, dev, :].reshape(dft.shape)

@@ -1,12 +1,12 @@
-"""Quick GPU perf + correctness probe of the PBS kernel (run through gpurun)."""
+"""Quick GPU perf + correctness probe of the PBS kernel (run through gpurun): tools/gpu_perf.py [B] [set1|lvl2]"""
 import sys, time, numpy as np
 sys.path.insert(0, '.')
 import torch
 import mosfhet_amd as ma
 from mosfhet_amd import host
 from oracle import oracle as O
-P = dict(ma.PARAMS_SET1)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+P = dict(ma.PARAMS_LVL2 if (len(sys.argv) > 2 and sys.argv[2] == "lvl2") else ma.PARAMS_SET1)
 host.seed(0x4D4F5346)
 lk = host.LweKey(P['n'], P['lwe_sigma']); rk = host.RlweKey(P['N'], 1, P['rlwe_sigma'])
 bk = host.gen_bootstrap_key(rk, lk, P['l'], P['Bg_bit'])
@@ -23,4 +23,4 @@ ok = all((o[b] == O.programmable_bootstrap(tv, cts[b], bkd, P['l'], P['Bg_bit'],
 ph = host.tlwe_phase(o, rk.extracted_lwe_key().s)
 err = np.abs((ph - lut[np.arange(B) % 4]).astype(np.int64).astype(np.float64)).max()
 ms = [eng.time_programmable_bootstrap(bsk, d_tv, d_ct, 3, 3, out=out) for _ in range(3)]
-print("B=%d bit-exact-vs-oracle=%s max-phase-err=2^%.1f kernel ms=%s  -> %.1f k PBS/s" % (B, ok, np.log2(err + 1), ["%.2f" % m for m in ms], B / min(ms)))
+print("N=%d B=%d bit-exact-vs-oracle=%s max-phase-err=2^%.1f kernel ms=%s  -> %.1f k PBS/s" % (P['N'], B, ok, np.log2(err + 1), ["%.2f" % m for m in ms], B / min(ms)))
