@@ -51,6 +51,7 @@ struct mosfhet_hip_ksk {
   uint64_t *d_ksk;
   int n_in, n_out, t, base_bit;
   size_t bytes;
+  KsWorkspace ws;  // transposed batch buffers, grown on demand
 };
 
 extern "C" const char *mosfhet_hip_last_error(void) { return g_err; }
@@ -368,6 +369,8 @@ extern "C" int mosfhet_hip_ksk_destroy(mosfhet_hip_ksk_t ksk) {
   if (!ksk) return MOSFHET_HIP_OK;
   hipSetDevice(ksk->ctx->device);
   hipFree(ksk->d_ksk);
+  if (ksk->ws.inT) hipFree(ksk->ws.inT);
+  if (ksk->ws.outT) hipFree(ksk->ws.outT);
   delete ksk;
   return MOSFHET_HIP_OK;
 }
@@ -377,8 +380,7 @@ extern "C" int mosfhet_hip_tlwe_keyswitch_batch(mosfhet_hip_ctx_t ctx, mosfhet_h
   if (!ctx || !ksk || !d_out || !d_in || count < 0) return fail(MOSFHET_HIP_EINVAL, "tlwe_keyswitch: bad argument");
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
-  launch_tlwe_keyswitch(ksk->d_ksk, d_out, d_in, count, ksk->n_in, ksk->n_out, ksk->t, ksk->base_bit, pick(ctx, stream));
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(launch_tlwe_keyswitch(ksk->d_ksk, d_out, d_in, count, ksk->n_in, ksk->n_out, ksk->t, ksk->base_bit, ksk->ws, pick(ctx, stream)));
   return MOSFHET_HIP_OK;
 }
 

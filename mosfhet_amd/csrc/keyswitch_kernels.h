@@ -4,79 +4,217 @@
 //   out = (0, ..., 0, in.b);  for i < n_in, j < t:  v = ((in.a[i] + 2^(63 - t bb)) >> (64 - (j+1) bb)) & (2^bb - 1);
 //   if v != 0:  out -= KS[i][j][v-1]            (rows of n_out + 1 Torus words, exact mod 2^64)
 //
-// Pure integer, HBM/L2-bound gather: a ciphertext touches up to n_in * t rows (24 MB at SET_1) of a
-// 72 MB table.  One workgroup switches G ciphertexts together: thread c owns output word(s) c of all G
-// accumulators (registers), the digit of every (ciphertext, i, j) is wave-uniform (scalar unit), and each
-// selected row is read with one fully coalesced sweep.  Loads are issued unconditionally (digit 0 reads row 0
-// and is masked afterwards) so that G * t independent row reads are in flight per i; ciphertexts of a tile
-// that pick the same row hit in the CU's L1.
+// Pure integer and gather-bound: un-batched, every ciphertext touches up to n_in*t rows (24 MB at SET_1, 83 MB at
+// lvl2) of a 72 MB / 1.2 GB table.  The batch is processed so that the table is streamed ONCE per tile of
+// ciphertexts instead of once per ciphertext:
+//   * ciphertexts sit on the LANES (a wavefront owns 64 ciphertexts), output words in registers: a wavefront
+//     accumulates a slice of W output words for its 64 ciphertexts (2 W VGPRs);
+//   * a workgroup of NW wavefronts (NW*64 ciphertexts) shares one slice; for a block of key digits (i, j0..j0+JB) it
+//     stages the 2^bb - 1 candidate rows of that slice into LDS with coalesced loads -- plus an all-zero row for
+//     digit 0, so there is no branch -- and every lane then reads ITS row (ds_read_b128, row stride W+2 words:
+//     distinct digits land on distinct bank groups, equal digits broadcast) and subtracts;
+//   * the batch is transposed on the way in and out (transpose_u64_kernel) so that both the per-lane input words
+//     and the result words are coalesced.
+// Table traffic per launch: (ciphertexts / (64 NW)) * table size, served from L2 / Infinity Cache.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace mosfhet {
 
-constexpr int KS_THREADS = 256;
-constexpr int KS_MAXC = 4;  // output words per thread -> n_out + 1 <= 1024
+// out[c][r] = sum_{s < parts} in[s * part_stride + r * ldin + c] for an R x C matrix of 64-bit words (leading
+// dimensions ldin / ldout; parts = 1: plain transpose); out rows c >= C and columns r >= R are not touched.
+// 32 x 32 tiles through LDS, block = (32, 8).
+__global__ __launch_bounds__(256) void transpose_u64_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, int R, int C,
+                                                            size_t ldin, size_t ldout, int parts, size_t part_stride) {
+  __shared__ uint64_t tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int k = threadIdx.y; k < 32; k += 8) {
+    const int r = r0 + k, c = c0 + threadIdx.x;
+    uint64_t v = 0;
+    if (r < R && c < C)
+      for (int s = 0; s < parts; s++) v += in[(size_t)s * part_stride + (size_t)r * ldin + c];
+    tile[k][threadIdx.x] = v;
+  }
+  __syncthreads();
+  for (int k = threadIdx.y; k < 32; k += 8) {
+    const int c = c0 + k, r = r0 + threadIdx.x;
+    if (c < C && r < R) out[(size_t)c * ldout + r] = tile[threadIdx.x][k];
+  }
+}
 
-template <int G>
-__global__ __launch_bounds__(KS_THREADS) void tlwe_keyswitch_kernel(const uint64_t *__restrict__ ksk, uint64_t *__restrict__ out,
-                                                                    const uint64_t *__restrict__ in, int count, int n_in,
-                                                                    int n_out, int t, int base_bit) {
-  const int row = n_out + 1;
+typedef unsigned long long ul2 __attribute__((ext_vector_type(2)));
+
+constexpr int KS_W = 32;         // output words per wavefront slice
+constexpr int KS_NW = 4;         // wavefronts (x 64 ciphertexts) per workgroup
+constexpr int KS_LDS_BYTES = 16384;
+
+constexpr int KS_PF_MAX = 8;     // upper bound of staged row elements a thread prefetches per stage
+
+// inT: [n_in + 1][Bp] (word i of ciphertext c at inT[i * Bp + c]; Bp a multiple of 64 * NW, padding zero-filled)
+// outT: [n_out + 1][Bp]
+// Stages (i, j0..j0+JB) are software-pipelined: while a stage is consumed from one LDS buffer, the rows of the next
+// stage are already in flight into registers and are written to the other buffer afterwards -- one barrier per stage.
+// PF = ceil(JB * cands / (64 NW / W)): candidate-row words each thread moves per stage (compile time: no predicated
+// load chains).  Requires t % JB == 0 or handles the short last block of an i by re-staging valid rows only.
+template <int W, int NW, int PF>
+__global__ __launch_bounds__(64 * NW) void tlwe_keyswitch_kernel(const uint64_t *__restrict__ ksk, const uint64_t *__restrict__ inT,
+                                                                uint64_t *__restrict__ outT, size_t Bp, int n_in, int n_out, int t,
+                                                                int base_bit, int JB, int i_per_split) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t rows[];  // [2][JB][cands + 1][W + 2]
+  constexpr int RS = W + 2;                                        // row stride in words (16-byte aligned, bank-skewed)
+  constexpr int SV_STEP = (64 * NW) / W;
   const int tid = threadIdx.x;
-  const int b0 = blockIdx.x * G;
-  const int per_j = (1 << base_bit) - 1;
+  const int row = n_out + 1, cands = (1 << base_bit) - 1;
+  const int w0 = blockIdx.x * W;                                   // first output word of this slice
+  const size_t ct = (size_t)blockIdx.y * (64 * NW) + tid;          // this lane's ciphertext (column of inT / outT)
   const uint64_t round_off = 1ull << (63 - base_bit * t);
-  const uint64_t mask = (1ull << base_bit) - 1;
+  const uint32_t mask = (1u << base_bit) - 1;
+  const size_t buf_words = (size_t)JB * (cands + 1) * RS;
 
-  uint64_t acc[G][KS_MAXC];
+  uint64_t acc[W];
 #pragma unroll
-  for (int g = 0; g < G; g++)
+  for (int w = 0; w < W; w++) acc[w] = 0;
+  // blockIdx.z splits the mask words i over several workgroups; partial sums go to outT[z] and are added up by the
+  // transposing epilogue.  Only split 0 carries the b word.
+  const int i_begin = blockIdx.z * i_per_split, i_end = (i_begin + i_per_split < n_in) ? i_begin + i_per_split : n_in;
+  outT += (size_t)blockIdx.z * (size_t)row * Bp;
+  if (blockIdx.z == 0 && n_out >= w0 && n_out < w0 + W) {
+    const uint64_t b = inT[(size_t)n_in * Bp + ct];
 #pragma unroll
-    for (int q = 0; q < KS_MAXC; q++) acc[g][q] = 0;
+    for (int w = 0; w < W; w++)
+      if (w0 + w == n_out) acc[w] = b;
+  }
+  // zero rows (digit 0) of every j slot of both buffers, once
+  for (int k = tid; k < 2 * JB * RS; k += 64 * NW) {
+    const int bj = k / RS;  // buffer * JB + jj
+    rows[(size_t)(bj / JB) * buf_words + (size_t)(bj % JB) * (cands + 1) * RS + (k % RS)] = 0;
+  }
 
-  for (int i = 0; i < n_in; i++) {
-    uint64_t ai[G];
+  // staging map: this thread moves word sw of candidate rows vv = sv0 + k * SV_STEP (k < PF) of a stage;
+  // LDS slot of candidate row vv = jj * cands + v is (jj * (cands + 1) + v + 1) * RS.  Rows past the end of the
+  // stage (vv >= jb * cands) are clamped to the last valid row for the load and simply not written.
+  const int sw = (w0 + tid % W < row) ? tid % W : 0, sv0 = tid / W;
+  int slot[PF];
+  size_t goff[PF];
 #pragma unroll
-    for (int g = 0; g < G; g++) {
-      const int b = b0 + g < count ? b0 + g : count - 1;  // tail tile: recompute the last ciphertext, never stored
-      ai[g] = in[(size_t)b * (n_in + 1) + i] + round_off;
-    }
-    const uint64_t *__restrict__ ki = ksk + (size_t)i * t * per_j * row;
-    for (int j = 0; j < t; j++) {
-      const int shift = 64 - (j + 1) * base_bit;
+  for (int k = 0; k < PF; k++) {
+    const int vv = sv0 + k * SV_STEP, jj = vv / cands, v = vv - jj * cands;
+    slot[k] = (jj * (cands + 1) + v + 1) * RS + tid % W;
+    goff[k] = (size_t)vv * row;
+  }
+  const bool in_row = (w0 + tid % W) < row;
+
+  uint64_t pf[PF];
+  const size_t i_stride = (size_t)t * cands * row;
+  const uint64_t *__restrict__ kbase = ksk + w0 + sw;
+  // prefetch stage (i = i_begin, j0 = 0)
+  {
+    const int last = ((t < JB ? t : JB) * cands - 1);
 #pragma unroll
-      for (int g = 0; g < G; g++) {
-        const uint32_t v = (uint32_t)((ai[g] >> shift) & mask);
-        const uint64_t *__restrict__ r = ki + ((size_t)j * per_j + (v ? v - 1 : 0)) * row;
-        const uint64_t keep = v ? ~0ull : 0ull;
+    for (int k = 0; k < PF; k++) pf[k] = kbase[(size_t)i_begin * i_stride + ((sv0 + k * SV_STEP <= last) ? goff[k] : (size_t)last * row)];
+  }
+  uint64_t a_next = inT[(size_t)i_begin * Bp + ct] + round_off;
+  int buf_sel = 0;
+  for (int i = i_begin; i < i_end; i++) {
+    const uint64_t a = a_next;
+    if (i + 1 < i_end) a_next = inT[(size_t)(i + 1) * Bp + ct] + round_off;
+    for (int j0 = 0; j0 < t; j0 += JB) {
+      const int jb = (t - j0 < JB) ? (t - j0) : JB;
+      uint64_t *buf = rows + (size_t)buf_sel * buf_words;
+      buf_sel ^= 1;
 #pragma unroll
-        for (int q = 0; q < KS_MAXC; q++) {
-          const int c = tid + q * KS_THREADS;
-          if (c < row) acc[g][q] -= r[c] & keep;
+      for (int k = 0; k < PF; k++)
+        if (in_row && sv0 + k * SV_STEP < jb * cands) buf[slot[k]] = pf[k];
+      __syncthreads();  // stage data visible; the other buffer is free (its readers passed the previous barrier)
+      // next stage: (i, j0 + JB) or (i + 1, 0)
+      {
+        int ni = i, nj = j0 + JB;
+        if (nj >= t) { ni = i + 1; nj = 0; }
+        if (ni < i_end) {
+          const int last = (((t - nj < JB) ? (t - nj) : JB) * cands - 1);
+          const uint64_t *__restrict__ src = kbase + (size_t)ni * i_stride + (size_t)nj * cands * row;
+#pragma unroll
+          for (int k = 0; k < PF; k++) pf[k] = src[(sv0 + k * SV_STEP <= last) ? goff[k] : (size_t)last * row];
+        }
+      }
+      for (int jj = 0; jj < jb; jj++) {
+        const uint32_t v = (uint32_t)(a >> (64 - (j0 + jj + 1) * base_bit)) & mask;
+        const ul2 *r = reinterpret_cast<const ul2 *>(buf + (size_t)(jj * (cands + 1) + v) * RS);  // 16-byte aligned rows
+#pragma unroll
+        for (int w = 0; w < W; w += 2) {
+          const ul2 x = r[w / 2];
+          acc[w] -= x.x;
+          acc[w + 1] -= x.y;
         }
       }
     }
   }
 #pragma unroll
-  for (int g = 0; g < G; g++) {
-    if (b0 + g >= count) break;
-    uint64_t *dst = out + (size_t)(b0 + g) * row;
-#pragma unroll
-    for (int q = 0; q < KS_MAXC; q++) {
-      const int c = tid + q * KS_THREADS;
-      if (c < n_out) dst[c] = acc[g][q];
-      else if (c == n_out) dst[c] = acc[g][q] + in[(size_t)(b0 + g) * (n_in + 1) + n_in];
-    }
-  }
+  for (int w = 0; w < W; w++)
+    if (w0 + w < row) outT[(size_t)(w0 + w) * Bp + ct] = acc[w];
 }
 
-inline void launch_tlwe_keyswitch(const uint64_t *ksk, uint64_t *out, const uint64_t *in, int count, int n_in, int n_out, int t,
-                                  int base_bit, hipStream_t s) {
-  constexpr int G = 8;
-  const int blocks = (count + G - 1) / G;
-  hipLaunchKernelGGL((tlwe_keyswitch_kernel<G>), dim3(blocks), dim3(KS_THREADS), 0, s, ksk, out, in, count, n_in, n_out, t, base_bit);
+struct KsWorkspace {
+  uint64_t *inT = nullptr, *outT = nullptr;
+  size_t words_in = 0, words_out = 0;
+};
+
+// Returns hipSuccess or the failing error.  ws is grown on demand (kept by the key handle between calls).
+inline hipError_t launch_tlwe_keyswitch(const uint64_t *ksk, uint64_t *out, const uint64_t *in, int count, int n_in, int n_out, int t,
+                                        int base_bit, KsWorkspace &ws, hipStream_t s) {
+  constexpr int W = KS_W, NW = KS_NW, TILE = 64 * NW;
+  const size_t Bp = ((size_t)count + TILE - 1) / TILE * TILE;
+  // split the mask words over blockIdx.z until the grid fills the chip (each workgroup walks its i-range serially)
+  const int slices = (n_out + 1 + W - 1) / W, ct_blocks = (int)(Bp / TILE);
+  int split = (1536 + slices * ct_blocks - 1) / (slices * ct_blocks);
+  if (split > 16) split = 16;
+  if (split > n_in / 8) split = n_in / 8;
+  if (split < 1) split = 1;
+  const int i_per_split = (n_in + split - 1) / split;
+  split = (n_in + i_per_split - 1) / i_per_split;
+  const size_t need_in = (size_t)(n_in + 1) * Bp, need_out = (size_t)split * (n_out + 1) * Bp;
+  hipError_t e;
+  if (ws.words_in < need_in) {
+    if (ws.inT) (void)hipFree(ws.inT);
+    if ((e = hipMalloc((void **)&ws.inT, need_in * sizeof(uint64_t))) != hipSuccess) return e;
+    ws.words_in = need_in;
+  }
+  if (ws.words_out < need_out) {
+    if (ws.outT) (void)hipFree(ws.outT);
+    if ((e = hipMalloc((void **)&ws.outT, need_out * sizeof(uint64_t))) != hipSuccess) return e;
+    ws.words_out = need_out;
+  }
+  if (Bp != (size_t)count && (e = hipMemsetAsync(ws.inT, 0, need_in * sizeof(uint64_t), s)) != hipSuccess) return e;
+  // in[count][n_in + 1] -> inT[n_in + 1][Bp]
+  hipLaunchKernelGGL(transpose_u64_kernel, dim3((n_in + 1 + 31) / 32, (count + 31) / 32), dim3(32, 8), 0, s, in, ws.inT, count, n_in + 1,
+                     (size_t)(n_in + 1), Bp, 1, (size_t)0);
+  const int cands = (1 << base_bit) - 1;
+  int JB = KS_LDS_BYTES / ((cands + 1) * (W + 2) * 8);          // per LDS buffer
+  const int pf_cap = KS_PF_MAX * (TILE / W) / cands;             // rows a stage can prefetch through registers
+  if (JB > pf_cap) JB = pf_cap;
+  if (JB < 1) JB = 1;
+  if (JB > t) JB = t;
+  if (cands > KS_PF_MAX * (TILE / W)) return hipErrorInvalidValue;  // base_bit too large for the staging registers
+  const size_t lds = 2 * (size_t)JB * (cands + 1) * (W + 2) * 8;
+  const int pf = (JB * cands + TILE / W - 1) / (TILE / W);
+  const dim3 grid(slices, ct_blocks, split);
+#define KS_LAUNCH(PF) hipLaunchKernelGGL((tlwe_keyswitch_kernel<W, NW, PF>), grid, dim3(TILE), lds, s, ksk, ws.inT, ws.outT, Bp, n_in, n_out, t, base_bit, JB, i_per_split)
+  switch (pf) {
+    case 1: KS_LAUNCH(1); break;
+    case 2: KS_LAUNCH(2); break;
+    case 3: KS_LAUNCH(3); break;
+    case 4: KS_LAUNCH(4); break;
+    case 5: KS_LAUNCH(5); break;
+    case 6: KS_LAUNCH(6); break;
+    case 7: KS_LAUNCH(7); break;
+    default: KS_LAUNCH(8); break;
+  }
+#undef KS_LAUNCH
+  // outT[n_out + 1][Bp] -> out[count][n_out + 1]
+  hipLaunchKernelGGL(transpose_u64_kernel, dim3((count + 31) / 32, (n_out + 1 + 31) / 32), dim3(32, 8), 0, s, ws.outT, out, n_out + 1, count,
+                     Bp, (size_t)(n_out + 1), split, (size_t)(n_out + 1) * Bp);
+  return hipGetLastError();
 }
 
 }  // namespace mosfhet
