@@ -108,11 +108,17 @@ void functional_bootstrap_wo_extract(TRLWE out, TRLWE tv, TLWE in, Bootstrap_Key
 void functional_bootstrap(TLWE out, TRLWE tv, TLWE in, Bootstrap_Key key, int torus_base);              /* :200-206 */
 void programmable_bootstrap(TLWE out, TRLWE tv, TLWE in, Bootstrap_Key key, int precision, int kappa, int theta); /* :208-220 */
 
+void full_domain_functional_bootstrap(TLWE out, TRLWE tv, TLWE in, Bootstrap_Key key, TLWE_KS_Key tlwe_ksk, int precision); /* :519-538 */
+void multivalue_bootstrap_CLOT21(TLWE *out, TRLWE tv, TLWE in, Bootstrap_Key key, int torus_base, int n_luts);              /* :222-230 */
+void trlwe_torus_packing_many_LUT(TRLWE out, Torus *in, int lut_size, int n_luts);   /* src/trlwe.c:677-687 (host) */
+
 /* ---- batch extensions (new): arrays of `count` samples, one shared test vector ---- */
 void functional_bootstrap_batch(TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_Key key, int torus_base);
 void programmable_bootstrap_batch(TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_Key key,
                                   int precision, int kappa, int theta);
 void tlwe_keyswitch_batch(TLWE *out, TLWE *in, int count, TLWE_KS_Key ks_key);
+void full_domain_functional_bootstrap_batch(TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_Key key, TLWE_KS_Key tlwe_ksk,
+                                            int precision);
 
 /* ---- flat helpers used by the Python binding and bench.py (new) ----
  * Generate a whole bootstrap / key-switch key in the flat torus-domain layouts of mosfhet_hip.h. */

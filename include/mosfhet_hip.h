@@ -121,6 +121,25 @@ int mosfhet_hip_ksk_destroy(mosfhet_hip_ksk_t ksk);
 int mosfhet_hip_tlwe_keyswitch_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t ksk, uint64_t *d_out /*[count][n_out+1]*/,
                                      const uint64_t *d_in /*[count][n_in+1]*/, int count, void *stream);
 
+/* trlwe_extract_tlwe at coefficient idx over a batch (src/trlwe.c:540-552), k = 1. */
+int mosfhet_hip_trlwe_extract_tlwe_batch(mosfhet_hip_ctx_t ctx, uint64_t *d_out /*[count][N+1]*/, const uint64_t *d_in /*[count][2][N]*/,
+                                         int N, int idx, int count, void *stream);
+/* tlwe_addto over a batch (src/tlwe.c:170-173): d_out[b] += d_in[b], samples of n+1 words. */
+int mosfhet_hip_tlwe_addto_batch(mosfhet_hip_ctx_t ctx, uint64_t *d_out, const uint64_t *d_in, int n, int count, void *stream);
+
+/* full_domain_functional_bootstrap over a batch (src/bootstrap.c:519-538): sign bootstrap with the constant test
+ * vector 2^62 - 2^(62-precision) at torus_base 2^(precision-1), b -= sign, LWE key switch (ksk: kN -> n), += input,
+ * second bootstrap with d_tv at torus_base 2^precision.  Scratch buffers live in the bsk handle. */
+int mosfhet_hip_full_domain_functional_bootstrap_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, mosfhet_hip_ksk_t ksk,
+                                                       uint64_t *d_out /*[count][kN+1]*/, const uint64_t *d_tv, int tv_count,
+                                                       const uint64_t *d_in /*[count][n+1]*/, int count, int precision, void *stream);
+
+/* multivalue_bootstrap_CLOT21 over a batch (src/bootstrap.c:222-230): one blind rotation at torus_base * n_luts,
+ * then n_luts sample extractions N / (n_luts * torus_base) coefficients apart. */
+int mosfhet_hip_multivalue_bootstrap_CLOT21_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_out /*[count][n_luts][kN+1]*/,
+                                                  const uint64_t *d_tv, int tv_count, const uint64_t *d_in, int count,
+                                                  int torus_base, int n_luts, void *stream);
+
 /* Timing hook for bench.py: runs `reps` launches of the programmable-bootstrap kernel on `stream`
  * bracketed by hipEvents ON THAT STREAM and returns the average kernel time in milliseconds
  * (synchronises the stream). */

@@ -44,6 +44,8 @@ struct mosfhet_hip_bsk {
   d2 *d_bk;  // [n][(k+1)l][k+1][P][lanes]
   int n, k, N, l, Bg_bit;
   size_t bytes;
+  uint64_t *scratch = nullptr;  // FDFB / multi-value temporaries, grown on demand
+  size_t scratch_words = 0;
 };
 
 struct mosfhet_hip_ksk {
@@ -187,6 +189,7 @@ extern "C" int mosfhet_hip_bsk_destroy(mosfhet_hip_bsk_t bsk) {
   if (!bsk) return MOSFHET_HIP_OK;
   hipSetDevice(bsk->ctx->device);
   hipFree(bsk->d_bk);
+  if (bsk->scratch) hipFree(bsk->scratch);
   delete bsk;
   return MOSFHET_HIP_OK;
 }
@@ -381,6 +384,84 @@ extern "C" int mosfhet_hip_tlwe_keyswitch_batch(mosfhet_hip_ctx_t ctx, mosfhet_h
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(launch_tlwe_keyswitch(ksk->d_ksk, d_out, d_in, count, ksk->n_in, ksk->n_out, ksk->t, ksk->base_bit, ksk->ws, pick(ctx, stream)));
+  return MOSFHET_HIP_OK;
+}
+
+// ---- glue entry points ----
+extern "C" int mosfhet_hip_trlwe_extract_tlwe_batch(mosfhet_hip_ctx_t ctx, uint64_t *d_out, const uint64_t *d_in, int N, int idx, int count,
+                                                    void *stream) {
+  if (!ctx || !d_out || !d_in || N < 1 || idx < 0 || idx >= N || count < 0) return fail(MOSFHET_HIP_EINVAL, "trlwe_extract: bad argument");
+  if (count == 0) return MOSFHET_HIP_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(trlwe_extract_kernel, dim3((N + 255) / 256, count), dim3(256), 0, pick(ctx, stream), d_out, (size_t)N + 1, d_in,
+                     (size_t)2 * N, N, idx);
+  HIP_TRY(hipGetLastError());
+  return MOSFHET_HIP_OK;
+}
+
+extern "C" int mosfhet_hip_tlwe_addto_batch(mosfhet_hip_ctx_t ctx, uint64_t *d_out, const uint64_t *d_in, int n, int count, void *stream) {
+  if (!ctx || !d_out || !d_in || n < 0 || count < 0) return fail(MOSFHET_HIP_EINVAL, "tlwe_addto: bad argument");
+  const size_t words = (size_t)count * (n + 1);
+  if (!words) return MOSFHET_HIP_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(words_addto_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, pick(ctx, stream), d_out, d_in, words);
+  HIP_TRY(hipGetLastError());
+  return MOSFHET_HIP_OK;
+}
+
+static int bsk_scratch(mosfhet_hip_bsk_t bsk, size_t words) {
+  if (bsk->scratch_words >= words) return MOSFHET_HIP_OK;
+  if (bsk->scratch) hipFree(bsk->scratch);
+  bsk->scratch = nullptr;
+  bsk->scratch_words = 0;
+  HIP_TRY(hipMalloc((void **)&bsk->scratch, words * sizeof(uint64_t)));
+  bsk->scratch_words = words;
+  return MOSFHET_HIP_OK;
+}
+
+extern "C" int mosfhet_hip_full_domain_functional_bootstrap_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, mosfhet_hip_ksk_t ksk,
+                                                                  uint64_t *d_out, const uint64_t *d_tv, int tv_count,
+                                                                  const uint64_t *d_in, int count, int precision, void *stream) {
+  if (!ctx || !bsk || !ksk || !d_out || !d_tv || !d_in || count < 0) return fail(MOSFHET_HIP_EINVAL, "fdfb: bad argument");
+  if (precision < 1 || precision > 30) return fail(MOSFHET_HIP_EINVAL, "fdfb: precision %d", precision);
+  if (ksk->n_in != bsk->k * bsk->N || ksk->n_out != bsk->n)
+    return fail(MOSFHET_HIP_EINVAL, "fdfb: key-switch key is %d -> %d, expected %d -> %d", ksk->n_in, ksk->n_out, bsk->k * bsk->N, bsk->n);
+  if (count == 0) return MOSFHET_HIP_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int N = bsk->N, n = bsk->n;
+  const size_t w_tv = (size_t)2 * N, w_sign = (size_t)count * (N + 1), w_in2 = (size_t)count * (n + 1);
+  int rc = bsk_scratch(bsk, w_tv + w_sign + w_in2);
+  if (rc) return rc;
+  uint64_t *tv_sign = bsk->scratch, *ct_sign = tv_sign + w_tv, *in2 = ct_sign + w_sign;
+  hipStream_t s = pick(ctx, stream);
+  // src/bootstrap.c:525-527: sign = 2^62 - 2^(62 - precision), constant test vector
+  const uint64_t sign = (1ull << 62) - (1ull << (62 - precision));
+  hipLaunchKernelGGL(trlwe_constant_kernel, dim3((N + 255) / 256), dim3(256), 0, s, tv_sign, N, sign);
+  if ((rc = mosfhet_hip_functional_bootstrap_batch(ctx, bsk, ct_sign, tv_sign, 1, d_in, count, 1 << (precision - 1), stream))) return rc;
+  hipLaunchKernelGGL(tlwe_add_to_b_kernel, dim3((count + 255) / 256), dim3(256), 0, s, ct_sign, count, (size_t)N + 1, (uint64_t)0 - sign);
+  if ((rc = mosfhet_hip_tlwe_keyswitch_batch(ctx, ksk, in2, ct_sign, count, stream))) return rc;
+  if ((rc = mosfhet_hip_tlwe_addto_batch(ctx, in2, d_in, n, count, stream))) return rc;
+  return mosfhet_hip_functional_bootstrap_batch(ctx, bsk, d_out, d_tv, tv_count, in2, count, 1 << precision, stream);
+}
+
+extern "C" int mosfhet_hip_multivalue_bootstrap_CLOT21_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_out,
+                                                             const uint64_t *d_tv, int tv_count, const uint64_t *d_in, int count,
+                                                             int torus_base, int n_luts, void *stream) {
+  if (!ctx || !bsk || !d_out || !d_tv || !d_in || count < 0 || torus_base < 1 || n_luts < 1)
+    return fail(MOSFHET_HIP_EINVAL, "multivalue_CLOT21: bad argument");
+  const int N = bsk->N;
+  if (N % (n_luts * torus_base)) return fail(MOSFHET_HIP_EINVAL, "multivalue_CLOT21: N not divisible by n_luts * torus_base");
+  if (count == 0) return MOSFHET_HIP_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  int rc = bsk_scratch(bsk, (size_t)count * 2 * N);
+  if (rc) return rc;
+  if ((rc = mosfhet_hip_functional_bootstrap_wo_extract_batch(ctx, bsk, bsk->scratch, d_tv, tv_count, d_in, count, torus_base * n_luts, stream)))
+    return rc;
+  const int slot = N / (n_luts * torus_base);
+  for (int i = 0; i < n_luts; i++)
+    hipLaunchKernelGGL(trlwe_extract_kernel, dim3((N + 255) / 256, count), dim3(256), 0, pick(ctx, stream), d_out + (size_t)i * (N + 1),
+                       (size_t)n_luts * (N + 1), bsk->scratch, (size_t)2 * N, N, i * slot);
+  HIP_TRY(hipGetLastError());
   return MOSFHET_HIP_OK;
 }
 

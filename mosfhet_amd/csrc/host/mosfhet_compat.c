@@ -510,6 +510,56 @@ void functional_bootstrap_wo_extract(TRLWE out, TRLWE tv, TLWE in, Bootstrap_Key
   bootstrap_many(MODE_WO_EXTRACT, NULL, out, tv, &in, 1, key, torus_base, 0, 0);
 }
 
+void trlwe_torus_packing_many_LUT(TRLWE out, Torus *in, int lut_size, int n_luts) {
+  const int N = out->b->N, span = N / (lut_size * n_luts);
+  trlwe_noiseless_trivial_sample(out, NULL);
+  for (int i = 0; i < lut_size; i++)
+    for (int j = 0; j < n_luts; j++)
+      for (int r = 0; r < span; r++) out->b->coeffs[(i * n_luts + j) * span + r] = in[j * lut_size + i];
+}
+
+void full_domain_functional_bootstrap_batch(TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_Key key, TLWE_KS_Key ksk, int precision) {
+  mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
+  const int n = key->n, N = key->N, k = key->k;
+  const size_t in_w = (size_t)count * (n + 1), tv_w = (size_t)(k + 1) * N, out_w = (size_t)count * (k * N + 1);
+  Torus *h = (Torus *)xmalloc(sizeof(Torus) * (in_w + tv_w + out_w));
+  tlwe_array_to_flat(h, in, count, n);
+  trlwe_to_flat(h + in_w, tv);
+  Torus *d = (Torus *)dev_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
+  dev_copy(d, h, sizeof(Torus) * (in_w + tv_w), HIP_H2D);
+  if (mosfhet_hip_full_domain_functional_bootstrap_batch(ctx, (mosfhet_hip_bsk_t)mosfhet_bootstrap_key_device(key),
+                                                         (mosfhet_hip_ksk_t)ksk->device, d + in_w + tv_w, d + in_w, 1, d, count, precision, NULL) ||
+      mosfhet_hip_ctx_sync(ctx, NULL))
+    die("full_domain_functional_bootstrap");
+  dev_copy(h + in_w + tv_w, d + in_w + tv_w, sizeof(Torus) * out_w, HIP_D2H);
+  tlwe_array_from_flat(out, h + in_w + tv_w, count, k * N);
+  hipFree(d);
+  free(h);
+}
+
+void full_domain_functional_bootstrap(TLWE out, TRLWE tv, TLWE in, Bootstrap_Key key, TLWE_KS_Key ksk, int precision) {
+  full_domain_functional_bootstrap_batch(&out, tv, &in, 1, key, ksk, precision);
+}
+
+void multivalue_bootstrap_CLOT21(TLWE *out, TRLWE tv, TLWE in, Bootstrap_Key key, int torus_base, int n_luts) {
+  mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
+  const int n = key->n, N = key->N, k = key->k;
+  const size_t in_w = (size_t)(n + 1), tv_w = (size_t)(k + 1) * N, out_w = (size_t)n_luts * (k * N + 1);
+  Torus *h = (Torus *)xmalloc(sizeof(Torus) * (in_w + tv_w + out_w));
+  tlwe_array_to_flat(h, &in, 1, n);
+  trlwe_to_flat(h + in_w, tv);
+  Torus *d = (Torus *)dev_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
+  dev_copy(d, h, sizeof(Torus) * (in_w + tv_w), HIP_H2D);
+  if (mosfhet_hip_multivalue_bootstrap_CLOT21_batch(ctx, (mosfhet_hip_bsk_t)mosfhet_bootstrap_key_device(key), d + in_w + tv_w, d + in_w, 1, d,
+                                                    1, torus_base, n_luts, NULL) ||
+      mosfhet_hip_ctx_sync(ctx, NULL))
+    die("multivalue_bootstrap_CLOT21");
+  dev_copy(h + in_w + tv_w, d + in_w + tv_w, sizeof(Torus) * out_w, HIP_D2H);
+  tlwe_array_from_flat(out, h + in_w + tv_w, n_luts, k * N);
+  hipFree(d);
+  free(h);
+}
+
 void blind_rotate(TRLWE tv, Torus *a, TRGSW_DFT *s, int size) {
   Bootstrap_Key key = NULL;
   for (int i = 0; i < MAX_KEYS; i++)

@@ -155,6 +155,35 @@ __global__ __launch_bounds__(64 * NW) void tlwe_keyswitch_kernel(const uint64_t 
     if (w0 + w < row) outT[(size_t)(w0 + w) * Bp + ct] = acc[w];
 }
 
+// ---- small batched TLWE / TRLWE glue kernels (all exact mod 2^64) ----
+// tlwe_addto over flat batches [src/tlwe.c:170-173]: out[i] += in[i]
+__global__ void words_addto_kernel(uint64_t *__restrict__ out, const uint64_t *__restrict__ in, size_t words) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < words) out[i] += in[i];
+}
+
+// ct[b].b += delta for every sample of a batch (row = n + 1 words)  [src/bootstrap.c:530: ct_sign->b -= sign]
+__global__ void tlwe_add_to_b_kernel(uint64_t *__restrict__ ct, int count, size_t row, uint64_t delta) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < count) ct[(size_t)b * row + row - 1] += delta;
+}
+
+// fill a trivial TRLWE whose b polynomial is the constant `value` (trlwe_torus_packing with one slot, src/trlwe.c:662-667)
+__global__ void trlwe_constant_kernel(uint64_t *__restrict__ tv, int N, uint64_t value) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) { tv[i] = 0; tv[N + i] = value; }
+}
+
+// trlwe_extract_tlwe at coefficient idx for a batch (k = 1) [src/trlwe.c:540-552]; in stride / out stride in words
+__global__ void trlwe_extract_kernel(uint64_t *__restrict__ out, size_t out_stride, const uint64_t *__restrict__ in, size_t in_stride,
+                                     int N, int idx) {
+  const uint64_t *c = in + (size_t)blockIdx.y * in_stride;
+  uint64_t *o = out + (size_t)blockIdx.y * out_stride;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < N) o[j] = (j <= idx) ? c[idx - j] : (0 - c[N + idx - j]);
+  if (j == 0) o[N] = c[N + idx];
+}
+
 struct KsWorkspace {
   uint64_t *inT = nullptr, *outT = nullptr;
   size_t words_in = 0, words_out = 0;

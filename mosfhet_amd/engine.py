@@ -224,6 +224,36 @@ class Engine:
         _check(lib().mosfhet_hip_tlwe_keyswitch_batch(self.h, ksk.h, _ptr(out), _ptr(ct), count, self._stream()))
         return out
 
+    def trlwe_extract_tlwe(self, trlwe, idx, out=None):
+        count, k1, N = trlwe.shape
+        assert k1 == 2
+        if out is None:
+            out = self.empty(count, N + 1)
+        _check(lib().mosfhet_hip_trlwe_extract_tlwe_batch(self.h, _ptr(out), _ptr(trlwe), N, idx, count, self._stream()))
+        return out
+
+    def tlwe_addto_(self, out, ct):
+        count, row = ct.shape
+        assert out.shape == ct.shape
+        _check(lib().mosfhet_hip_tlwe_addto_batch(self.h, _ptr(out), _ptr(ct), row - 1, count, self._stream()))
+        return out
+
+    def full_domain_functional_bootstrap(self, bsk, ksk, tv, ct, precision, out=None):
+        count = ct.shape[0]
+        if out is None:
+            out = self.empty(count, bsk.k * bsk.N + 1)
+        _check(lib().mosfhet_hip_full_domain_functional_bootstrap_batch(
+            self.h, bsk.h, ksk.h, _ptr(out), _ptr(tv), self._tv(tv, bsk, count), _ptr(ct), count, precision, self._stream()))
+        return out
+
+    def multivalue_bootstrap_CLOT21(self, bsk, tv, ct, torus_base, n_luts, out=None):
+        count = ct.shape[0]
+        if out is None:
+            out = self.empty(count, n_luts, bsk.k * bsk.N + 1)
+        _check(lib().mosfhet_hip_multivalue_bootstrap_CLOT21_batch(
+            self.h, bsk.h, _ptr(out), _ptr(tv), self._tv(tv, bsk, count), _ptr(ct), count, torus_base, n_luts, self._stream()))
+        return out
+
     # ---- measurement ----
     def time_programmable_bootstrap(self, bsk, tv, ct, precision, reps, out=None):
         """Average milliseconds per kernel launch, hipEvents on the launch stream."""

@@ -116,3 +116,14 @@ def torus_packing(lut, k, N):
     tv = np.zeros((k + 1, N), dtype=np.uint64)
     tv[k] = np.repeat(lut, N // lut.size)
     return tv
+
+
+def torus_packing_many_lut(lut, k, N, lut_size, n_luts):
+    """trlwe_torus_packing_many_LUT (src/trlwe.c:677-687): n_luts LUTs of lut_size slots, interleaved."""
+    lut = np.asarray(lut, dtype=np.uint64)
+    tv = np.zeros((k + 1, N), dtype=np.uint64)
+    span = N // (lut_size * n_luts)
+    for i in range(lut_size):
+        for j in range(n_luts):
+            tv[k, (i * n_luts + j) * span:(i * n_luts + j + 1) * span] = lut[j * lut_size + i]
+    return tv

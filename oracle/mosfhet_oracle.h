@@ -100,6 +100,13 @@ void orc_programmable_bootstrap(const orc_fft_plan *p, Torus *out, const Torus *
                       const double *bk_dft, int n, int k, int l, int Bg_bit,
                       int precision, int kappa, int theta);                            /* bootstrap.c:208-220 */
 
+void orc_full_domain_functional_bootstrap(const orc_fft_plan *p, Torus *out /*[kN+1]*/, const Torus *tv, const Torus *in /*[n+1]*/,
+                      const double *bk_dft, const Torus *ksk /*[kN][t][2^bb-1][n+1]*/, int n, int k, int l, int Bg_bit,
+                      int t, int base_bit, int precision);                             /* bootstrap.c:519-538 */
+void orc_multivalue_bootstrap_CLOT21(const orc_fft_plan *p, Torus *out /*[n_luts][kN+1]*/, const Torus *tv, const Torus *in,
+                      const double *bk_dft, int n, int k, int l, int Bg_bit, int torus_base, int n_luts); /* bootstrap.c:222-230 */
+void orc_trlwe_torus_packing_many_LUT(Torus *out, const Torus *lut, int k, int N, int lut_size, int n_luts); /* trlwe.c:677-687 */
+
 /* ---- deterministic test-input generation (own code; the reference's RNG is RDRAND-seeded
  *      and not reproducible, src/misc.c:34-49) ---- */
 typedef struct { uint64_t s; } orc_rng;

@@ -276,6 +276,28 @@ def programmable_bootstrap(tv, c, bk_dft, l, Bg_bit, precision, kappa, theta):
     return out
 
 
+def full_domain_functional_bootstrap(tv, c, bk_dft, ksk, l, Bg_bit, t, base_bit, precision):
+    k1, N = tv.shape
+    out = np.empty((k1 - 1) * N + 1, dtype=np.uint64)
+    lib().orc_full_domain_functional_bootstrap(plan(N).h, _u(out), _u(tv), _u(c), _d(bk_dft), _u(ksk), C.c_int(c.size - 1),
+                                               k1 - 1, l, Bg_bit, t, base_bit, precision)
+    return out
+
+
+def multivalue_bootstrap_CLOT21(tv, c, bk_dft, l, Bg_bit, torus_base, n_luts):
+    k1, N = tv.shape
+    out = np.empty((n_luts, (k1 - 1) * N + 1), dtype=np.uint64)
+    lib().orc_multivalue_bootstrap_CLOT21(plan(N).h, _u(out), _u(tv), _u(c), _d(bk_dft), C.c_int(c.size - 1), k1 - 1, l, Bg_bit,
+                                          torus_base, n_luts)
+    return out
+
+
+def trlwe_torus_packing_many_LUT(lut, k, N, lut_size, n_luts):
+    out = np.empty((k + 1, N), dtype=np.uint64)
+    lib().orc_trlwe_torus_packing_many_LUT(_u(out), _u(u64(lut)), k, N, lut_size, n_luts)
+    return out
+
+
 # ---------------- deterministic inputs ----------------
 def gen_binary_key(rng, n):
     s = np.empty(n, dtype=np.uint64)

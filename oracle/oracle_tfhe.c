@@ -117,6 +117,51 @@ void orc_programmable_bootstrap(const orc_fft_plan *p, Torus *out, const Torus *
   free(tmp);
 }
 
+/* src/bootstrap.c:519-538  full-domain functional bootstrap ("this work"): a first bootstrap with the constant
+ * test vector `sign` extracts the sign of the phase; ct_sign.b -= sign; key switch back to dimension n; add the
+ * input; second bootstrap with the user's test vector at doubled torus_base. */
+void orc_full_domain_functional_bootstrap(const orc_fft_plan *p, Torus *out, const Torus *tv, const Torus *in,
+                                          const double *bk_dft, const Torus *ksk, int n, int k, int l, int Bg_bit,
+                                          int t, int base_bit, int precision) {
+  int cnt = 0;
+  (void)orc_fft_twiddles(p, &cnt);
+  const int N = 2 * (cnt + 1);
+  Torus *tv_sign = (Torus *)malloc(sizeof(Torus) * (size_t)(k + 1) * N);
+  Torus *ct_sign = (Torus *)malloc(sizeof(Torus) * (size_t)(k * N + 1));
+  Torus *in2 = (Torus *)malloc(sizeof(Torus) * (size_t)(n + 1));
+  const Torus sign = ((Torus)1 << (W - 2)) - ((Torus)1 << (W - precision - 2));
+  orc_trlwe_torus_packing(tv_sign, &sign, k, N, 1);
+  orc_functional_bootstrap(p, ct_sign, tv_sign, in, bk_dft, n, k, l, Bg_bit, 1 << (precision - 1));
+  ct_sign[(size_t)k * N] -= sign;
+  orc_tlwe_keyswitch(in2, ct_sign, ksk, k * N, n, t, base_bit);
+  for (int i = 0; i <= n; i++) in2[i] += in[i];
+  orc_functional_bootstrap(p, out, tv, in2, bk_dft, n, k, l, Bg_bit, 1 << precision);
+  free(tv_sign);
+  free(ct_sign);
+  free(in2);
+}
+
+/* src/bootstrap.c:222-230  one blind rotation at torus_base * n_luts, then n_luts extractions slot_size apart */
+void orc_multivalue_bootstrap_CLOT21(const orc_fft_plan *p, Torus *out, const Torus *tv, const Torus *in,
+                                     const double *bk_dft, int n, int k, int l, int Bg_bit, int torus_base, int n_luts) {
+  int cnt = 0;
+  (void)orc_fft_twiddles(p, &cnt);
+  const int N = 2 * (cnt + 1), slot_size = N / (n_luts * torus_base);
+  Torus *acc = (Torus *)malloc(sizeof(Torus) * (size_t)(k + 1) * N);
+  orc_functional_bootstrap_wo_extract(p, acc, tv, in, bk_dft, n, k, l, Bg_bit, torus_base * n_luts);
+  for (int i = 0; i < n_luts; i++) orc_trlwe_extract_tlwe(out + (size_t)i * (k * N + 1), acc, k, N, i * slot_size);
+  free(acc);
+}
+
+/* src/trlwe.c:677-687  interleaved packing of n_luts LUTs of lut_size slots */
+void orc_trlwe_torus_packing_many_LUT(Torus *out, const Torus *lut, int k, int N, int lut_size, int n_luts) {
+  memset(out, 0, sizeof(Torus) * (size_t)(k + 1) * N);
+  const int span = N / (lut_size * n_luts);
+  for (int i = 0; i < lut_size; i++)
+    for (int j = 0; j < n_luts; j++)
+      for (int r = 0; r < span; r++) out[(size_t)k * N + (size_t)(i * n_luts + j) * span + r] = lut[j * lut_size + i];
+}
+
 /* ------------------------------------------------------------------------------------------
  * Deterministic inputs.  The reference seeds from RDRAND / urandom (src/misc.c:34-49) and is not
  * reproducible, so tests draw keys and samples from splitmix64 with the same distributions.

@@ -268,6 +268,37 @@ void ref_tlwe_keyswitch(Torus *out, const Torus *in, void *h, int n_out) {
   free_tlwe(o);
 }
 
+/* ---------- FDFB / multi-value (src/bootstrap.c:519-538, 222-230) ---------- */
+void ref_full_domain_functional_bootstrap(Torus *out, const Torus *tv, const Torus *in, void *bkh, void *kskh, int precision) {
+  Bootstrap_Key bk = (Bootstrap_Key)bkh;
+  TRLWE t = trlwe_from_flat(tv, bk->k, bk->N);
+  TLWE c = tlwe_from_flat(in, bk->n), o = tlwe_alloc_sample(bk->k * bk->N);
+  full_domain_functional_bootstrap(o, t, c, bk, (TLWE_KS_Key)kskh, precision);
+  tlwe_to_flat(out, o);
+  free_trlwe(t);
+  free_tlwe(c);
+  free_tlwe(o);
+}
+
+void ref_multivalue_bootstrap_CLOT21(Torus *out, const Torus *tv, const Torus *in, void *bkh, int torus_base, int n_luts) {
+  Bootstrap_Key bk = (Bootstrap_Key)bkh;
+  TRLWE t = trlwe_from_flat(tv, bk->k, bk->N);
+  TLWE c = tlwe_from_flat(in, bk->n);
+  TLWE *o = tlwe_alloc_sample_array(n_luts, bk->k * bk->N);
+  multivalue_bootstrap_CLOT21(o, t, c, bk, torus_base, n_luts);
+  for (int i = 0; i < n_luts; i++) tlwe_to_flat(out + (size_t)i * (bk->k * bk->N + 1), o[i]);
+  free_trlwe(t);
+  free_tlwe(c);
+  free_tlwe_array(o, n_luts);
+}
+
+void ref_trlwe_torus_packing_many_LUT(Torus *out, Torus *lut, int k, int N, int lut_size, int n_luts) {
+  TRLWE c = trlwe_alloc_new_sample(k, N);
+  trlwe_torus_packing_many_LUT(c, lut, lut_size, n_luts);
+  trlwe_to_flat(out, c, N);
+  free_trlwe(c);
+}
+
 /* ---------- CPU baseline: time `reps` reference programmable bootstraps on the calling thread.
  * Re-entrant across threads once ref_init(N) has run on the main thread (FFT processors are
  * __thread, src/polynomial.c:338-349). Returns elapsed seconds. ---------- */

@@ -176,6 +176,24 @@ class Ref:
         self.l.ref_tlwe_keyswitch(_u(out), _u(c), h, n_out)
         return out
 
+    def full_domain_functional_bootstrap(self, tv, c, bkh, kskh, precision):
+        k1, N = tv.shape
+        out = np.empty((k1 - 1) * N + 1, dtype=np.uint64)
+        self.l.ref_full_domain_functional_bootstrap(_u(out), _u(tv), _u(c), bkh, kskh, precision)
+        return out
+
+    def multivalue_bootstrap_CLOT21(self, tv, c, bkh, torus_base, n_luts):
+        k1, N = tv.shape
+        out = np.empty((n_luts, (k1 - 1) * N + 1), dtype=np.uint64)
+        self.l.ref_multivalue_bootstrap_CLOT21(_u(out), _u(tv), _u(c), bkh, torus_base, n_luts)
+        return out
+
+    def trlwe_torus_packing_many_LUT(self, lut, k, N, lut_size, n_luts):
+        lut = np.ascontiguousarray(lut, dtype=np.uint64)
+        out = np.empty((k + 1, N), dtype=np.uint64)
+        self.l.ref_trlwe_torus_packing_many_LUT(_u(out), _u(lut), k, N, lut_size, n_luts)
+        return out
+
     def bench_programmable_bootstrap(self, tv, c, h, precision, reps):
         """Seconds for `reps` programmable_bootstrap calls on the calling thread (GIL released)."""
         return self.l.ref_bench_programmable_bootstrap(_u(tv), _u(c), h, precision, reps)

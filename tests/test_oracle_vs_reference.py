@@ -86,3 +86,33 @@ def test_blind_rotate_and_bootstrap_short_key(oracle, ref):
     got = oracle.programmable_bootstrap(tv, c, bk_dft, l, Bg, 4, 2, 1)
     assert oracle.torus_dist(got, ref.programmable_bootstrap(tv, c, h, 4, 2, 1)).max() < 2.0 ** 38
     ref.bk_free(h)
+
+
+def test_fdfb_and_multivalue_short_key(oracle, ref):
+    """full_domain_functional_bootstrap (src/bootstrap.c:519-538) and multivalue_bootstrap_CLOT21 (:222-230) with a
+    12-bit LWE key at SET_1 ring parameters: the integer glue (sign LUT, b -= sign, key switch, add, many-LUT packing,
+    extraction offsets) must agree with the reference; FFT parts within the short-key ciphertext tolerance."""
+    rng = oracle.Rng(0x999)
+    N, l, Bg, sigma, n, t, bb = 1024, 2, 8, 2.98e-8, 12, 5, 2
+    lwe_s = oracle.gen_binary_key(rng, n)
+    rlwe_s = oracle.gen_binary_key(rng, N).reshape(1, N)
+    bk = oracle.gen_bootstrap_key(rng, lwe_s, rlwe_s, l, Bg, sigma)
+    bk_dft = oracle.bk_to_dft(bk, 1, l)
+    ksk = oracle.gen_tlwe_ks_key(rng, rlwe_s.reshape(-1).copy(), lwe_s, t, bb, 2.0 ** -30)
+    h, kh = ref.bk_new(bk, 1, l, Bg), ref.ksk_new(ksk, bb)
+    lut = oracle.u64(rng.words(8))
+    tv = oracle.trlwe_torus_packing_many_LUT(lut, 1, N, 4, 2)
+    assert (tv == ref.trlwe_torus_packing_many_LUT(lut, 1, N, 4, 2)).all()
+    for m in range(8):
+        c = oracle.tlwe_sample(rng, (m << 61) % 2 ** 64, lwe_s, 2.0 ** -30)
+        mine = oracle.full_domain_functional_bootstrap(tv, c, bk_dft, ksk, l, Bg, t, bb, 3)
+        theirs = ref.full_domain_functional_bootstrap(tv, c, h, kh, 3)
+        assert oracle.torus_dist(mine, theirs).max() < 2.0 ** 40, m
+    lut16 = oracle.u64(rng.words(16))
+    tv16 = oracle.trlwe_torus_packing(lut16, 1, N)
+    c = oracle.tlwe_sample(rng, oracle.double2torus(0.25), lwe_s, 2.0 ** -30)
+    mine = oracle.multivalue_bootstrap_CLOT21(tv16, c, bk_dft, l, Bg, 2, 8)
+    theirs = ref.multivalue_bootstrap_CLOT21(tv16, c, h, 2, 8)
+    assert oracle.torus_dist(mine, theirs).max() < 2.0 ** 38
+    ref.bk_free(h)
+    ref.ksk_free(kh)
