@@ -44,6 +44,7 @@ extern "C" {
 #endif
 
 typedef uint64_t Torus;
+typedef struct { uint64_t s; } orc_rng;   /* splitmix64 state of the deterministic test-input generator */
 
 /* ---- scalars (src/misc.c:13-28) ---- */
 Torus    orc_double2torus(double x);
@@ -107,9 +108,26 @@ void orc_multivalue_bootstrap_CLOT21(const orc_fft_plan *p, Torus *out /*[n_luts
                       const double *bk_dft, int n, int k, int l, int Bg_bit, int torus_base, int n_luts); /* bootstrap.c:222-230 */
 void orc_trlwe_torus_packing_many_LUT(Torus *out, const Torus *lut, int k, int N, int lut_size, int n_luts); /* trlwe.c:677-687 */
 
+/* ---- FFT-based TRLWE key switch, Galois automorphisms, GA bootstrap (k = 1) ---- */
+void orc_trlwe_keyswitch(const orc_fft_plan *p, Torus *out /*[2][N], may alias in*/, const Torus *in, const double *ks_dft /*[t][2][N]*/,
+                         int t, int base_bit);                                          /* keyswitch.c:162-193 */
+void orc_trlwe_eval_automorphism(const orc_fft_plan *p, Torus *out, const Torus *in, uint64_t gen, const double *ks_dft,
+                                 int t, int base_bit);                                  /* trlwe.c:775-781 */
+uint32_t orc_inverse_mod_2N(uint32_t x, int N);                                         /* misc.c:142-159 (odd x) */
+void orc_blind_rotate_ga(const orc_fft_plan *p, Torus *acc, const Torus *a, const double *bk_dft, const double *ak_dft /*[N][t][2][N]*/,
+                         int n, int l, int Bg_bit);                                     /* bootstrap_ga.c:39-60 (t = l, base_bit = Bg_bit) */
+void orc_functional_bootstrap_wo_extract_ga(const orc_fft_plan *p, Torus *out, const Torus *tv, const Torus *in, const double *bk_dft,
+                         const double *ak_dft, int n, int l, int Bg_bit, int torus_base); /* bootstrap_ga.c:62-68 */
+void orc_functional_bootstrap_ga(const orc_fft_plan *p, Torus *out, const Torus *tv, const Torus *in, const double *bk_dft,
+                         const double *ak_dft, int n, int l, int Bg_bit, int torus_base); /* bootstrap_ga.c:70-76 */
+void orc_gen_trlwe_ks_key(orc_rng *r, Torus *ks /*[t][2][N]*/, const Torus *s_in /*[N]*/, const Torus *s_out /*[N]*/, int N, int t,
+                          int base_bit, double sigma);                                  /* keyswitch.c:12-37 */
+void orc_gen_automorphism_keyset(orc_rng *r, Torus *ak /*[N][t][2][N]*/, const Torus *s, int N, int t, int base_bit, double sigma); /* keyswitch.c:500-511, skip_even */
+void orc_gen_bootstrap_key_ga(orc_rng *r, Torus *bk, const Torus *lwe_s, int n, const Torus *rlwe_s, int N, int l, int Bg_bit,
+                              double sigma);                                            /* bootstrap_ga.c:17-20: BK_i = TRGSW(X^{s_i}) */
+
 /* ---- deterministic test-input generation (own code; the reference's RNG is RDRAND-seeded
  *      and not reproducible, src/misc.c:34-49) ---- */
-typedef struct { uint64_t s; } orc_rng;
 uint64_t orc_rng_next(orc_rng *r);                       /* splitmix64 */
 double   orc_rng_normal(orc_rng *r, double sigma);       /* Box-Muller as misc.c:87-91 */
 void orc_gen_binary_key(orc_rng *r, Torus *s, int n);    /* tlwe.c:70-82 with bound 2 */

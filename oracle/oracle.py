@@ -298,6 +298,68 @@ def trlwe_torus_packing_many_LUT(lut, k, N, lut_size, n_luts):
     return out
 
 
+# ---------------- GA / TRLWE key switch ----------------
+def trlwe_keyswitch(c, ks_dft, t, base_bit):
+    out = np.empty_like(c)
+    lib().orc_trlwe_keyswitch(plan(c.shape[1]).h, _u(out), _u(c), _d(ks_dft), t, base_bit)
+    return out
+
+
+def trlwe_eval_automorphism(c, gen, ks_dft, t, base_bit):
+    out = np.empty_like(c)
+    lib().orc_trlwe_eval_automorphism(plan(c.shape[1]).h, _u(out), _u(c), C.c_uint64(gen), _d(ks_dft), t, base_bit)
+    return out
+
+
+def inverse_mod_2N(x, N):
+    lib().orc_inverse_mod_2N.restype = C.c_uint32
+    return lib().orc_inverse_mod_2N(C.c_uint32(x), N)
+
+
+def ks_to_dft(ks):
+    """TRLWE key-switch rows u64[...][2][N] -> float64 same shape (oracle slot order)."""
+    N = ks.shape[-1]
+    flat = np.ascontiguousarray(ks.reshape(-1, N))
+    out = np.empty(flat.shape, dtype=np.float64)
+    for i in range(flat.shape[0]):
+        out[i] = torus_to_dft(flat[i])
+    return out.reshape(ks.shape)
+
+
+def functional_bootstrap_ga(tv, c, bk_dft, ak_dft, l, Bg_bit, torus_base, extract=True):
+    k1, N = tv.shape
+    n = c.size - 1
+    if extract:
+        out = np.empty(N + 1, dtype=np.uint64)
+        lib().orc_functional_bootstrap_ga(plan(N).h, _u(out), _u(tv), _u(c), _d(bk_dft), _d(ak_dft), n, l, Bg_bit, torus_base)
+    else:
+        out = np.empty_like(tv)
+        lib().orc_functional_bootstrap_wo_extract_ga(plan(N).h, _u(out), _u(tv), _u(c), _d(bk_dft), _d(ak_dft), n, l, Bg_bit, torus_base)
+    return out
+
+
+def gen_trlwe_ks_key(rng, s_in, s_out, t, base_bit, sigma):
+    N = s_in.size
+    ks = np.empty((t, 2, N), dtype=np.uint64)
+    lib().orc_gen_trlwe_ks_key(rng.ref(), _u(ks), _u(s_in), _u(s_out), N, t, base_bit, C.c_double(sigma))
+    return ks
+
+
+def gen_automorphism_keyset(rng, s, t, base_bit, sigma):
+    N = s.size
+    ak = np.empty((N, t, 2, N), dtype=np.uint64)
+    lib().orc_gen_automorphism_keyset(rng.ref(), _u(ak), _u(s), N, t, base_bit, C.c_double(sigma))
+    return ak
+
+
+def gen_bootstrap_key_ga(rng, lwe_s, rlwe_s, l, Bg_bit, sigma):
+    k, N = rlwe_s.shape
+    n = lwe_s.size
+    bk = np.empty((n, 2 * l, 2, N), dtype=np.uint64)
+    lib().orc_gen_bootstrap_key_ga(rng.ref(), _u(bk), _u(lwe_s), n, _u(rlwe_s), N, l, Bg_bit, C.c_double(sigma))
+    return bk
+
+
 # ---------------- deterministic inputs ----------------
 def gen_binary_key(rng, n):
     s = np.empty(n, dtype=np.uint64)

@@ -163,6 +163,132 @@ void orc_trlwe_torus_packing_many_LUT(Torus *out, const Torus *lut, int k, int N
 }
 
 /* ------------------------------------------------------------------------------------------
+ * FFT-based TRLWE key switch, Galois automorphisms and the GA blind rotation (k = 1).
+ * ------------------------------------------------------------------------------------------ */
+/* src/keyswitch.c:162-193  out = (0, in.b) - IDFT( sum_j DFT(digit_j(in.a)) (.) KS[j] ), rounded digits of
+ * polynomial_decompose_i with (base_bit, t).  In-place use (out == in) is relied upon by trlwe.c:780. */
+void orc_trlwe_keyswitch(const orc_fft_plan *p, Torus *out, const Torus *in, const double *ks_dft, int t, int base_bit) {
+  int cnt = 0;
+  (void)orc_fft_twiddles(p, &cnt);
+  const int N = 2 * (cnt + 1);
+  Torus *dec = (Torus *)malloc(sizeof(Torus) * (size_t)N);
+  Torus *as = (Torus *)malloc(sizeof(Torus) * (size_t)2 * N);
+  double *dec_dft = (double *)malloc(sizeof(double) * (size_t)N);
+  double *acc = (double *)calloc((size_t)2 * N, sizeof(double));
+  for (int j = 0; j < t; j++) {
+    orc_poly_decompose_i(dec, in, N, base_bit, t, j);
+    orc_int_to_dft(p, dec_dft, (const int64_t *)dec);
+    for (int c = 0; c < 2; c++) orc_dft_mul_addto(acc + (size_t)c * N, dec_dft, ks_dft + ((size_t)j * 2 + c) * N, N);
+  }
+  for (int c = 0; c < 2; c++) orc_dft_to_torus(p, as + (size_t)c * N, acc + (size_t)c * N);
+  for (int i = 0; i < N; i++) {
+    const Torus b = in[N + i];
+    out[i] = (Torus)0 - as[i];
+    out[N + i] = b - as[N + i];
+  }
+  free(dec);
+  free(as);
+  free(dec_dft);
+  free(acc);
+}
+
+/* src/trlwe.c:775-781  X -> X^gen on both components, then key switch back from s(X^gen) to s(X) */
+void orc_trlwe_eval_automorphism(const orc_fft_plan *p, Torus *out, const Torus *in, uint64_t gen, const double *ks_dft,
+                                 int t, int base_bit) {
+  int cnt = 0;
+  (void)orc_fft_twiddles(p, &cnt);
+  const int N = 2 * (cnt + 1);
+  Torus *tmp = (Torus *)malloc(sizeof(Torus) * (size_t)2 * N);
+  orc_poly_permute(tmp, in, N, gen);
+  orc_poly_permute(tmp + N, in + N, N, gen);
+  orc_trlwe_keyswitch(p, out, tmp, ks_dft, t, base_bit);
+  free(tmp);
+}
+
+/* src/misc.c:142-159 tabulates the inverses of odd x modulo 2N; computed here by Newton iteration mod 2^k */
+uint32_t orc_inverse_mod_2N(uint32_t x, int N) {
+  const uint32_t mask = 2u * (uint32_t)N - 1;
+  uint32_t inv = x;  /* x * x = 1 mod 8 */
+  for (int i = 0; i < 4; i++) inv = (inv * (2u - x * inv)) & mask;
+  return inv & mask;
+}
+
+/* src/bootstrap_ga.c:39-60  blind rotation with automorphisms; every a_i is forced odd */
+void orc_blind_rotate_ga(const orc_fft_plan *p, Torus *acc, const Torus *a, const double *bk_dft, const double *ak_dft,
+                         int n, int l, int Bg_bit) {
+  int cnt = 0;
+  (void)orc_fft_twiddles(p, &cnt);
+  const int N = 2 * (cnt + 1), log_2N = log2_int(2 * N);
+  const uint64_t mod_mask = 2 * (uint64_t)N - 1;
+  const size_t trgsw_sz = (size_t)2 * l * 2 * N, ak_sz = (size_t)l * 2 * N;
+  Torus *rot = (Torus *)malloc(sizeof(Torus) * (size_t)2 * N);
+  const uint64_t w0 = orc_inverse_mod_2N((uint32_t)(orc_torus2int(a[0], log_2N) | 1), N);
+  orc_trlwe_eval_automorphism(p, rot, acc, w0, ak_dft + ((w0 - 1) >> 1) * ak_sz, l, Bg_bit);
+  for (int i = 0; i < n - 1; i++) {
+    const uint64_t ai = orc_torus2int(a[i], log_2N) | 1;
+    const uint64_t w1 = orc_inverse_mod_2N((uint32_t)(orc_torus2int(a[i + 1], log_2N) | 1), N);
+    const uint64_t gen = (ai * w1) & mod_mask;
+    orc_external_product(p, acc, rot, bk_dft + (size_t)i * trgsw_sz, 1, l, Bg_bit);
+    orc_trlwe_eval_automorphism(p, rot, acc, gen, ak_dft + ((gen - 1) >> 1) * ak_sz, l, Bg_bit);
+  }
+  const uint64_t an = orc_torus2int(a[n - 1], log_2N) | 1;
+  orc_external_product(p, rot, rot, bk_dft + (size_t)(n - 1) * trgsw_sz, 1, l, Bg_bit);
+  orc_trlwe_eval_automorphism(p, acc, rot, an, ak_dft + ((an - 1) >> 1) * ak_sz, l, Bg_bit);
+  free(rot);
+}
+
+/* src/bootstrap_ga.c:62-68 */
+void orc_functional_bootstrap_wo_extract_ga(const orc_fft_plan *p, Torus *out, const Torus *tv, const Torus *in, const double *bk_dft,
+                                            const double *ak_dft, int n, int l, int Bg_bit, int torus_base) {
+  int cnt = 0;
+  (void)orc_fft_twiddles(p, &cnt);
+  const int N = 2 * (cnt + 1), log_2N = log2_int(2 * N);
+  const Torus prec_offset = orc_double2torus(1. / (4 * torus_base));
+  const int rot = 2 * N - (int)orc_torus2int(in[n] + prec_offset, log_2N);
+  for (int c = 0; c < 2; c++) orc_poly_mul_by_xai(out + (size_t)c * N, tv + (size_t)c * N, N, rot);
+  orc_blind_rotate_ga(p, out, in, bk_dft, ak_dft, n, l, Bg_bit);
+}
+
+/* src/bootstrap_ga.c:70-76 */
+void orc_functional_bootstrap_ga(const orc_fft_plan *p, Torus *out, const Torus *tv, const Torus *in, const double *bk_dft,
+                                 const double *ak_dft, int n, int l, int Bg_bit, int torus_base) {
+  int cnt = 0;
+  (void)orc_fft_twiddles(p, &cnt);
+  const int N = 2 * (cnt + 1);
+  Torus *acc = (Torus *)malloc(sizeof(Torus) * (size_t)2 * N);
+  orc_functional_bootstrap_wo_extract_ga(p, acc, tv, in, bk_dft, ak_dft, n, l, Bg_bit, torus_base);
+  orc_trlwe_extract_tlwe(out, acc, 1, N, 0);
+  free(acc);
+}
+
+/* src/keyswitch.c:12-37  KS[j] = TRLWE_out( s_in(X) * 2^(W-(j+1)bb) ), kept in the torus domain */
+void orc_gen_trlwe_ks_key(orc_rng *r, Torus *ks, const Torus *s_in, const Torus *s_out, int N, int t, int base_bit, double sigma) {
+  Torus *msg = (Torus *)malloc(sizeof(Torus) * (size_t)N);
+  for (int j = 0; j < t; j++) {
+    for (int i = 0; i < N; i++) msg[i] = s_in[i] * ((Torus)1 << (W - (j + 1) * base_bit));
+    orc_trlwe_sample(r, ks + (size_t)j * 2 * N, msg, s_out, 1, N, sigma);
+  }
+  free(msg);
+}
+
+/* src/keyswitch.c:500-511 with skip_even: entry j switches from s(X^(2j+1)) back to s(X) */
+void orc_gen_automorphism_keyset(orc_rng *r, Torus *ak, const Torus *s, int N, int t, int base_bit, double sigma) {
+  Torus *s2 = (Torus *)malloc(sizeof(Torus) * (size_t)N);
+  for (int j = 0; j < N; j++) {
+    orc_poly_permute(s2, s, N, (uint64_t)(2 * j + 1));
+    orc_gen_trlwe_ks_key(r, ak + (size_t)j * t * 2 * N, s2, s, N, t, base_bit, sigma);
+  }
+  free(s2);
+}
+
+/* src/bootstrap_ga.c:17-20  BK_i = TRGSW(X^{s_i}) */
+void orc_gen_bootstrap_key_ga(orc_rng *r, Torus *bk, const Torus *lwe_s, int n, const Torus *rlwe_s, int N, int l, int Bg_bit,
+                              double sigma) {
+  const size_t sz = (size_t)2 * l * 2 * N;
+  for (int i = 0; i < n; i++) orc_trgsw_monomial_sample(r, bk + (size_t)i * sz, 1, (int)lwe_s[i], rlwe_s, 1, N, l, Bg_bit, sigma);
+}
+
+/* ------------------------------------------------------------------------------------------
  * Deterministic inputs.  The reference seeds from RDRAND / urandom (src/misc.c:34-49) and is not
  * reproducible, so tests draw keys and samples from splitmix64 with the same distributions.
  * ------------------------------------------------------------------------------------------ */

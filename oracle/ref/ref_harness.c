@@ -299,6 +299,81 @@ void ref_trlwe_torus_packing_many_LUT(Torus *out, Torus *lut, int k, int N, int 
   free_trlwe(c);
 }
 
+/* ---------- FFT-based TRLWE key switch, automorphisms, GA bootstrap (src/keyswitch.c:162-193, src/trlwe.c:775-781,
+ * src/bootstrap_ga.c) ---------- */
+static TRLWE_KS_Key trlwe_ks_from_flat(const Torus *flat /*[t][k+1][N]*/, int k, int N, int t, int base_bit) {
+  TRLWE_KS_Key res = (TRLWE_KS_Key)safe_malloc(sizeof(*res));
+  res->base_bit = base_bit;
+  res->k = k;
+  res->t = t;
+  res->s = (TRLWE_DFT **)safe_malloc(sizeof(TRLWE_DFT *) * k);
+  res->s[0] = (TRLWE_DFT *)safe_malloc(sizeof(TRLWE_DFT) * t);
+  for (int j = 0; j < t; j++) {
+    TRLWE tmp = trlwe_from_flat(flat + (size_t)j * (k + 1) * N, k, N);
+    res->s[0][j] = trlwe_alloc_new_DFT_sample(k, N);
+    trlwe_to_DFT(res->s[0][j], tmp);
+    free_trlwe(tmp);
+  }
+  return res;
+}
+
+void ref_trlwe_keyswitch(Torus *out, const Torus *in, const Torus *ks_flat, int N, int t, int base_bit) {
+  TRLWE_KS_Key ks = trlwe_ks_from_flat(ks_flat, 1, N, t, base_bit);
+  TRLWE c = trlwe_from_flat(in, 1, N), o = trlwe_alloc_new_sample(1, N);
+  trlwe_keyswitch(o, c, ks);
+  trlwe_to_flat(out, o, N);
+  free_trlwe(c);
+  free_trlwe(o);
+  free_trlwe_ks_key(ks);
+}
+
+void ref_trlwe_eval_automorphism(Torus *out, const Torus *in, uint64_t gen, const Torus *ks_flat, int N, int t, int base_bit) {
+  TRLWE_KS_Key ks = trlwe_ks_from_flat(ks_flat, 1, N, t, base_bit);
+  TRLWE c = trlwe_from_flat(in, 1, N), o = trlwe_alloc_new_sample(1, N);
+  trlwe_eval_automorphism(o, c, gen, ks);
+  trlwe_to_flat(out, o, N);
+  free_trlwe(c);
+  free_trlwe(o);
+  free_trlwe_ks_key(ks);
+}
+
+uint32_t ref_inverse_mod_2N(uint32_t x, int N) { return inverse_mod_2N((uint16_t)x, (uint16_t)N); }
+
+/* Bootstrap_GA_Key from torus-domain TRGSW(X^{s_i}) rows and the automorphism key set ak_flat[N][l][2][N]
+ * (what new_bootstrap_key_ga builds, src/bootstrap_ga.c:5-24, minus the non-reproducible encryption) */
+void *ref_bk_ga_new(const Torus *bk_flat, const Torus *ak_flat, int n, int N, int l, int Bg_bit) {
+  Bootstrap_GA_Key res = (Bootstrap_GA_Key)safe_malloc(sizeof(*res));
+  res->s = (TRGSW_DFT *)safe_malloc(sizeof(TRGSW_DFT) * n);
+  res->su = NULL;
+  res->n = n; res->k = 1; res->l = l; res->N = N; res->Bg_bit = Bg_bit; res->unfolding = 1;
+  const size_t sz = (size_t)2 * l * 2 * N;
+  for (int i = 0; i < n; i++) res->s[i] = trgsw_dft_from_flat(bk_flat + i * sz, 1, N, l, Bg_bit);
+  res->ak = (TRLWE_KS_Key *)safe_malloc(sizeof(TRLWE_KS_Key) * N);
+  for (int j = 0; j < N; j++) res->ak[j] = trlwe_ks_from_flat(ak_flat + (size_t)j * l * 2 * N, 1, N, l, Bg_bit);
+  return res;
+}
+
+void ref_bk_ga_free(void *h) { free_bootstrap_key_ga((Bootstrap_GA_Key)h); }
+
+void ref_functional_bootstrap_ga(Torus *out, const Torus *tv, const Torus *in, void *h, int torus_base, int extract) {
+  Bootstrap_GA_Key bk = (Bootstrap_GA_Key)h;
+  TRLWE t = trlwe_from_flat(tv, 1, bk->N);
+  TLWE c = tlwe_from_flat(in, bk->n);
+  if (extract) {
+    TLWE o = tlwe_alloc_sample(bk->N);
+    functional_bootstrap_ga(o, t, c, bk, torus_base);
+    tlwe_to_flat(out, o);
+    free_tlwe(o);
+  } else {
+    TRLWE o = trlwe_alloc_new_sample(1, bk->N);
+    functional_bootstrap_wo_extract_ga(o, t, c, bk, torus_base);
+    trlwe_to_flat(out, o, bk->N);
+    free_trlwe(o);
+  }
+  free_trlwe(t);
+  free_tlwe(c);
+}
+
 /* ---------- CPU baseline: time `reps` reference programmable bootstraps on the calling thread.
  * Re-entrant across threads once ref_init(N) has run on the main thread (FFT processors are
  * __thread, src/polynomial.c:338-349). Returns elapsed seconds. ---------- */

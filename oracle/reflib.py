@@ -194,6 +194,36 @@ class Ref:
         self.l.ref_trlwe_torus_packing_many_LUT(_u(out), _u(lut), k, N, lut_size, n_luts)
         return out
 
+    def trlwe_keyswitch(self, c, ks, base_bit):
+        t, _, N = ks.shape
+        out = np.empty_like(c)
+        self.l.ref_trlwe_keyswitch(_u(out), _u(c), _u(ks), N, t, base_bit)
+        return out
+
+    def trlwe_eval_automorphism(self, c, gen, ks, base_bit):
+        t, _, N = ks.shape
+        out = np.empty_like(c)
+        self.l.ref_trlwe_eval_automorphism(_u(out), _u(c), C.c_uint64(gen), _u(ks), N, t, base_bit)
+        return out
+
+    def inverse_mod_2N(self, x, N):
+        self.l.ref_inverse_mod_2N.restype = C.c_uint32
+        return self.l.ref_inverse_mod_2N(C.c_uint32(x), N)
+
+    def bk_ga_new(self, bk, ak, l, Bg_bit):
+        n, _, _, N = bk.shape
+        self.l.ref_bk_ga_new.restype = C.c_void_p
+        return C.c_void_p(self.l.ref_bk_ga_new(_u(bk), _u(ak), n, N, l, Bg_bit))
+
+    def bk_ga_free(self, h):
+        self.l.ref_bk_ga_free(h)
+
+    def functional_bootstrap_ga(self, tv, c, h, torus_base, extract=True):
+        k1, N = tv.shape
+        out = np.empty(N + 1, dtype=np.uint64) if extract else np.empty_like(tv)
+        self.l.ref_functional_bootstrap_ga(_u(out), _u(tv), _u(c), h, torus_base, int(extract))
+        return out
+
     def bench_programmable_bootstrap(self, tv, c, h, precision, reps):
         """Seconds for `reps` programmable_bootstrap calls on the calling thread (GIL released)."""
         return self.l.ref_bench_programmable_bootstrap(_u(tv), _u(c), h, precision, reps)

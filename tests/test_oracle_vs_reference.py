@@ -116,3 +116,36 @@ def test_fdfb_and_multivalue_short_key(oracle, ref):
     assert oracle.torus_dist(mine, theirs).max() < 2.0 ** 38
     ref.bk_free(h)
     ref.ksk_free(kh)
+
+
+def test_trlwe_keyswitch_automorphism_and_ga_bootstrap(oracle, ref):
+    """FFT-based trlwe_keyswitch (src/keyswitch.c:162-193), trlwe_eval_automorphism (src/trlwe.c:775-781), inverse_mod_2N
+    (src/misc.c:142-159) and functional_bootstrap_ga (src/bootstrap_ga.c) with a 10-word LWE key."""
+    rng = oracle.Rng(0x6A)
+    N, l, Bg, sigma, n = 1024, 2, 8, 2.98e-8, 10
+    for x in (1, 3, 5, 1023, 1025, 2047):
+        assert ref.inverse_mod_2N(x, N) == oracle.inverse_mod_2N(x, N)
+    s = oracle.gen_binary_key(rng, N)
+    s2 = oracle.gen_binary_key(rng, N)
+    ks = oracle.gen_trlwe_ks_key(rng, s2, s, 4, 8, sigma)
+    c = oracle.trlwe_sample(rng, oracle.u64(rng.words(N)), s2.reshape(1, N), sigma)
+    mine = oracle.trlwe_keyswitch(c, oracle.ks_to_dft(ks), 4, 8)
+    assert oracle.torus_dist(mine, ref.trlwe_keyswitch(c, ks, 8)).max() < 2.0 ** 34
+    ak = oracle.gen_automorphism_keyset(rng, s, l, Bg, sigma)
+    ak_dft = oracle.ks_to_dft(ak)
+    c = oracle.trlwe_sample(rng, oracle.u64(rng.words(N)), s.reshape(1, N), sigma)
+    for gen in (1, 3, 2 * N - 1, 777):
+        mine = oracle.trlwe_eval_automorphism(c, gen, ak_dft[(gen - 1) // 2], l, Bg)
+        assert oracle.torus_dist(mine, ref.trlwe_eval_automorphism(c, gen, ak[(gen - 1) // 2], Bg)).max() < 2.0 ** 34, gen
+    lwe_s = oracle.gen_binary_key(rng, n)
+    bk = oracle.gen_bootstrap_key_ga(rng, lwe_s, s.reshape(1, N), l, Bg, sigma)
+    bk_dft = oracle.bk_to_dft(bk, 1, l)
+    h = ref.bk_ga_new(bk, ak, l, Bg)
+    lut = oracle.u64(rng.words(4))
+    tv = oracle.trlwe_torus_packing(lut, 1, N)
+    for m in range(4):
+        ct = oracle.tlwe_sample(rng, oracle.double2torus(m / 8.0), lwe_s, 1e-6)
+        mine = oracle.functional_bootstrap_ga(tv, ct, bk_dft, ak_dft, l, Bg, 4)
+        assert oracle.torus_dist(mine, ref.functional_bootstrap_ga(tv, ct, h, 4)).max() < 2.0 ** 42, m
+        assert oracle.torus_dist(oracle.tlwe_phase(mine, s), lut[m]) < 2.0 ** 58
+    ref.bk_ga_free(h)
