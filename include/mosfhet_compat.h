@@ -112,6 +112,17 @@ void full_domain_functional_bootstrap(TLWE out, TRLWE tv, TLWE in, Bootstrap_Key
 void multivalue_bootstrap_CLOT21(TLWE *out, TRLWE tv, TLWE in, Bootstrap_Key key, int torus_base, int n_luts);              /* :222-230 */
 void trlwe_torus_packing_many_LUT(TRLWE out, Torus *in, int lut_size, int n_luts);   /* src/trlwe.c:677-687 (host) */
 
+/* ---- bootstrap with Galois automorphisms (src/bootstrap_ga.c)  -> GPU ---- */
+typedef struct _Bootstrap_GA_Key { TRGSW_DFT *s; TRGSW *su; void **ak; int n, k, N, Bg_bit, l, unfolding; } *Bootstrap_GA_Key; /* mosfhet.h:135-140; s, ak opaque */
+Bootstrap_GA_Key new_bootstrap_key_ga(TRGSW_Key out_key, TLWE_Key in_key);                                   /* :5-24 */
+void free_bootstrap_key_ga(Bootstrap_GA_Key key);                                                            /* :26-33 */
+void functional_bootstrap_wo_extract_ga(TRLWE out, TRLWE tv, TLWE in, Bootstrap_GA_Key key, int torus_base); /* :62-68 */
+void functional_bootstrap_ga(TLWE out, TRLWE tv, TLWE in, Bootstrap_GA_Key key, int torus_base);             /* :70-76 */
+void functional_bootstrap_ga_batch(TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_GA_Key key, int torus_base);  /* new */
+void polynomial_permute(TorusPolynomial out, TorusPolynomial in, uint64_t gen);                               /* src/polynomial.c:442-450 (host) */
+void mosfhet_gen_bootstrap_key_ga_flat(Torus *out /*[n][(k+1)l][k+1][N]*/, TRGSW_Key out_key, TLWE_Key in_key);       /* BK_i = TRGSW(X^{s_i}) */
+void mosfhet_gen_automorphism_keyset_flat(Torus *out /*[N][t][2][N]*/, TRLWE_Key key, int t, int base_bit);           /* src/keyswitch.c:500-511 */
+
 /* ---- batch extensions (new): arrays of `count` samples, one shared test vector ---- */
 void functional_bootstrap_batch(TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_Key key, int torus_base);
 void programmable_bootstrap_batch(TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_Key key,

@@ -42,6 +42,7 @@ extern "C" {
 typedef struct mosfhet_hip_ctx *mosfhet_hip_ctx_t;     /* one per (process, device) */
 typedef struct mosfhet_hip_bsk *mosfhet_hip_bsk_t;     /* device-resident DFT bootstrap key */
 typedef struct mosfhet_hip_ksk *mosfhet_hip_ksk_t;     /* device-resident LWE key-switch key */
+typedef struct mosfhet_hip_gak *mosfhet_hip_gak_t;     /* device-resident automorphism (TRLWE key-switch) key set */
 
 const char *mosfhet_hip_last_error(void);
 const char *mosfhet_hip_version(void);
@@ -139,6 +140,23 @@ int mosfhet_hip_full_domain_functional_bootstrap_batch(mosfhet_hip_ctx_t ctx, mo
 int mosfhet_hip_multivalue_bootstrap_CLOT21_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_out /*[count][n_luts][kN+1]*/,
                                                   const uint64_t *d_tv, int tv_count, const uint64_t *d_in, int count,
                                                   int torus_base, int n_luts, void *stream);
+
+/* Automorphism key set (Bootstrap_GA_Key.ak, src/bootstrap_ga.c:10, src/keyswitch.c:500-511 with skip_even): N FFT-based
+ * TRLWE key-switch keys, entry j switching from s(X^(2j+1)) back to s(X).  h_ak = Torus[N][t][k+1][N] in the TORUS
+ * domain (rows KS[j] = TRLWE(s_in(X) 2^(64-(j+1) base_bit)), src/keyswitch.c:12-37); transformed on upload. k = 1. */
+int mosfhet_hip_gak_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_gak_t *out, const uint64_t *h_ak, int N, int t, int base_bit);
+int mosfhet_hip_gak_destroy(mosfhet_hip_gak_t gak);
+/* trlwe_eval_automorphism over a batch (src/trlwe.c:775-781 = polynomial_permute, src/polynomial.c:442-450, followed by the
+ * FFT-based trlwe_keyswitch, src/keyswitch.c:162-193): d_out[b] = KeySwitch_{ak[(gen-1)/2]}(d_in[b](X^gen)); gen odd, < 2N.
+ * With gen = 1 this is trlwe_keyswitch itself (entry 0 switches from s to s). */
+int mosfhet_hip_trlwe_eval_automorphism_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_gak_t gak, uint64_t *d_out /*[count][2][N]*/,
+                                              const uint64_t *d_in /*[count][2][N]*/, int gen, int count, void *stream);
+/* functional_bootstrap_ga / functional_bootstrap_wo_extract_ga over a batch (src/bootstrap_ga.c:62-76).  bsk must hold
+ * BK_i = TRGSW(X^{s_i}) (new_bootstrap_key_ga, :17-20); gak must have t = l and base_bit = Bg_bit (:10).
+ * extract != 0: d_out = TLWE [count][N+1]; else the rotated TRLWE [count][2][N]. */
+int mosfhet_hip_functional_bootstrap_ga_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, mosfhet_hip_gak_t gak, uint64_t *d_out,
+                                              const uint64_t *d_tv, int tv_count, const uint64_t *d_in /*[count][n+1]*/, int count,
+                                              int torus_base, int extract, void *stream);
 
 /* Timing hook for bench.py: runs `reps` launches of the programmable-bootstrap kernel on `stream`
  * bracketed by hipEvents ON THAT STREAM and returns the average kernel time in milliseconds

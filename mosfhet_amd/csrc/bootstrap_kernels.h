@@ -303,6 +303,220 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Galois-automorphism bootstrap [src/bootstrap_ga.c:39-76] and its building blocks:
+//   trlwe_keyswitch          [src/keyswitch.c:162-193]  out = (0, b) - IDFT(sum_j DFT(digit_j(a)) (.) KS[j])
+//   trlwe_eval_automorphism  [src/trlwe.c:775-781, src/polynomial.c:442-450]  X -> X^gen on both components, then
+//                            key switch with ak[(gen-1)/2]
+//   blind_rotate_ga          acc <- Auto_{w0}(acc); per i: acc <- Auto_{gen_i}(BK_i (.) acc), BK_i = TRGSW(X^{s_i})
+// Same accumulator placement as pbs_kernel: component a in VGPRs (al, ah), component b in LDS (acc1).
+// ak entry layout = L key rows of a bootstrap-key entry: [L][2][8][T] complex, slot order.
+// ------------------------------------------------------------------------------------------------------------
+// acc <- TRGSW (.) acc (external product, result REPLACES the accumulator)
+template <class F, int L, int BG>
+__device__ __forceinline__ void ga_external_product(uint64_t (&al)[8], uint64_t (&ah)[8], uint64_t *acc1, d2 *xch, const F &fft,
+                                                    const d2 *__restrict__ bkrow, uint64_t off, int Bg_bit, double scale, int t) {
+  constexpr int M = F::M, T = F::THREADS;
+  using D = Digits<L, BG>;
+  double o_re[2][8], o_im[2][8];
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int m = 0; m < 8; m++) { o_re[c][m] = 0.0; o_im[c][m] = 0.0; }
+#pragma unroll 1
+  for (int q = 0; q < 2; q++) {
+    typename D::word_t w_lo[8], w_hi[8];
+    uint32_t ext[8];
+    if (q == 0) {
+#pragma unroll
+      for (int m = 0; m < 8; m++) D::pack(w_lo[m], w_hi[m], ext[m], al[m] + off, ah[m] + off);
+    } else {
+#pragma unroll
+      for (int m = 0; m < 8; m++) D::pack(w_lo[m], w_hi[m], ext[m], acc1[m * T + t] + off, acc1[M + m * T + t] + off);
+    }
+    cmux_rows<F, L, BG>(w_lo, w_hi, ext, q, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
+  }
+  fft.inverse(o_re[0], o_im[0], xch, t);
+#pragma unroll
+  for (int m = 0; m < 8; m++) {
+    al[m] = round_mod_2_64(o_re[0][m], scale);
+    ah[m] = round_mod_2_64(o_im[0][m], scale);
+  }
+  fft.inverse(o_re[1], o_im[1], xch, t);
+#pragma unroll
+  for (int m = 0; m < 8; m++) {
+    acc1[m * T + t] = round_mod_2_64(o_re[1][m], scale);
+    acc1[M + m * T + t] = round_mod_2_64(o_im[1][m], scale);
+  }
+  F::sync();
+}
+
+// acc <- Auto_gen(acc): permute both components (out[(i gen) mod N] = +-in[i]) and key switch with `entry`
+template <class F, int L, int BG>
+__device__ __forceinline__ void ga_eval_automorphism(uint64_t (&al)[8], uint64_t (&ah)[8], uint64_t *acc1, d2 *xch, const F &fft,
+                                                     const d2 *__restrict__ entry, int gen, uint64_t off, int Bg_bit, double scale,
+                                                     int t) {
+  constexpr int N = F::N, M = F::M, T = F::THREADS;
+  using D = Digits<L, BG>;
+  typename D::word_t w_lo[8], w_hi[8];
+  uint32_t ext[8];
+  {
+    // component a: scatter through the staging buffer, read back in layout A, keep only the digit words
+    uint64_t *st = reinterpret_cast<uint64_t *>(xch);
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int i0 = (m * T + t) * gen, i1 = (M + m * T + t) * gen;
+      st[i0 & (N - 1)] = (i0 & N) ? (0 - al[m]) : al[m];
+      st[i1 & (N - 1)] = (i1 & N) ? (0 - ah[m]) : ah[m];
+    }
+    F::sync();
+#pragma unroll
+    for (int m = 0; m < 8; m++) D::pack(w_lo[m], w_hi[m], ext[m], st[m * T + t] + off, st[M + m * T + t] + off);
+    F::sync();
+  }
+  {
+    // component b: permute in place in LDS (read everything, barrier, scatter)
+    uint64_t v_lo[8], v_hi[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) { v_lo[m] = acc1[m * T + t]; v_hi[m] = acc1[M + m * T + t]; }
+    F::sync();
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int i0 = (m * T + t) * gen, i1 = (M + m * T + t) * gen;
+      acc1[i0 & (N - 1)] = (i0 & N) ? (0 - v_lo[m]) : v_lo[m];
+      acc1[i1 & (N - 1)] = (i1 & N) ? (0 - v_hi[m]) : v_hi[m];
+    }
+    F::sync();
+  }
+  double o_re[2][8], o_im[2][8];
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int m = 0; m < 8; m++) { o_re[c][m] = 0.0; o_im[c][m] = 0.0; }
+  cmux_rows<F, L, BG>(w_lo, w_hi, ext, 0, o_re, o_im, xch, fft, entry, Bg_bit, t);
+  fft.inverse(o_re[0], o_im[0], xch, t);
+#pragma unroll
+  for (int m = 0; m < 8; m++) {
+    al[m] = 0 - round_mod_2_64(o_re[0][m], scale);
+    ah[m] = 0 - round_mod_2_64(o_im[0][m], scale);
+  }
+  fft.inverse(o_re[1], o_im[1], xch, t);
+#pragma unroll
+  for (int m = 0; m < 8; m++) {
+    acc1[m * T + t] -= round_mod_2_64(o_re[1][m], scale);
+    acc1[M + m * T + t] -= round_mod_2_64(o_im[1][m], scale);
+  }
+  F::sync();
+}
+
+// inverse of odd x modulo 2N (a power of two) by Newton iteration [src/misc.c:142-159 tabulates it]
+__device__ __forceinline__ uint32_t inverse_mod_2n(uint32_t x, uint32_t mask) {
+  uint32_t inv = x;
+#pragma unroll
+  for (int i = 0; i < 4; i++) inv = (inv * (2u - x * inv)) & mask;
+  return inv;
+}
+
+struct GaParams {
+  PbsParams p;
+  const d2 *__restrict__ ak;  // [N][L][2][8][T] complex: automorphism key-switch keys, entry (gen - 1) / 2
+  int mode;                   // 0: functional_bootstrap(_wo_extract)_ga;  1: one trlwe_eval_automorphism with generator `gen`
+  int gen;
+};
+
+template <class F, int L, int BG>
+__global__ __launch_bounds__(F::THREADS, 2) void pbs_ga_kernel(GaParams g) {
+  constexpr int N = F::N, M = F::M, T = F::THREADS, LOG2N2 = F::LOGM + 2;
+  __shared__ __attribute__((aligned(16))) d2 xch[F::XCH_SLOTS];
+  __shared__ __attribute__((aligned(16))) uint64_t acc1[N];
+  const PbsParams &p = g.p;
+  const int t = threadIdx.x;
+  const size_t b = blockIdx.x;
+  const int Bg_bit = BG > 0 ? BG : p.Bg_bit;
+  F fft;
+  fft.init(p.tw, t);
+  uint64_t off = 1ull << (63 - L * Bg_bit);
+#pragma unroll
+  for (int i = 0; i < L; i++) off += 1ull << (63 - i * Bg_bit);
+  const double scale = 0x1p-64 / (double)M;
+  const size_t row_sz = (size_t)2 * L * 2 * M, ak_sz = (size_t)L * 2 * M;
+  uint64_t al[8], ah[8];
+
+  if (g.mode == 1) {
+    // trlwe_eval_automorphism on a batch of TRLWE samples: in = p.in [B][2][N], out = p.out
+    const uint64_t *src = p.in + b * (size_t)(2 * N);
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      al[m] = src[m * T + t];
+      ah[m] = src[M + m * T + t];
+      acc1[m * T + t] = src[N + m * T + t];
+      acc1[M + m * T + t] = src[N + M + m * T + t];
+    }
+    F::sync();
+    ga_eval_automorphism<F, L, BG>(al, ah, acc1, xch, fft, g.ak + (size_t)((g.gen - 1) >> 1) * ak_sz, g.gen, off, Bg_bit, scale, t);
+  } else {
+    const uint64_t *__restrict__ ct = p.in + b * (size_t)(p.n + 1);
+    {
+      // src/bootstrap_ga.c:64-65: acc = tv * X^(2N - bbar)
+      const uint64_t *__restrict__ tv = p.tv + b * (size_t)p.tv_stride;
+      const uint32_t bbar = modswitch<LOG2N2>(ct[p.n] + p.prec_offset);
+      const int rot = (2 * N - (int)bbar) & (2 * N - 1);
+      const int a_lo = rot & (N - 1);
+      const bool flip = (rot & N) != 0;
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        al[m] = rot_coeff<N>(tv, m * T + t, a_lo, flip);
+        ah[m] = rot_coeff<N>(tv, M + m * T + t, a_lo, flip);
+        acc1[m * T + t] = rot_coeff<N>(tv + N, m * T + t, a_lo, flip);
+        acc1[M + m * T + t] = rot_coeff<N>(tv + N, M + m * T + t, a_lo, flip);
+      }
+    }
+    F::sync();
+    const uint32_t mask = 2 * N - 1;
+    // src/bootstrap_ga.c:44-45: w0' = (a_0 | 1)^-1 ; acc = Auto_{w0'}(acc)
+    uint32_t a_cur = modswitch<LOG2N2>(ct[0]) | 1u;
+    {
+      const int gen = (int)inverse_mod_2n(a_cur, mask);
+      ga_eval_automorphism<F, L, BG>(al, ah, acc1, xch, fft, g.ak + (size_t)((gen - 1) >> 1) * ak_sz, gen, off, Bg_bit, scale, t);
+    }
+    for (int i = 0; i < p.n; i++) {
+      // :46-58: acc = BK_i (.) acc ; gen = a_i * (a_{i+1})^-1 (last step: a_{n-1}) ; acc = Auto_gen(acc)
+      int gen;
+      if (i + 1 < p.n) {
+        const uint32_t a_next = modswitch<LOG2N2>(ct[i + 1]) | 1u;
+        gen = (int)((a_cur * inverse_mod_2n(a_next, mask)) & mask);
+        a_cur = a_next;
+      } else {
+        gen = (int)a_cur;
+      }
+      ga_external_product<F, L, BG>(al, ah, acc1, xch, fft, p.bk + (size_t)i * row_sz, off, Bg_bit, scale, t);
+      ga_eval_automorphism<F, L, BG>(al, ah, acc1, xch, fft, g.ak + (size_t)((gen - 1) >> 1) * ak_sz, gen, off, Bg_bit, scale, t);
+    }
+  }
+
+  if (g.mode == 0 && p.extract) {
+    uint64_t *st = reinterpret_cast<uint64_t *>(xch);
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      st[m * T + t] = al[m];
+      st[M + m * T + t] = ah[m];
+    }
+    F::sync();
+    uint64_t *dst = p.out + b * (size_t)(N + 1);
+    for (int j = t; j < N; j += T) dst[j] = (j == 0) ? st[0] : (0 - st[N - j]);
+    if (t == 0) dst[N] = acc1[0];
+  } else {
+    uint64_t *dst = p.out + b * (size_t)(2 * N);
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      dst[m * T + t] = al[m];
+      dst[M + m * T + t] = ah[m];
+      dst[N + m * T + t] = acc1[m * T + t];
+      dst[N + M + m * T + t] = acc1[M + m * T + t];
+    }
+  }
+}
+
 // trgsw_to_DFT / polynomial_torus_to_DFT for a flat array of polynomials [src/trgsw.c:345-349,
 // src/polynomial.c:368-375]: one team per polynomial, output in slot order [m][thread].
 template <class F>

@@ -56,6 +56,13 @@ struct mosfhet_hip_ksk {
   KsWorkspace ws;  // transposed batch buffers, grown on demand
 };
 
+struct mosfhet_hip_gak {
+  mosfhet_hip_ctx_t ctx;
+  d2 *d_ak;  // [N][t][2][8][T]
+  int N, t, base_bit;
+  size_t bytes;
+};
+
 extern "C" const char *mosfhet_hip_last_error(void) { return g_err; }
 extern "C" const char *mosfhet_hip_version(void) { return "mosfhet_amd 0.1 (gfx950)"; }
 
@@ -463,6 +470,102 @@ extern "C" int mosfhet_hip_multivalue_bootstrap_CLOT21_batch(mosfhet_hip_ctx_t c
                        (size_t)n_luts * (N + 1), bsk->scratch, (size_t)2 * N, N, i * slot);
   HIP_TRY(hipGetLastError());
   return MOSFHET_HIP_OK;
+}
+
+// ---- Galois automorphisms ----
+extern "C" int mosfhet_hip_gak_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_gak_t *out, const uint64_t *h_ak, int N, int t, int base_bit) {
+  if (!ctx || !out || !h_ak) return fail(MOSFHET_HIP_EINVAL, "gak_create: bad argument");
+  int rc = check_params("gak_create", 1, N, t, base_bit);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(ctx->device));
+  mosfhet_hip_gak *g = new mosfhet_hip_gak();
+  g->ctx = ctx; g->N = N; g->t = t; g->base_bit = base_bit;
+  const size_t polys = (size_t)N * t * 2;
+  g->bytes = polys * N * sizeof(double);
+  uint64_t *d_tmp = nullptr;
+  HIP_TRY(hipMalloc((void **)&d_tmp, g->bytes));
+  HIP_TRY(hipMalloc((void **)&g->d_ak, g->bytes));
+  HIP_TRY(hipMemcpy(d_tmp, h_ak, g->bytes, hipMemcpyHostToDevice));
+  if (N == 1024) hipLaunchKernelGGL(torus_to_dft_kernel<Fft1024>, dim3((unsigned)polys), dim3(64), 0, nullptr, d_tmp, g->d_ak, ctx->tw1024);
+  else hipLaunchKernelGGL(torus_to_dft_kernel<Fft2048>, dim3((unsigned)polys), dim3(128), 0, nullptr, d_tmp, g->d_ak, ctx->tw2048);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  hipFree(d_tmp);
+  *out = g;
+  return MOSFHET_HIP_OK;
+}
+
+extern "C" int mosfhet_hip_gak_destroy(mosfhet_hip_gak_t gak) {
+  if (!gak) return MOSFHET_HIP_OK;
+  hipSetDevice(gak->ctx->device);
+  hipFree(gak->d_ak);
+  delete gak;
+  return MOSFHET_HIP_OK;
+}
+
+template <class F, int L, int BG>
+static void launch_ga(const GaParams &g, int count, hipStream_t s) {
+  hipLaunchKernelGGL((pbs_ga_kernel<F, L, BG>), dim3((unsigned)count), dim3(F::THREADS), 0, s, g);
+}
+
+template <class F>
+static int launch_ga_f(int l, int Bg_bit, const GaParams &g, int count, hipStream_t s) {
+  if (l == 2 && Bg_bit == 8) launch_ga<F, 2, 8>(g, count, s);
+  else if (l == 4 && Bg_bit == 9) launch_ga<F, 4, 9>(g, count, s);
+  else if (l == 1) launch_ga<F, 1, 0>(g, count, s);
+  else if (l == 2) launch_ga<F, 2, 0>(g, count, s);
+  else if (l == 3) launch_ga<F, 3, 0>(g, count, s);
+  else if (l == 4) launch_ga<F, 4, 0>(g, count, s);
+  else return fail(MOSFHET_HIP_EINVAL, "l = %d not instantiated", l);
+  HIP_TRY(hipGetLastError());
+  return MOSFHET_HIP_OK;
+}
+
+extern "C" int mosfhet_hip_trlwe_eval_automorphism_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_gak_t gak, uint64_t *d_out,
+                                                         const uint64_t *d_in, int gen, int count, void *stream) {
+  if (!ctx || !gak || !d_out || !d_in || count < 0) return fail(MOSFHET_HIP_EINVAL, "eval_automorphism: bad argument");
+  if (gen < 1 || gen >= 2 * gak->N || !(gen & 1)) return fail(MOSFHET_HIP_EINVAL, "eval_automorphism: generator %d must be odd and < 2N", gen);
+  if (count == 0) return MOSFHET_HIP_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  GaParams g;
+  memset(&g, 0, sizeof(g));
+  g.p.tw = gak->N == 1024 ? ctx->tw1024 : ctx->tw2048;
+  g.p.in = d_in;
+  g.p.out = d_out;
+  g.p.Bg_bit = gak->base_bit;
+  g.ak = gak->d_ak;
+  g.mode = 1;
+  g.gen = gen;
+  return gak->N == 1024 ? launch_ga_f<Fft1024>(gak->t, gak->base_bit, g, count, pick(ctx, stream))
+                        : launch_ga_f<Fft2048>(gak->t, gak->base_bit, g, count, pick(ctx, stream));
+}
+
+extern "C" int mosfhet_hip_functional_bootstrap_ga_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, mosfhet_hip_gak_t gak,
+                                                         uint64_t *d_out, const uint64_t *d_tv, int tv_count, const uint64_t *d_in,
+                                                         int count, int torus_base, int extract, void *stream) {
+  if (!ctx || !bsk || !gak || !d_out || !d_tv || !d_in || count < 0 || torus_base < 1)
+    return fail(MOSFHET_HIP_EINVAL, "functional_bootstrap_ga: bad argument");
+  if (tv_count != 1 && tv_count != count) return fail(MOSFHET_HIP_EINVAL, "functional_bootstrap_ga: tv_count must be 1 or count");
+  if (gak->N != bsk->N || gak->t != bsk->l || gak->base_bit != bsk->Bg_bit)
+    return fail(MOSFHET_HIP_EINVAL, "functional_bootstrap_ga: automorphism keys must use the bootstrap key's N, l, Bg_bit");
+  if (count == 0) return MOSFHET_HIP_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  GaParams g;
+  memset(&g, 0, sizeof(g));
+  g.p.bk = bsk->d_bk;
+  g.p.tw = bsk->N == 1024 ? ctx->tw1024 : ctx->tw2048;
+  g.p.in = d_in;
+  g.p.tv = d_tv;
+  g.p.out = d_out;
+  g.p.tv_stride = (tv_count == 1) ? 0 : (long long)2 * bsk->N;
+  g.p.n = bsk->n;
+  g.p.Bg_bit = bsk->Bg_bit;
+  g.p.prec_offset = (uint64_t)((int64_t)(18446744073709551616.0 * (1. / (4 * (double)torus_base))));
+  g.p.extract = extract ? 1 : 0;
+  g.ak = gak->d_ak;
+  g.mode = 0;
+  return bsk->N == 1024 ? launch_ga_f<Fft1024>(bsk->l, bsk->Bg_bit, g, count, pick(ctx, stream))
+                        : launch_ga_f<Fft2048>(bsk->l, bsk->Bg_bit, g, count, pick(ctx, stream));
 }
 
 // ---- timing hook ----

@@ -587,6 +587,110 @@ void blind_rotate(TRLWE tv, Torus *a, TRGSW_DFT *s, int size) {
   free(h);
 }
 
+/* ------------------------------------------------------------------ Galois-automorphism bootstrap */
+void polynomial_permute(TorusPolynomial out, TorusPolynomial in, uint64_t gen) {
+  const uint64_t N = (uint64_t)in->N, mask = N - 1;
+  for (uint64_t i = 0; i < N; i++) {
+    const uint64_t idx = i * gen;
+    out->coeffs[idx & mask] = (idx & N) ? (Torus)0 - in->coeffs[i] : in->coeffs[i];
+  }
+}
+
+void mosfhet_gen_bootstrap_key_ga_flat(Torus *out, TRGSW_Key out_key, TLWE_Key in_key) {
+  const int l = out_key->l, k = out_key->trlwe_key->k, N = out_key->trlwe_key->s[0]->N;
+  const size_t row = (size_t)(k + 1) * N, sz = (size_t)(k + 1) * l * row;
+  TRGSW tmp = trgsw_alloc_new_sample(l, out_key->Bg_bit, k, N);
+  for (int i = 0; i < in_key->n; i++) {
+    trgsw_monomial_sample(tmp, 1, (int)in_key->s[i], out_key);   /* src/bootstrap_ga.c:19 */
+    for (int q = 0; q < (k + 1) * l; q++) trlwe_to_flat(out + (size_t)i * sz + q * row, tmp->samples[q]);
+  }
+  free_trgsw(tmp);
+}
+
+/* entry j (generator 2j+1): rows r < t = TRLWE_key( key(X^(2j+1)) * 2^(64-(r+1) base_bit) )  [src/keyswitch.c:12-37,500-511] */
+void mosfhet_gen_automorphism_keyset_flat(Torus *out, TRLWE_Key key, int t, int base_bit) {
+  const int N = key->s[0]->N;
+  TorusPolynomial s2 = polynomial_new_torus_polynomial(N), msg = polynomial_new_torus_polynomial(N);
+  TRLWE tmp = trlwe_alloc_new_sample(1, N);
+  for (int j = 0; j < N; j++) {
+    polynomial_permute(s2, key->s[0], (uint64_t)(2 * j + 1));
+    for (int r = 0; r < t; r++) {
+      for (int i = 0; i < N; i++) msg->coeffs[i] = s2->coeffs[i] * ((Torus)1 << (W - (r + 1) * base_bit));
+      trlwe_sample(tmp, msg, key);
+      trlwe_to_flat(out + (((size_t)j * t + r) * 2) * N, tmp);
+    }
+  }
+  free_polynomial(s2);
+  free_polynomial(msg);
+  free_trlwe(tmp);
+}
+
+Bootstrap_GA_Key new_bootstrap_key_ga(TRGSW_Key out_key, TLWE_Key in_key) {
+  const int l = out_key->l, k = out_key->trlwe_key->k, N = out_key->trlwe_key->s[0]->N, n = in_key->n;
+  if (k != 1) { fprintf(stderr, "mosfhet_amd: new_bootstrap_key_ga: k = 1 only\n"); abort(); }
+  mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
+  Bootstrap_GA_Key res = (Bootstrap_GA_Key)xmalloc(sizeof(*res));
+  res->n = n; res->k = k; res->l = l; res->N = N; res->Bg_bit = out_key->Bg_bit; res->unfolding = 1;
+  res->su = NULL;
+  Torus *flat = (Torus *)xmalloc(sizeof(Torus) * (size_t)n * 2 * l * 2 * N);
+  mosfhet_gen_bootstrap_key_ga_flat(flat, out_key, in_key);
+  mosfhet_hip_bsk_t dev = NULL;
+  if (mosfhet_hip_bsk_create(ctx, &dev, flat, n, k, N, l, out_key->Bg_bit)) die("new_bootstrap_key_ga");
+  free(flat);
+  flat = (Torus *)xmalloc(sizeof(Torus) * (size_t)N * l * 2 * N);
+  mosfhet_gen_automorphism_keyset_flat(flat, out_key->trlwe_key, l, out_key->Bg_bit);   /* src/bootstrap_ga.c:10: t = l, base_bit = Bg_bit */
+  mosfhet_hip_gak_t gak = NULL;
+  if (mosfhet_hip_gak_create(ctx, &gak, flat, N, l, out_key->Bg_bit)) die("new_bootstrap_key_ga (automorphism keys)");
+  free(flat);
+  res->s = (TRGSW_DFT *)xmalloc(sizeof(TRGSW_DFT));
+  res->s[0] = (TRGSW_DFT)dev;
+  res->ak = (void **)xmalloc(sizeof(void *));
+  res->ak[0] = gak;
+  return res;
+}
+
+void free_bootstrap_key_ga(Bootstrap_GA_Key key) {
+  if (!key) return;
+  mosfhet_hip_bsk_destroy((mosfhet_hip_bsk_t)key->s[0]);
+  mosfhet_hip_gak_destroy((mosfhet_hip_gak_t)key->ak[0]);
+  free(key->s);
+  free(key->ak);
+  free(key);
+}
+
+static void bootstrap_ga_many(TLWE *out, TRLWE out_trlwe, TRLWE tv, TLWE *in, int count, Bootstrap_GA_Key key, int torus_base) {
+  mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
+  const int n = key->n, N = key->N, extract = out != NULL;
+  const size_t in_w = (size_t)count * (n + 1), tv_w = (size_t)2 * N;
+  const size_t out_w = extract ? (size_t)count * (N + 1) : (size_t)count * tv_w;
+  Torus *h = (Torus *)xmalloc(sizeof(Torus) * (in_w + tv_w + out_w));
+  tlwe_array_to_flat(h, in, count, n);
+  trlwe_to_flat(h + in_w, tv);
+  Torus *d = (Torus *)dev_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
+  dev_copy(d, h, sizeof(Torus) * (in_w + tv_w), HIP_H2D);
+  if (mosfhet_hip_functional_bootstrap_ga_batch(ctx, (mosfhet_hip_bsk_t)key->s[0], (mosfhet_hip_gak_t)key->ak[0], d + in_w + tv_w, d + in_w, 1, d,
+                                                count, torus_base, extract, NULL) ||
+      mosfhet_hip_ctx_sync(ctx, NULL))
+    die("functional_bootstrap_ga");
+  dev_copy(h + in_w + tv_w, d + in_w + tv_w, sizeof(Torus) * out_w, HIP_D2H);
+  if (extract) tlwe_array_from_flat(out, h + in_w + tv_w, count, N);
+  else trlwe_from_flat(out_trlwe, h + in_w + tv_w);
+  hipFree(d);
+  free(h);
+}
+
+void functional_bootstrap_ga_batch(TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_GA_Key key, int torus_base) {
+  bootstrap_ga_many(out, NULL, tv, in, count, key, torus_base);
+}
+
+void functional_bootstrap_ga(TLWE out, TRLWE tv, TLWE in, Bootstrap_GA_Key key, int torus_base) {
+  bootstrap_ga_many(&out, NULL, tv, &in, 1, key, torus_base);
+}
+
+void functional_bootstrap_wo_extract_ga(TRLWE out, TRLWE tv, TLWE in, Bootstrap_GA_Key key, int torus_base) {
+  bootstrap_ga_many(NULL, out, tv, &in, 1, key, torus_base);
+}
+
 /* ------------------------------------------------------------------ LWE key switch */
 void mosfhet_gen_tlwe_ks_key_flat(Torus *out, TLWE_Key out_key, TLWE_Key in_key, int t, int base_bit) {
   const int base = 1 << base_bit;

@@ -100,6 +100,16 @@ class KeySwitchKey:
             self.h = None
 
 
+class AutomorphismKeys:
+    def __init__(self, engine, handle, N, t, base_bit):
+        self.engine, self.h, self.N, self.t, self.base_bit = engine, handle, N, t, base_bit
+
+    def free(self):
+        if self.h:
+            lib().mosfhet_hip_gak_destroy(self.h)
+            self.h = None
+
+
 class Engine:
     """One engine per (process, GPU): wraps mosfhet_hip_ctx_t."""
 
@@ -147,6 +157,30 @@ class Engine:
         h = C.c_void_p()
         _check(lib().mosfhet_hip_ksk_create(self.h, C.byref(h), ksk.ctypes.data_as(C.c_void_p), n_in, row - 1, t, base_bit))
         return KeySwitchKey(self, h, n_in, row - 1, t, base_bit)
+
+    def load_automorphism_keys(self, ak_torus, base_bit):
+        """ak_torus: numpy uint64 [N][t][2][N] (torus domain, entry j for generator 2j+1)."""
+        ak_torus = np.ascontiguousarray(ak_torus, dtype=np.uint64)
+        N, t, two, N2 = ak_torus.shape
+        assert two == 2 and N2 == N
+        h = C.c_void_p()
+        _check(lib().mosfhet_hip_gak_create(self.h, C.byref(h), ak_torus.ctypes.data_as(C.c_void_p), N, t, base_bit))
+        return AutomorphismKeys(self, h, N, t, base_bit)
+
+    def trlwe_eval_automorphism(self, gak, ct, gen, out=None):
+        count = ct.shape[0]
+        if out is None:
+            out = self.empty(count, 2, gak.N)
+        _check(lib().mosfhet_hip_trlwe_eval_automorphism_batch(self.h, gak.h, _ptr(out), _ptr(ct), int(gen), count, self._stream()))
+        return out
+
+    def functional_bootstrap_ga(self, bsk, gak, tv, ct, torus_base, extract=True, out=None):
+        count = ct.shape[0]
+        if out is None:
+            out = self.empty(count, bsk.N + 1) if extract else self.empty(count, 2, bsk.N)
+        _check(lib().mosfhet_hip_functional_bootstrap_ga_batch(self.h, bsk.h, gak.h, _ptr(out), _ptr(tv), self._tv(tv, bsk, count),
+                                                               _ptr(ct), count, torus_base, int(extract), self._stream()))
+        return out
 
     # ---- bootstraps ----
     def _tv(self, tv, bsk, count):

@@ -127,3 +127,23 @@ def torus_packing_many_lut(lut, k, N, lut_size, n_luts):
         for j in range(n_luts):
             tv[k, (i * n_luts + j) * span:(i * n_luts + j + 1) * span] = lut[j * lut_size + i]
     return tv
+
+
+def gen_bootstrap_key_ga(rlwe_key, lwe_key, l, Bg_bit):
+    """Torus-domain GA bootstrap key u64[n][2l][2][N], BK_i = TRGSW(X^{s_i}) (src/bootstrap_ga.c:17-20)."""
+    L = _lib()
+    gk = L.trgsw_new_key(rlwe_key.p, l, Bg_bit)
+    out = np.empty((lwe_key.n, (rlwe_key.k + 1) * l, rlwe_key.k + 1, rlwe_key.N), dtype=np.uint64)
+    L.mosfhet_gen_bootstrap_key_ga_flat.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_TLWEKey)]
+    L.mosfhet_gen_bootstrap_key_ga_flat(out.ctypes.data_as(C.c_void_p), gk, lwe_key.p)
+    return out
+
+
+def gen_automorphism_keyset(rlwe_key, t, base_bit):
+    """Automorphism key-switch keys u64[N][t][2][N], entry j for generator 2j+1 (src/keyswitch.c:500-511)."""
+    L = _lib()
+    N = rlwe_key.N
+    out = np.empty((N, t, 2, N), dtype=np.uint64)
+    L.mosfhet_gen_automorphism_keyset_flat.argtypes = [C.c_void_p, C.POINTER(_TRLWEKey), C.c_int, C.c_int]
+    L.mosfhet_gen_automorphism_keyset_flat(out.ctypes.data_as(C.c_void_p), rlwe_key.p, t, base_bit)
+    return out
