@@ -158,6 +158,28 @@ int mosfhet_hip_functional_bootstrap_ga_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip
                                               const uint64_t *d_tv, int tv_count, const uint64_t *d_in /*[count][n+1]*/, int count,
                                               int torus_base, int extract, void *stream);
 
+/* Generic set of FFT-based TRLWE key-switch keys (TRLWE_KS_Key, src/keyswitch.c:12-37): `entries` keys of t rows each,
+ * h_rows = Torus[entries][t][2][N] in the torus domain.  (mosfhet_hip_gak_create is this with entries = N.) */
+int mosfhet_hip_trlwe_ksk_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_gak_t *out, const uint64_t *h_rows, int entries, int N, int t,
+                                 int base_bit);
+/* trlwe_keyswitch over a batch (src/keyswitch.c:162-193) with key `entry` of the set; any t. */
+int mosfhet_hip_trlwe_keyswitch_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_gak_t tks, int entry, uint64_t *d_out /*[count][2][N]*/,
+                                      const uint64_t *d_in, int count, void *stream);
+/* trlwe_priv_keyswitch_2 over a batch (src/keyswitch.c:52-63); tks = the two keys of trlwe_new_priv_KS_key (:39-50). */
+int mosfhet_hip_trlwe_priv_keyswitch_2_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_gak_t tks, uint64_t *d_out, const uint64_t *d_in,
+                                             int count, void *stream);
+/* LWE -> TRLWE packing key (Generic_KS_Key of trlwe_new_packing1_KS_key, src/keyswitch.c:368-390), rows UNcompressed:
+ * h_rows = Torus[n][t][2^base_bit - 1][2][N]; and trlwe_packing1_keyswitch over a batch (src/keyswitch.c:458-475). */
+int mosfhet_hip_packing1_ksk_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t *out, const uint64_t *h_rows, int n, int N, int t,
+                                    int base_bit);
+int mosfhet_hip_trlwe_packing1_keyswitch_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t ksk, uint64_t *d_out /*[count][2][N]*/,
+                                               const uint64_t *d_in /*[count][n+1]*/, int count, void *stream);
+/* circuit_bootstrap_3 over a batch (src/bootstrap.c:346-366): d_out[b] = TRGSW = Torus[2l][2][N], rows i < l from the private
+ * key switch, rows l + i from the packing key switch.  kska = 2-entry key set, kskb = packing key (n = N). */
+int mosfhet_hip_circuit_bootstrap_3_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, mosfhet_hip_gak_t kska, mosfhet_hip_ksk_t kskb,
+                                          uint64_t *d_out /*[count][2l][2][N]*/, const uint64_t *d_in /*[count][n+1]*/, int count,
+                                          void *stream);
+
 /* Timing hook for bench.py: runs `reps` launches of the programmable-bootstrap kernel on `stream`
  * bracketed by hipEvents ON THAT STREAM and returns the average kernel time in milliseconds
  * (synchronises the stream). */

@@ -517,6 +517,115 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_ga_kernel(GaParams g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// FFT-based TRLWE key switch with run-time (t, base_bit) [src/keyswitch.c:162-193] and trlwe_priv_keyswitch_2
+// [src/keyswitch.c:52-63], used by circuit_bootstrap_3 (kska: t = 20, base_bit = 2 in the reference's test).
+// One team per TRLWE sample; everything stays in registers (thread owns coefficients m*T+t and m*T+t+M).
+// Key entry layout: [t][2][8][T] complex (slot order), as produced by torus_to_dft_kernel.
+// ------------------------------------------------------------------------------------------------------------
+// o += sum_{j<t} DFT(digit_j(a)) (.) entry[j][c]   (digits of a_lo/a_hi + offset, rounded rule of polynomial_decompose_i)
+template <class F>
+__device__ __forceinline__ void ks_rows_rt(const uint64_t (&dd_lo)[8], const uint64_t (&dd_hi)[8], double (&o_re)[2][8], double (&o_im)[2][8],
+                                           d2 *xch, const F &fft, const d2 *__restrict__ entry, int t, int base_bit, int tid) {
+  constexpr int M = F::M, T = F::THREADS;
+  const uint32_t mask = (1u << base_bit) - 1;
+  const int half = 1 << (base_bit - 1);
+#pragma unroll 1
+  for (int j = 0; j < t; j++) {
+    const d2 *__restrict__ row = entry + (size_t)j * (2 * M);
+    const int shift = 64 - (j + 1) * base_bit;
+    double re[8], im[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      re[m] = (double)((int)((uint32_t)(dd_lo[m] >> shift) & mask) - half);
+      im[m] = (double)((int)((uint32_t)(dd_hi[m] >> shift) & mask) - half);
+    }
+    fft.forward_head(re, im, xch, tid);
+    d2 k0[8], k1[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) k0[m] = row[m * T + tid];
+    fft.forward_tail(re, im);
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      k1[m] = row[M + m * T + tid];
+      o_re[0][m] = __builtin_fma(-im[m], k0[m].y, __builtin_fma(re[m], k0[m].x, o_re[0][m]));
+      o_im[0][m] = __builtin_fma(im[m], k0[m].x, __builtin_fma(re[m], k0[m].y, o_im[0][m]));
+    }
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      o_re[1][m] = __builtin_fma(-im[m], k1[m].y, __builtin_fma(re[m], k1[m].x, o_re[1][m]));
+      o_im[1][m] = __builtin_fma(im[m], k1[m].x, __builtin_fma(re[m], k1[m].y, o_im[1][m]));
+    }
+  }
+}
+
+// mode 0: out = trlwe_keyswitch(in, ks0)                       = (0, in.b) - as(in.a; ks0)
+// mode 1: out = trlwe_priv_keyswitch_2(in, {ks0, ks1})         = -as(in.a; ks0) - as(-in.b; ks1)
+template <class F>
+__global__ __launch_bounds__(F::THREADS, 2) void trlwe_fft_keyswitch_kernel(const d2 *__restrict__ ks0, const d2 *__restrict__ ks1,
+                                                                          const d2 *__restrict__ tw, const uint64_t *__restrict__ in,
+                                                                          size_t in_stride, uint64_t *__restrict__ out, size_t out_stride,
+                                                                          int t, int base_bit, int mode) {
+  constexpr int N = F::N, M = F::M, T = F::THREADS;
+  __shared__ __attribute__((aligned(16))) d2 xch[F::XCH_SLOTS];
+  const int tid = threadIdx.x;
+  const uint64_t *c = in + (size_t)blockIdx.x * in_stride;
+  uint64_t *o = out + (size_t)blockIdx.x * out_stride;
+  F fft;
+  fft.init(tw, tid);
+  uint64_t off = 1ull << (63 - t * base_bit);
+  for (int i = 0; i < t; i++) off += 1ull << (63 - i * base_bit);
+  const double scale = 0x1p-64 / (double)M;
+  uint64_t res_a_lo[8], res_a_hi[8], res_b_lo[8], res_b_hi[8];
+#pragma unroll
+  for (int m = 0; m < 8; m++) {
+    res_a_lo[m] = 0;
+    res_a_hi[m] = 0;
+    res_b_lo[m] = mode == 0 ? c[N + m * T + tid] : 0;
+    res_b_hi[m] = mode == 0 ? c[N + M + m * T + tid] : 0;
+  }
+  const int passes = mode == 1 ? 2 : 1;
+#pragma unroll 1
+  for (int pass = 0; pass < passes; pass++) {
+    // pass 0 of mode 1: a' = -in.b with ks1 (src/keyswitch.c:55-57); otherwise a' = in.a with ks0
+    const bool neg_b = (mode == 1 && pass == 0);
+    const d2 *__restrict__ entry = neg_b ? ks1 : ks0;
+    uint64_t dd_lo[8], dd_hi[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const uint64_t x_lo = neg_b ? (0 - c[N + m * T + tid]) : c[m * T + tid];
+      const uint64_t x_hi = neg_b ? (0 - c[N + M + m * T + tid]) : c[M + m * T + tid];
+      dd_lo[m] = x_lo + off;
+      dd_hi[m] = x_hi + off;
+    }
+    double o_re[2][8], o_im[2][8];
+#pragma unroll
+    for (int cc = 0; cc < 2; cc++)
+#pragma unroll
+      for (int m = 0; m < 8; m++) { o_re[cc][m] = 0.0; o_im[cc][m] = 0.0; }
+    ks_rows_rt<F>(dd_lo, dd_hi, o_re, o_im, xch, fft, entry, t, base_bit, tid);
+    fft.inverse(o_re[0], o_im[0], xch, tid);
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      res_a_lo[m] -= round_mod_2_64(o_re[0][m], scale);
+      res_a_hi[m] -= round_mod_2_64(o_im[0][m], scale);
+    }
+    fft.inverse(o_re[1], o_im[1], xch, tid);
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      res_b_lo[m] -= round_mod_2_64(o_re[1][m], scale);
+      res_b_hi[m] -= round_mod_2_64(o_im[1][m], scale);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 8; m++) {
+    o[m * T + tid] = res_a_lo[m];
+    o[M + m * T + tid] = res_a_hi[m];
+    o[N + m * T + tid] = res_b_lo[m];
+    o[N + M + m * T + tid] = res_b_hi[m];
+  }
+}
+
 // trgsw_to_DFT / polynomial_torus_to_DFT for a flat array of polynomials [src/trgsw.c:345-349,
 // src/polynomial.c:368-375]: one team per polynomial, output in slot order [m][thread].
 template <class F>

@@ -52,14 +52,15 @@ struct mosfhet_hip_ksk {
   mosfhet_hip_ctx_t ctx;
   uint64_t *d_ksk;
   int n_in, n_out, t, base_bit;
+  int row, b_word;  // output row words and the word that receives in.b (LWE: n_out + 1, n_out; packing -> TRLWE: 2N, N)
   size_t bytes;
   KsWorkspace ws;  // transposed batch buffers, grown on demand
 };
 
 struct mosfhet_hip_gak {
   mosfhet_hip_ctx_t ctx;
-  d2 *d_ak;  // [N][t][2][8][T]
-  int N, t, base_bit;
+  d2 *d_ak;  // [entries][t][2][8][T]
+  int N, t, base_bit, entries;
   size_t bytes;
 };
 
@@ -368,6 +369,7 @@ extern "C" int mosfhet_hip_ksk_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t *
   HIP_TRY(hipSetDevice(ctx->device));
   mosfhet_hip_ksk *k = new mosfhet_hip_ksk();
   k->ctx = ctx; k->n_in = n_in; k->n_out = n_out; k->t = t; k->base_bit = base_bit;
+  k->row = n_out + 1; k->b_word = n_out;
   k->bytes = (size_t)n_in * t * ((1u << base_bit) - 1) * (n_out + 1) * sizeof(uint64_t);
   HIP_TRY(hipMalloc((void **)&k->d_ksk, k->bytes));
   HIP_TRY(hipMemcpy(k->d_ksk, h_ksk, k->bytes, hipMemcpyHostToDevice));
@@ -390,7 +392,9 @@ extern "C" int mosfhet_hip_tlwe_keyswitch_batch(mosfhet_hip_ctx_t ctx, mosfhet_h
   if (!ctx || !ksk || !d_out || !d_in || count < 0) return fail(MOSFHET_HIP_EINVAL, "tlwe_keyswitch: bad argument");
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
-  HIP_TRY(launch_tlwe_keyswitch(ksk->d_ksk, d_out, d_in, count, ksk->n_in, ksk->n_out, ksk->t, ksk->base_bit, ksk->ws, pick(ctx, stream)));
+  if (ksk->b_word != ksk->n_out) return fail(MOSFHET_HIP_EINVAL, "tlwe_keyswitch: this key is a packing (LWE -> TRLWE) key");
+  HIP_TRY(launch_tlwe_keyswitch(ksk->d_ksk, d_out, (size_t)ksk->row, d_in, (size_t)ksk->n_in + 1, count, ksk->n_in, ksk->row, ksk->b_word, ksk->t,
+                                ksk->base_bit, ksk->ws, pick(ctx, stream)));
   return MOSFHET_HIP_OK;
 }
 
@@ -473,19 +477,20 @@ extern "C" int mosfhet_hip_multivalue_bootstrap_CLOT21_batch(mosfhet_hip_ctx_t c
 }
 
 // ---- Galois automorphisms ----
-extern "C" int mosfhet_hip_gak_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_gak_t *out, const uint64_t *h_ak, int N, int t, int base_bit) {
-  if (!ctx || !out || !h_ak) return fail(MOSFHET_HIP_EINVAL, "gak_create: bad argument");
-  int rc = check_params("gak_create", 1, N, t, base_bit);
-  if (rc) return rc;
+extern "C" int mosfhet_hip_trlwe_ksk_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_gak_t *out, const uint64_t *h_rows, int entries, int N, int t,
+                                            int base_bit) {
+  if (!ctx || !out || !h_rows || entries < 1) return fail(MOSFHET_HIP_EINVAL, "trlwe_ksk_create: bad argument");
+  if (N != 1024 && N != 2048) return fail(MOSFHET_HIP_EINVAL, "trlwe_ksk_create: N = %d not supported (1024, 2048)", N);
+  if (t < 1 || base_bit < 1 || t * base_bit >= 64) return fail(MOSFHET_HIP_EINVAL, "trlwe_ksk_create: bad t = %d base_bit = %d", t, base_bit);
   HIP_TRY(hipSetDevice(ctx->device));
   mosfhet_hip_gak *g = new mosfhet_hip_gak();
-  g->ctx = ctx; g->N = N; g->t = t; g->base_bit = base_bit;
-  const size_t polys = (size_t)N * t * 2;
+  g->ctx = ctx; g->N = N; g->t = t; g->base_bit = base_bit; g->entries = entries;
+  const size_t polys = (size_t)entries * t * 2;
   g->bytes = polys * N * sizeof(double);
   uint64_t *d_tmp = nullptr;
   HIP_TRY(hipMalloc((void **)&d_tmp, g->bytes));
   HIP_TRY(hipMalloc((void **)&g->d_ak, g->bytes));
-  HIP_TRY(hipMemcpy(d_tmp, h_ak, g->bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_tmp, h_rows, g->bytes, hipMemcpyHostToDevice));
   if (N == 1024) hipLaunchKernelGGL(torus_to_dft_kernel<Fft1024>, dim3((unsigned)polys), dim3(64), 0, nullptr, d_tmp, g->d_ak, ctx->tw1024);
   else hipLaunchKernelGGL(torus_to_dft_kernel<Fft2048>, dim3((unsigned)polys), dim3(128), 0, nullptr, d_tmp, g->d_ak, ctx->tw2048);
   HIP_TRY(hipGetLastError());
@@ -493,6 +498,10 @@ extern "C" int mosfhet_hip_gak_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_gak_t *
   hipFree(d_tmp);
   *out = g;
   return MOSFHET_HIP_OK;
+}
+
+extern "C" int mosfhet_hip_gak_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_gak_t *out, const uint64_t *h_ak, int N, int t, int base_bit) {
+  return mosfhet_hip_trlwe_ksk_create(ctx, out, h_ak, N, N, t, base_bit);
 }
 
 extern "C" int mosfhet_hip_gak_destroy(mosfhet_hip_gak_t gak) {
@@ -566,6 +575,94 @@ extern "C" int mosfhet_hip_functional_bootstrap_ga_batch(mosfhet_hip_ctx_t ctx, 
   g.mode = 0;
   return bsk->N == 1024 ? launch_ga_f<Fft1024>(bsk->l, bsk->Bg_bit, g, count, pick(ctx, stream))
                         : launch_ga_f<Fft2048>(bsk->l, bsk->Bg_bit, g, count, pick(ctx, stream));
+}
+
+// ---- FFT TRLWE key switches with run-time parameters, packing key switch, circuit bootstrap ----
+static int launch_fft_ks(mosfhet_hip_ctx_t ctx, mosfhet_hip_gak_t tks, const d2 *ks0, const d2 *ks1, uint64_t *d_out, size_t out_stride,
+                         const uint64_t *d_in, size_t in_stride, int count, int mode, hipStream_t s) {
+  if (tks->N == 1024)
+    hipLaunchKernelGGL(trlwe_fft_keyswitch_kernel<Fft1024>, dim3(count), dim3(64), 0, s, ks0, ks1, ctx->tw1024, d_in, in_stride, d_out, out_stride,
+                       tks->t, tks->base_bit, mode);
+  else
+    hipLaunchKernelGGL(trlwe_fft_keyswitch_kernel<Fft2048>, dim3(count), dim3(128), 0, s, ks0, ks1, ctx->tw2048, d_in, in_stride, d_out, out_stride,
+                       tks->t, tks->base_bit, mode);
+  HIP_TRY(hipGetLastError());
+  return MOSFHET_HIP_OK;
+}
+
+extern "C" int mosfhet_hip_trlwe_keyswitch_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_gak_t tks, int entry, uint64_t *d_out, const uint64_t *d_in,
+                                                 int count, void *stream) {
+  if (!ctx || !tks || !d_out || !d_in || count < 0 || entry < 0 || entry >= tks->entries) return fail(MOSFHET_HIP_EINVAL, "trlwe_keyswitch: bad argument");
+  if (count == 0) return MOSFHET_HIP_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  const d2 *k = tks->d_ak + (size_t)entry * tks->t * 2 * (tks->N / 2);
+  return launch_fft_ks(ctx, tks, k, k, d_out, (size_t)2 * tks->N, d_in, (size_t)2 * tks->N, count, 0, pick(ctx, stream));
+}
+
+extern "C" int mosfhet_hip_trlwe_priv_keyswitch_2_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_gak_t tks, uint64_t *d_out, const uint64_t *d_in,
+                                                        int count, void *stream) {
+  if (!ctx || !tks || !d_out || !d_in || count < 0 || tks->entries != 2) return fail(MOSFHET_HIP_EINVAL, "priv_keyswitch_2: needs a 2-entry key set");
+  if (count == 0) return MOSFHET_HIP_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t esz = (size_t)tks->t * 2 * (tks->N / 2);
+  return launch_fft_ks(ctx, tks, tks->d_ak, tks->d_ak + esz, d_out, (size_t)2 * tks->N, d_in, (size_t)2 * tks->N, count, 1, pick(ctx, stream));
+}
+
+extern "C" int mosfhet_hip_packing1_ksk_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t *out, const uint64_t *h_rows, int n, int N, int t,
+                                               int base_bit) {
+  // same table layout as the LWE key: rows of 2N words instead of n_out + 1, in.b lands on word N (b[0])
+  int rc = mosfhet_hip_ksk_create(ctx, out, h_rows, n, 2 * N - 1, t, base_bit);
+  if (rc) return rc;
+  (*out)->b_word = N;
+  return MOSFHET_HIP_OK;
+}
+
+extern "C" int mosfhet_hip_trlwe_packing1_keyswitch_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t ksk, uint64_t *d_out, const uint64_t *d_in,
+                                                          int count, void *stream) {
+  if (!ctx || !ksk || !d_out || !d_in || count < 0) return fail(MOSFHET_HIP_EINVAL, "packing1_keyswitch: bad argument");
+  if (ksk->b_word == ksk->n_out) return fail(MOSFHET_HIP_EINVAL, "packing1_keyswitch: this key is an LWE -> LWE key");
+  if (count == 0) return MOSFHET_HIP_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(launch_tlwe_keyswitch(ksk->d_ksk, d_out, (size_t)ksk->row, d_in, (size_t)ksk->n_in + 1, count, ksk->n_in, ksk->row, ksk->b_word, ksk->t,
+                                ksk->base_bit, ksk->ws, pick(ctx, stream)));
+  return MOSFHET_HIP_OK;
+}
+
+// test vector of circuit_bootstrap_3 (src/bootstrap.c:350-355): 2l slots, slot l + i = 2^(64 - (i+1) Bg), slots < l zero
+__global__ void circuit_bootstrap_lut_kernel(uint64_t *__restrict__ tv, int N, int l, int Bg_bit) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int slot = i / (N / (2 * l));
+  tv[i] = 0;
+  tv[N + i] = slot >= l ? (1ull << (64 - (slot - l + 1) * Bg_bit)) : 0;
+}
+
+extern "C" int mosfhet_hip_circuit_bootstrap_3_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, mosfhet_hip_gak_t kska, mosfhet_hip_ksk_t kskb,
+                                                     uint64_t *d_out, const uint64_t *d_in, int count, void *stream) {
+  if (!ctx || !bsk || !kska || !kskb || !d_out || !d_in || count < 0) return fail(MOSFHET_HIP_EINVAL, "circuit_bootstrap_3: bad argument");
+  const int N = bsk->N, l = bsk->l;
+  if (kska->entries != 2 || kska->N != N) return fail(MOSFHET_HIP_EINVAL, "circuit_bootstrap_3: kska must be the 2-entry private key-switch set for N");
+  if (kskb->row != 2 * N || kskb->b_word != N || kskb->n_in != N) return fail(MOSFHET_HIP_EINVAL, "circuit_bootstrap_3: kskb must be a packing key N -> TRLWE(N)");
+  if (N % (2 * l)) return fail(MOSFHET_HIP_EINVAL, "circuit_bootstrap_3: N not divisible by 2l");
+  if (count == 0) return MOSFHET_HIP_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t w_tv = (size_t)2 * N, w_acc = (size_t)count * 2 * N, w_ext = (size_t)count * (N + 1);
+  int rc = bsk_scratch(bsk, w_tv + w_acc + w_ext);
+  if (rc) return rc;
+  uint64_t *tv = bsk->scratch, *acc = tv + w_tv, *ext = acc + w_acc;
+  hipStream_t s = pick(ctx, stream);
+  hipLaunchKernelGGL(circuit_bootstrap_lut_kernel, dim3((N + 255) / 256), dim3(256), 0, s, tv, N, l, bsk->Bg_bit);
+  if ((rc = mosfhet_hip_functional_bootstrap_wo_extract_batch(ctx, bsk, acc, tv, 1, d_in, count, 2 * l, stream))) return rc;
+  const int slot = N / (2 * l);
+  const size_t trgsw = (size_t)2 * l * 2 * N, esz = (size_t)kska->t * 2 * (N / 2);
+  for (int i = 0; i < l; i++) {
+    hipLaunchKernelGGL(trlwe_extract_kernel, dim3((N + 255) / 256, count), dim3(256), 0, s, ext, (size_t)N + 1, acc, (size_t)2 * N, N, i * slot);
+    uint64_t *row_b = d_out + (size_t)(l + i) * 2 * N, *row_a = d_out + (size_t)i * 2 * N;
+    HIP_TRY(launch_tlwe_keyswitch(kskb->d_ksk, row_b, trgsw, ext, (size_t)N + 1, count, N, 2 * N, N, kskb->t, kskb->base_bit, kskb->ws, s));
+    if ((rc = launch_fft_ks(ctx, kska, kska->d_ak, kska->d_ak + esz, row_a, trgsw, row_b, trgsw, count, 1, s))) return rc;
+  }
+  HIP_TRY(hipGetLastError());
+  return MOSFHET_HIP_OK;
 }
 
 // ---- timing hook ----

@@ -52,20 +52,21 @@ constexpr int KS_LDS_BYTES = 16384;
 constexpr int KS_PF_MAX = 8;     // upper bound of staged row elements a thread prefetches per stage
 
 // inT: [n_in + 1][Bp] (word i of ciphertext c at inT[i * Bp + c]; Bp a multiple of 64 * NW, padding zero-filled)
-// outT: [n_out + 1][Bp]
+// outT: [row][Bp]; rows have `row` words and the input's b word is added into word `b_word`
+// (LWE -> LWE: row = n_out + 1, b_word = n_out; LWE -> TRLWE packing: row = 2N, b_word = N, src/keyswitch.c:458-475)
 // Stages (i, j0..j0+JB) are software-pipelined: while a stage is consumed from one LDS buffer, the rows of the next
 // stage are already in flight into registers and are written to the other buffer afterwards -- one barrier per stage.
 // PF = ceil(JB * cands / (64 NW / W)): candidate-row words each thread moves per stage (compile time: no predicated
 // load chains).  Requires t % JB == 0 or handles the short last block of an i by re-staging valid rows only.
 template <int W, int NW, int PF>
 __global__ __launch_bounds__(64 * NW) void tlwe_keyswitch_kernel(const uint64_t *__restrict__ ksk, const uint64_t *__restrict__ inT,
-                                                                uint64_t *__restrict__ outT, size_t Bp, int n_in, int n_out, int t,
+                                                                uint64_t *__restrict__ outT, size_t Bp, int n_in, int row, int b_word, int t,
                                                                 int base_bit, int JB, int i_per_split) {
   extern __shared__ __attribute__((aligned(16))) uint64_t rows[];  // [2][JB][cands + 1][W + 2]
   constexpr int RS = W + 2;                                        // row stride in words (16-byte aligned, bank-skewed)
   constexpr int SV_STEP = (64 * NW) / W;
   const int tid = threadIdx.x;
-  const int row = n_out + 1, cands = (1 << base_bit) - 1;
+  const int cands = (1 << base_bit) - 1;
   const int w0 = blockIdx.x * W;                                   // first output word of this slice
   const size_t ct = (size_t)blockIdx.y * (64 * NW) + tid;          // this lane's ciphertext (column of inT / outT)
   const uint64_t round_off = 1ull << (63 - base_bit * t);
@@ -79,11 +80,11 @@ __global__ __launch_bounds__(64 * NW) void tlwe_keyswitch_kernel(const uint64_t 
   // transposing epilogue.  Only split 0 carries the b word.
   const int i_begin = blockIdx.z * i_per_split, i_end = (i_begin + i_per_split < n_in) ? i_begin + i_per_split : n_in;
   outT += (size_t)blockIdx.z * (size_t)row * Bp;
-  if (blockIdx.z == 0 && n_out >= w0 && n_out < w0 + W) {
+  if (blockIdx.z == 0 && b_word >= w0 && b_word < w0 + W) {
     const uint64_t b = inT[(size_t)n_in * Bp + ct];
 #pragma unroll
     for (int w = 0; w < W; w++)
-      if (w0 + w == n_out) acc[w] = b;
+      if (w0 + w == b_word) acc[w] = b;
   }
   // zero rows (digit 0) of every j slot of both buffers, once
   for (int k = tid; k < 2 * JB * RS; k += 64 * NW) {
@@ -190,19 +191,20 @@ struct KsWorkspace {
 };
 
 // Returns hipSuccess or the failing error.  ws is grown on demand (kept by the key handle between calls).
-inline hipError_t launch_tlwe_keyswitch(const uint64_t *ksk, uint64_t *out, const uint64_t *in, int count, int n_in, int n_out, int t,
-                                        int base_bit, KsWorkspace &ws, hipStream_t s) {
+// in: rows of n_in + 1 words spaced in_stride words apart; out: rows of `row` words spaced out_stride apart.
+inline hipError_t launch_tlwe_keyswitch(const uint64_t *ksk, uint64_t *out, size_t out_stride, const uint64_t *in, size_t in_stride, int count,
+                                        int n_in, int row, int b_word, int t, int base_bit, KsWorkspace &ws, hipStream_t s) {
   constexpr int W = KS_W, NW = KS_NW, TILE = 64 * NW;
   const size_t Bp = ((size_t)count + TILE - 1) / TILE * TILE;
   // split the mask words over blockIdx.z until the grid fills the chip (each workgroup walks its i-range serially)
-  const int slices = (n_out + 1 + W - 1) / W, ct_blocks = (int)(Bp / TILE);
+  const int slices = (row + W - 1) / W, ct_blocks = (int)(Bp / TILE);
   int split = (1536 + slices * ct_blocks - 1) / (slices * ct_blocks);
   if (split > 16) split = 16;
   if (split > n_in / 8) split = n_in / 8;
   if (split < 1) split = 1;
   const int i_per_split = (n_in + split - 1) / split;
   split = (n_in + i_per_split - 1) / i_per_split;
-  const size_t need_in = (size_t)(n_in + 1) * Bp, need_out = (size_t)split * (n_out + 1) * Bp;
+  const size_t need_in = (size_t)(n_in + 1) * Bp, need_out = (size_t)split * row * Bp;
   hipError_t e;
   if (ws.words_in < need_in) {
     if (ws.inT) (void)hipFree(ws.inT);
@@ -217,7 +219,7 @@ inline hipError_t launch_tlwe_keyswitch(const uint64_t *ksk, uint64_t *out, cons
   if (Bp != (size_t)count && (e = hipMemsetAsync(ws.inT, 0, need_in * sizeof(uint64_t), s)) != hipSuccess) return e;
   // in[count][n_in + 1] -> inT[n_in + 1][Bp]
   hipLaunchKernelGGL(transpose_u64_kernel, dim3((n_in + 1 + 31) / 32, (count + 31) / 32), dim3(32, 8), 0, s, in, ws.inT, count, n_in + 1,
-                     (size_t)(n_in + 1), Bp, 1, (size_t)0);
+                     in_stride, Bp, 1, (size_t)0);
   const int cands = (1 << base_bit) - 1;
   int JB = KS_LDS_BYTES / ((cands + 1) * (W + 2) * 8);          // per LDS buffer
   const int pf_cap = KS_PF_MAX * (TILE / W) / cands;             // rows a stage can prefetch through registers
@@ -228,7 +230,7 @@ inline hipError_t launch_tlwe_keyswitch(const uint64_t *ksk, uint64_t *out, cons
   const size_t lds = 2 * (size_t)JB * (cands + 1) * (W + 2) * 8;
   const int pf = (JB * cands + TILE / W - 1) / (TILE / W);
   const dim3 grid(slices, ct_blocks, split);
-#define KS_LAUNCH(PF) hipLaunchKernelGGL((tlwe_keyswitch_kernel<W, NW, PF>), grid, dim3(TILE), lds, s, ksk, ws.inT, ws.outT, Bp, n_in, n_out, t, base_bit, JB, i_per_split)
+#define KS_LAUNCH(PF) hipLaunchKernelGGL((tlwe_keyswitch_kernel<W, NW, PF>), grid, dim3(TILE), lds, s, ksk, ws.inT, ws.outT, Bp, n_in, row, b_word, t, base_bit, JB, i_per_split)
   switch (pf) {
     case 1: KS_LAUNCH(1); break;
     case 2: KS_LAUNCH(2); break;
@@ -240,9 +242,9 @@ inline hipError_t launch_tlwe_keyswitch(const uint64_t *ksk, uint64_t *out, cons
     default: KS_LAUNCH(8); break;
   }
 #undef KS_LAUNCH
-  // outT[n_out + 1][Bp] -> out[count][n_out + 1]
-  hipLaunchKernelGGL(transpose_u64_kernel, dim3((count + 31) / 32, (n_out + 1 + 31) / 32), dim3(32, 8), 0, s, ws.outT, out, n_out + 1, count,
-                     Bp, (size_t)(n_out + 1), split, (size_t)(n_out + 1) * Bp);
+  // outT[row][Bp] -> out[count][row]
+  hipLaunchKernelGGL(transpose_u64_kernel, dim3((count + 31) / 32, (row + 31) / 32), dim3(32, 8), 0, s, ws.outT, out, row, count, Bp, out_stride,
+                     split, (size_t)row * Bp);
   return hipGetLastError();
 }
 

@@ -167,6 +167,51 @@ class Engine:
         _check(lib().mosfhet_hip_gak_create(self.h, C.byref(h), ak_torus.ctypes.data_as(C.c_void_p), N, t, base_bit))
         return AutomorphismKeys(self, h, N, t, base_bit)
 
+    def load_trlwe_ks_keys(self, rows, base_bit):
+        """rows: numpy uint64 [entries][t][2][N] (torus domain) -> device FFT key-switch key set."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        entries, t, two, N = rows.shape
+        h = C.c_void_p()
+        _check(lib().mosfhet_hip_trlwe_ksk_create(self.h, C.byref(h), rows.ctypes.data_as(C.c_void_p), entries, N, t, base_bit))
+        return AutomorphismKeys(self, h, N, t, base_bit)
+
+    def load_packing1_key(self, rows, base_bit):
+        """rows: numpy uint64 [n][t][2^bb-1][2][N] -> device LWE -> TRLWE packing key."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        n, t, per_j, two, N = rows.shape
+        h = C.c_void_p()
+        _check(lib().mosfhet_hip_packing1_ksk_create(self.h, C.byref(h), rows.ctypes.data_as(C.c_void_p), n, N, t, base_bit))
+        return KeySwitchKey(self, h, n, 2 * N - 1, t, base_bit)
+
+    def trlwe_keyswitch(self, tks, entry, ct, out=None):
+        count = ct.shape[0]
+        if out is None:
+            out = self.empty(count, 2, tks.N)
+        _check(lib().mosfhet_hip_trlwe_keyswitch_batch(self.h, tks.h, int(entry), _ptr(out), _ptr(ct), count, self._stream()))
+        return out
+
+    def trlwe_priv_keyswitch_2(self, tks, ct, out=None):
+        count = ct.shape[0]
+        if out is None:
+            out = self.empty(count, 2, tks.N)
+        _check(lib().mosfhet_hip_trlwe_priv_keyswitch_2_batch(self.h, tks.h, _ptr(out), _ptr(ct), count, self._stream()))
+        return out
+
+    def trlwe_packing1_keyswitch(self, ksk, ct, out=None):
+        count = ct.shape[0]
+        N = (ksk.n_out + 1) // 2
+        if out is None:
+            out = self.empty(count, 2, N)
+        _check(lib().mosfhet_hip_trlwe_packing1_keyswitch_batch(self.h, ksk.h, _ptr(out), _ptr(ct), count, self._stream()))
+        return out
+
+    def circuit_bootstrap_3(self, bsk, kska, kskb, ct, out=None):
+        count = ct.shape[0]
+        if out is None:
+            out = self.empty(count, 2 * bsk.l, 2, bsk.N)
+        _check(lib().mosfhet_hip_circuit_bootstrap_3_batch(self.h, bsk.h, kska.h, kskb.h, _ptr(out), _ptr(ct), count, self._stream()))
+        return out
+
     def trlwe_eval_automorphism(self, gak, ct, gen, out=None):
         count = ct.shape[0]
         if out is None:

@@ -126,6 +126,18 @@ void orc_gen_automorphism_keyset(orc_rng *r, Torus *ak /*[N][t][2][N]*/, const T
 void orc_gen_bootstrap_key_ga(orc_rng *r, Torus *bk, const Torus *lwe_s, int n, const Torus *rlwe_s, int N, int l, int Bg_bit,
                               double sigma);                                            /* bootstrap_ga.c:17-20: BK_i = TRGSW(X^{s_i}) */
 
+/* ---- circuit bootstrap (k = 1) ---- */
+void orc_trlwe_packing1_keyswitch(Torus *out /*[2][N]*/, const Torus *in /*[n+1]*/, const Torus *ksk /*[n][t][2^bb-1][2][N]*/,
+                                  int n, int N, int t, int base_bit);                    /* keyswitch.c:458-475 */
+void orc_trlwe_priv_keyswitch_2(const orc_fft_plan *p, Torus *out, const Torus *in, const double *ks0_dft, const double *ks1_dft,
+                                int t, int base_bit);                                    /* keyswitch.c:52-63 */
+void orc_circuit_bootstrap_3(const orc_fft_plan *p, Torus *out /*[2l][2][N]*/, const Torus *in, const double *bk_dft, const double *kska0_dft,
+                             const double *kska1_dft, int ta, int bba, const Torus *kskb, int tb, int bbb, int n, int l, int Bg_bit); /* bootstrap.c:346-366 */
+void orc_gen_packing1_ks_key(orc_rng *r, Torus *ksk, const Torus *s_in /*[n]*/, int n, const Torus *s_out /*[N]*/, int N, int t, int base_bit,
+                             double sigma);                                              /* keyswitch.c:368-390 */
+void orc_gen_priv_ks_key(orc_rng *r, Torus *ks0 /*[t][2][N]*/, Torus *ks1, const Torus *s_out, const Torus *s_in, int N, int t, int base_bit,
+                         double sigma);                                                  /* keyswitch.c:39-50 */
+
 /* ---- deterministic test-input generation (own code; the reference's RNG is RDRAND-seeded
  *      and not reproducible, src/misc.c:34-49) ---- */
 uint64_t orc_rng_next(orc_rng *r);                       /* splitmix64 */

@@ -360,6 +360,43 @@ def gen_bootstrap_key_ga(rng, lwe_s, rlwe_s, l, Bg_bit, sigma):
     return bk
 
 
+# ---------------- circuit bootstrap ----------------
+def trlwe_packing1_keyswitch(c, ksk, base_bit):
+    n, t, _, _, N = ksk.shape
+    out = np.empty((2, N), dtype=np.uint64)
+    lib().orc_trlwe_packing1_keyswitch(_u(out), _u(c), _u(ksk), n, N, t, base_bit)
+    return out
+
+
+def trlwe_priv_keyswitch_2(c, ks0_dft, ks1_dft, t, base_bit):
+    out = np.empty_like(c)
+    lib().orc_trlwe_priv_keyswitch_2(plan(c.shape[1]).h, _u(out), _u(c), _d(ks0_dft), _d(ks1_dft), t, base_bit)
+    return out
+
+
+def circuit_bootstrap_3(c, bk_dft, kska0_dft, kska1_dft, bba, kskb, bbb, l, Bg_bit):
+    N = bk_dft.shape[-1]
+    ta, tb = kska0_dft.shape[0], kskb.shape[1]
+    out = np.empty((2 * l, 2, N), dtype=np.uint64)
+    lib().orc_circuit_bootstrap_3(plan(N).h, _u(out), _u(c), _d(bk_dft), _d(kska0_dft), _d(kska1_dft), ta, bba, _u(kskb), tb, bbb,
+                                  C.c_int(c.size - 1), l, Bg_bit)
+    return out
+
+
+def gen_packing1_ks_key(rng, s_in, s_out, t, base_bit, sigma):
+    n, N = s_in.size, s_out.size
+    ksk = np.empty((n, t, (1 << base_bit) - 1, 2, N), dtype=np.uint64)
+    lib().orc_gen_packing1_ks_key(rng.ref(), _u(ksk), _u(s_in), n, _u(s_out), N, t, base_bit, C.c_double(sigma))
+    return ksk
+
+
+def gen_priv_ks_key(rng, s_out, s_in, t, base_bit, sigma):
+    N = s_out.size
+    ks0, ks1 = np.empty((t, 2, N), dtype=np.uint64), np.empty((t, 2, N), dtype=np.uint64)
+    lib().orc_gen_priv_ks_key(rng.ref(), _u(ks0), _u(ks1), _u(s_out), _u(s_in), N, t, base_bit, C.c_double(sigma))
+    return ks0, ks1
+
+
 # ---------------- deterministic inputs ----------------
 def gen_binary_key(rng, n):
     s = np.empty(n, dtype=np.uint64)

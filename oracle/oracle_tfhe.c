@@ -289,6 +289,92 @@ void orc_gen_bootstrap_key_ga(orc_rng *r, Torus *bk, const Torus *lwe_s, int n, 
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Circuit bootstrap (k = 1): LWE -> TRGSW.
+ * ------------------------------------------------------------------------------------------ */
+/* src/keyswitch.c:458-475  TLWE(m) -> TRLWE(m X^0) by table lookup; rows are TRLWE samples (2N words); same digit
+ * rule as tlwe_keyswitch; in.b goes to coefficient 0 of the b polynomial. */
+void orc_trlwe_packing1_keyswitch(Torus *out, const Torus *in, const Torus *ksk, int n, int N, int t, int base_bit) {
+  const Torus round_off = (Torus)1 << (W - 1 - base_bit * t);
+  const Torus mask = ((Torus)1 << base_bit) - 1;
+  const size_t row = (size_t)2 * N, per_j = ((size_t)1 << base_bit) - 1;
+  memset(out, 0, sizeof(Torus) * row);
+  out[N] = in[n];
+  for (int i = 0; i < n; i++) {
+    const Torus ai = in[i] + round_off;
+    for (int j = 0; j < t; j++) {
+      const Torus v = (ai >> (W - (j + 1) * base_bit)) & mask;
+      if (!v) continue;
+      const Torus *r = ksk + (((size_t)i * t + j) * per_j + (v - 1)) * row;
+      for (size_t c = 0; c < row; c++) out[c] -= r[c];
+    }
+  }
+}
+
+/* src/keyswitch.c:52-63  TRLWE_s(m) -> TRLWE_s(-s m) with two FFT key switches: ks1 on (-in.b, 0), ks0 on (in.a, 0) */
+void orc_trlwe_priv_keyswitch_2(const orc_fft_plan *p, Torus *out, const Torus *in, const double *ks0_dft, const double *ks1_dft,
+                                int t, int base_bit) {
+  int cnt = 0;
+  (void)orc_fft_twiddles(p, &cnt);
+  const int N = 2 * (cnt + 1);
+  Torus *tmp = (Torus *)calloc((size_t)2 * N, sizeof(Torus)), *tmp2 = (Torus *)calloc((size_t)2 * N, sizeof(Torus));
+  for (int i = 0; i < N; i++) tmp[i] = (Torus)0 - in[N + i];
+  orc_trlwe_keyswitch(p, tmp, tmp, ks1_dft, t, base_bit);
+  memcpy(tmp2, in, sizeof(Torus) * (size_t)N);
+  orc_trlwe_keyswitch(p, tmp2, tmp2, ks0_dft, t, base_bit);
+  for (int i = 0; i < 2 * N; i++) out[i] = tmp2[i] + tmp[i];
+  free(tmp);
+  free(tmp2);
+}
+
+/* src/bootstrap.c:346-366  circuit_bootstrap_3: one blind rotation with the 2l-slot LUT (0,...,0, 2^(W-Bg), ..., 2^(W-l Bg)),
+ * then per level: extract, packing key switch (row l+i) and private key switch of that row (row i). */
+void orc_circuit_bootstrap_3(const orc_fft_plan *p, Torus *out, const Torus *in, const double *bk_dft, const double *kska0_dft,
+                             const double *kska1_dft, int ta, int bba, const Torus *kskb, int tb, int bbb, int n, int l, int Bg_bit) {
+  int cnt = 0;
+  (void)orc_fft_twiddles(p, &cnt);
+  const int N = 2 * (cnt + 1), slot_size = N / (2 * l);
+  Torus *lut = (Torus *)calloc((size_t)2 * l, sizeof(Torus));
+  Torus *tv = (Torus *)malloc(sizeof(Torus) * (size_t)2 * N), *acc = (Torus *)malloc(sizeof(Torus) * (size_t)2 * N);
+  Torus *ext = (Torus *)malloc(sizeof(Torus) * (size_t)(N + 1));
+  for (int i = 0; i < l; i++) lut[l + i] = (Torus)1 << (W - (i + 1) * Bg_bit);
+  orc_trlwe_torus_packing(tv, lut, 1, N, 2 * l);
+  orc_functional_bootstrap_wo_extract(p, acc, tv, in, bk_dft, n, 1, l, Bg_bit, 2 * l);
+  for (int i = 0; i < l; i++) {
+    orc_trlwe_extract_tlwe(ext, acc, 1, N, i * slot_size);
+    orc_trlwe_packing1_keyswitch(out + (size_t)(l + i) * 2 * N, ext, kskb, N, N, tb, bbb);
+    orc_trlwe_priv_keyswitch_2(p, out + (size_t)i * 2 * N, out + (size_t)(l + i) * 2 * N, kska0_dft, kska1_dft, ta, bba);
+  }
+  free(lut);
+  free(tv);
+  free(acc);
+  free(ext);
+}
+
+/* src/keyswitch.c:368-390  KS[i][j][v-1] = TRLWE_out(0) with s_in[i] v 2^(W-(j+1)bb) added to coefficient 0 of b */
+void orc_gen_packing1_ks_key(orc_rng *r, Torus *ksk, const Torus *s_in, int n, const Torus *s_out, int N, int t, int base_bit, double sigma) {
+  const int base = 1 << base_bit;
+  const size_t row = (size_t)2 * N;
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < t; j++)
+      for (int v = 1; v < base; v++) {
+        Torus *dst = ksk + (((size_t)i * t + j) * (base - 1) + (v - 1)) * row;
+        orc_trlwe_sample(r, dst, NULL, s_out, 1, N, sigma);
+        dst[N] += s_in[i] * (Torus)v * ((Torus)1 << (W - (j + 1) * base_bit));
+      }
+}
+
+/* src/keyswitch.c:39-50  ks0 switches from (-s_out * s_in), ks1 from (-s_out), both to s_out */
+void orc_gen_priv_ks_key(orc_rng *r, Torus *ks0, Torus *ks1, const Torus *s_out, const Torus *s_in, int N, int t, int base_bit, double sigma) {
+  Torus *neg = (Torus *)malloc(sizeof(Torus) * (size_t)N), *prod = (Torus *)malloc(sizeof(Torus) * (size_t)N);
+  for (int i = 0; i < N; i++) neg[i] = (Torus)0 - s_out[i];
+  orc_poly_naive_mul(prod, neg, s_in, N);
+  orc_gen_trlwe_ks_key(r, ks0, prod, s_out, N, t, base_bit, sigma);
+  orc_gen_trlwe_ks_key(r, ks1, neg, s_out, N, t, base_bit, sigma);
+  free(neg);
+  free(prod);
+}
+
+/* ------------------------------------------------------------------------------------------
  * Deterministic inputs.  The reference seeds from RDRAND / urandom (src/misc.c:34-49) and is not
  * reproducible, so tests draw keys and samples from splitmix64 with the same distributions.
  * ------------------------------------------------------------------------------------------ */

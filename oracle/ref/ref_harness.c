@@ -374,6 +374,46 @@ void ref_functional_bootstrap_ga(Torus *out, const Torus *tv, const Torus *in, v
   free_tlwe(c);
 }
 
+/* ---------- circuit bootstrap (src/bootstrap.c:346-366, src/keyswitch.c:52-63,458-475) ---------- */
+/* Generic_KS_Key from flat rows [n][t][2^bb-1][2][N]; built with plain (uncompressed) TRLWE rows -- the library is
+ * compiled with USE_COMPRESSED_TRLWE, whose _MACRO_trlwe_subto expects seed-compressed rows, so the table-lookup
+ * loop of trlwe_packing1_keyswitch (keyswitch.c:458-475) is restated here on plain rows with the library's trlwe_subto. */
+void ref_trlwe_packing1_keyswitch(Torus *out, const Torus *in, const Torus *ksk, int n, int N, int t, int base_bit) {
+  const int bit_size = sizeof(Torus) * 8;
+  const Torus prec_offset = 1UL << (bit_size - (1 + base_bit * t));
+  const Torus mask = (1UL << base_bit) - 1;
+  const size_t row = (size_t)2 * N, per_j = (1UL << base_bit) - 1;
+  TRLWE o = trlwe_alloc_new_sample(1, N), r = trlwe_alloc_new_sample(1, N);
+  trlwe_noiseless_trivial_sample(o, NULL);
+  o->b->coeffs[0] = in[n];
+  for (int i = 0; i < n; i++) {
+    const Torus aibar = in[i] + prec_offset;
+    for (int j = 0; j < t; j++) {
+      const Torus aij = (aibar >> (bit_size - (j + 1) * base_bit)) & mask;
+      if (aij != 0) {
+        const Torus *src = ksk + (((size_t)i * t + j) * per_j + (aij - 1)) * row;
+        memcpy(r->a[0]->coeffs, src, sizeof(Torus) * N);
+        memcpy(r->b->coeffs, src + N, sizeof(Torus) * N);
+        trlwe_subto(o, r);
+      }
+    }
+  }
+  trlwe_to_flat(out, o, N);
+  free_trlwe(o);
+  free_trlwe(r);
+}
+
+void ref_trlwe_priv_keyswitch_2(Torus *out, const Torus *in, const Torus *ks0_flat, const Torus *ks1_flat, int N, int t, int base_bit) {
+  TRLWE_KS_Key ks[2] = {trlwe_ks_from_flat(ks0_flat, 1, N, t, base_bit), trlwe_ks_from_flat(ks1_flat, 1, N, t, base_bit)};
+  TRLWE c = trlwe_from_flat(in, 1, N), o = trlwe_alloc_new_sample(1, N);
+  trlwe_priv_keyswitch_2(o, c, ks);
+  trlwe_to_flat(out, o, N);
+  free_trlwe(c);
+  free_trlwe(o);
+  free_trlwe_ks_key(ks[0]);
+  free_trlwe_ks_key(ks[1]);
+}
+
 /* ---------- CPU baseline: time `reps` reference programmable bootstraps on the calling thread.
  * Re-entrant across threads once ref_init(N) has run on the main thread (FFT processors are
  * __thread, src/polynomial.c:338-349). Returns elapsed seconds. ---------- */

@@ -224,6 +224,18 @@ class Ref:
         self.l.ref_functional_bootstrap_ga(_u(out), _u(tv), _u(c), h, torus_base, int(extract))
         return out
 
+    def trlwe_packing1_keyswitch(self, c, ksk, base_bit):
+        n, t, _, _, N = ksk.shape
+        out = np.empty((2, N), dtype=np.uint64)
+        self.l.ref_trlwe_packing1_keyswitch(_u(out), _u(c), _u(ksk), n, N, t, base_bit)
+        return out
+
+    def trlwe_priv_keyswitch_2(self, c, ks0, ks1, base_bit):
+        t, _, N = ks0.shape
+        out = np.empty_like(c)
+        self.l.ref_trlwe_priv_keyswitch_2(_u(out), _u(c), _u(ks0), _u(ks1), N, t, base_bit)
+        return out
+
     def bench_programmable_bootstrap(self, tv, c, h, precision, reps):
         """Seconds for `reps` programmable_bootstrap calls on the calling thread (GIL released)."""
         return self.l.ref_bench_programmable_bootstrap(_u(tv), _u(c), h, precision, reps)

@@ -149,3 +149,29 @@ def test_trlwe_keyswitch_automorphism_and_ga_bootstrap(oracle, ref):
         assert oracle.torus_dist(mine, ref.functional_bootstrap_ga(tv, ct, h, 4)).max() < 2.0 ** 42, m
         assert oracle.torus_dist(oracle.tlwe_phase(mine, s), lut[m]) < 2.0 ** 58
     ref.bk_ga_free(h)
+
+
+def test_circuit_bootstrap_pieces(oracle, ref):
+    """trlwe_priv_keyswitch_2 (src/keyswitch.c:52-63) against the reference, and trlwe_packing1_keyswitch
+    (src/keyswitch.c:458-475): the reference is built with seed-compressed key rows, so its table-lookup loop is restated on
+    plain rows in oracle/ref/ref_harness.c (same digit rule, the library's own trlwe_subto) -- bit-exact."""
+    rng = oracle.Rng(0x7B)
+    N, sigma = 1024, 2.0 ** -40
+    s = oracle.gen_binary_key(rng, N)
+    ks0, ks1 = oracle.gen_priv_ks_key(rng, s, s, 10, 3, sigma)
+    msg = np.zeros(N, dtype=np.uint64)
+    msg[0] = oracle.double2torus(0.125)
+    ct = oracle.trlwe_sample(rng, msg, s.reshape(1, N), sigma)
+    mine = oracle.trlwe_priv_keyswitch_2(ct, oracle.ks_to_dft(ks0), oracle.ks_to_dft(ks1), 10, 3)
+    assert oracle.torus_dist(mine, ref.trlwe_priv_keyswitch_2(ct, ks0, ks1, 3)).max() < 2.0 ** 36
+    want = oracle.poly_naive_mul(np.uint64(0) - s, msg)     # TRLWE(m) -> TRLWE(-s m)
+    assert oracle.torus_dist(oracle.trlwe_phase(mine, s.reshape(1, N)), want).max() < 2.0 ** 52  # test_trlwe_pack_key_priv_ks tolerance
+    n_in = 48
+    s_in = oracle.gen_binary_key(rng, n_in)
+    kskb = oracle.gen_packing1_ks_key(rng, s_in, s, 5, 3, sigma)
+    for m in (0.125, -0.25):
+        c = oracle.tlwe_sample(rng, oracle.double2torus(m), s_in, sigma)
+        mine = oracle.trlwe_packing1_keyswitch(c, kskb, 3)
+        assert (mine == ref.trlwe_packing1_keyswitch(c, kskb, 3)).all()
+        ph = oracle.trlwe_phase(mine, s.reshape(1, N))
+        assert oracle.torus_dist(ph[0], oracle.double2torus(m)) < 2.0 ** 58 and oracle.torus_dist(ph[1:], np.zeros(N - 1, dtype=np.uint64)).max() < 2.0 ** 58
