@@ -123,6 +123,28 @@ void polynomial_permute(TorusPolynomial out, TorusPolynomial in, uint64_t gen); 
 void mosfhet_gen_bootstrap_key_ga_flat(Torus *out /*[n][(k+1)l][k+1][N]*/, TRGSW_Key out_key, TLWE_Key in_key);       /* BK_i = TRGSW(X^{s_i}) */
 void mosfhet_gen_automorphism_keyset_flat(Torus *out /*[N][t][2][N]*/, TRLWE_Key key, int t, int base_bit);           /* src/keyswitch.c:500-511 */
 
+/* ---- TRLWE key switches and circuit bootstrap (src/keyswitch.c, src/bootstrap.c:346-366)  -> GPU ----
+ * Both key types are device resident: `s` is NULL (reference: host arrays of TRLWE_DFT / TRLWE, mosfhet.h:90-103) and
+ * `device` holds the engine handle.  A TRLWE_KS_Key array returned by trlwe_new_priv_KS_key shares ONE device key set
+ * (entry = index in the set), as the automorphism keys do. */
+typedef struct _TRLWE_KS_Key { void **s; int base_bit, t, k;                          /* mosfhet.h:90-93 */
+                               void *device; int entry, owner; } *TRLWE_KS_Key;        /* + engine handle (appended) */
+typedef struct _Generic_KS_Key { TRLWE ***s; int base_bit, t, n, include_b;            /* mosfhet.h:100-103 */
+                                 void *device; } *Generic_KS_Key;                      /* + engine handle (appended) */
+TRLWE_KS_Key trlwe_new_KS_key(TRLWE_Key out_key, TRLWE_Key in_key, int t, int base_bit);         /* keyswitch.c:12-37 */
+void free_trlwe_ks_key(TRLWE_KS_Key key);                                                         /* keyswitch.c:195-203 */
+void trlwe_keyswitch(TRLWE out, TRLWE in, TRLWE_KS_Key ks_key);                                   /* keyswitch.c:162-193; out == in allowed */
+TRLWE_KS_Key *trlwe_new_priv_KS_key(TRLWE_Key out_key, TRLWE_Key in_key, int t, int base_bit);    /* keyswitch.c:39-50 (array of 2) */
+void trlwe_priv_keyswitch_2(TRLWE out, TRLWE in, TRLWE_KS_Key *ks_key);                           /* keyswitch.c:52-63 */
+Generic_KS_Key trlwe_new_packing1_KS_key(TRLWE_Key out_key, TLWE_Key in_key, int t, int base_bit);/* keyswitch.c:368-390 */
+void free_trlwe_generic_ks_key(Generic_KS_Key key);                                               /* keyswitch.c:392-407 */
+void trlwe_packing1_keyswitch(TRLWE out, TLWE in, Generic_KS_Key ks_key);                         /* keyswitch.c:458-475 */
+void circuit_bootstrap_3(TRGSW out, TLWE in, Bootstrap_Key key, TRLWE_KS_Key *kska, Generic_KS_Key kskb);   /* bootstrap.c:346-366 */
+void circuit_bootstrap_3_batch(TRGSW *out, TLWE *in, int count, Bootstrap_Key key, TRLWE_KS_Key *kska, Generic_KS_Key kskb); /* new */
+void mosfhet_gen_trlwe_ks_key_flat(Torus *out /*[t][2][N]*/, const Torus *s_in /*[N]*/, TRLWE_Key out_key, int t, int base_bit);
+void mosfhet_gen_priv_ks_key_flat(Torus *out /*[2][t][2][N]*/, TRLWE_Key out_key, TRLWE_Key in_key, int t, int base_bit);
+void mosfhet_gen_packing1_ks_key_flat(Torus *out /*[n][t][2^bb-1][2][N]*/, TRLWE_Key out_key, TLWE_Key in_key, int t, int base_bit);
+
 /* ---- batch extensions (new): arrays of `count` samples, one shared test vector ---- */
 void functional_bootstrap_batch(TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_Key key, int torus_base);
 void programmable_bootstrap_batch(TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_Key key,

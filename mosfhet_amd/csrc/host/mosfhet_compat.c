@@ -767,3 +767,162 @@ void tlwe_keyswitch_batch(TLWE *out, TLWE *in, int count, TLWE_KS_Key ks) {
 }
 
 void tlwe_keyswitch(TLWE out, TLWE in, TLWE_KS_Key ks_key) { tlwe_keyswitch_batch(&out, &in, 1, ks_key); }
+
+/* ------------------------------------------------------------------ TRLWE key switches, circuit bootstrap */
+/* rows r < t = TRLWE_out( s_in * 2^(64 - (r+1) base_bit) )   [src/keyswitch.c:12-37] */
+void mosfhet_gen_trlwe_ks_key_flat(Torus *out, const Torus *s_in, TRLWE_Key out_key, int t, int base_bit) {
+  const int N = out_key->s[0]->N;
+  TorusPolynomial msg = polynomial_new_torus_polynomial(N);
+  TRLWE tmp = trlwe_alloc_new_sample(1, N);
+  for (int r = 0; r < t; r++) {
+    for (int i = 0; i < N; i++) msg->coeffs[i] = s_in[i] * ((Torus)1 << (W - (r + 1) * base_bit));
+    trlwe_sample(tmp, msg, out_key);
+    trlwe_to_flat(out + (size_t)r * 2 * N, tmp);
+  }
+  free_polynomial(msg);
+  free_trlwe(tmp);
+}
+
+/* entry 0 switches from -s_out * s_in, entry 1 from -s_out   [src/keyswitch.c:39-50] */
+void mosfhet_gen_priv_ks_key_flat(Torus *out, TRLWE_Key out_key, TRLWE_Key in_key, int t, int base_bit) {
+  const int N = out_key->s[0]->N;
+  Torus *neg = (Torus *)xmalloc(sizeof(Torus) * (size_t)N), *prod = (Torus *)xmalloc(sizeof(Torus) * (size_t)N);
+  for (int i = 0; i < N; i++) neg[i] = (Torus)0 - out_key->s[0]->coeffs[i];
+  memset(prod, 0, sizeof(Torus) * (size_t)N);
+  negacyclic_mul_addto(prod, neg, in_key->s[0]->coeffs, N);
+  mosfhet_gen_trlwe_ks_key_flat(out, prod, out_key, t, base_bit);
+  mosfhet_gen_trlwe_ks_key_flat(out + (size_t)t * 2 * N, neg, out_key, t, base_bit);
+  free(neg);
+  free(prod);
+}
+
+/* s[i][j][v-1] = TRLWE_out( constant s_in[i] * v * 2^(64 - (j+1) base_bit) )   [src/keyswitch.c:368-390] */
+void mosfhet_gen_packing1_ks_key_flat(Torus *out, TRLWE_Key out_key, TLWE_Key in_key, int t, int base_bit) {
+  const int N = out_key->s[0]->N, base = 1 << base_bit;
+  TRLWE tmp = trlwe_alloc_new_sample(1, N);
+  for (int i = 0; i < in_key->n; i++)
+    for (int j = 0; j < t; j++)
+      for (int v = 1; v < base; v++) {
+        trlwe_sample(tmp, NULL, out_key);
+        tmp->b->coeffs[0] += in_key->s[i] * (Torus)v * ((Torus)1 << (W - (j + 1) * base_bit));
+        trlwe_to_flat(out + ((((size_t)i * t + j) * (base - 1)) + (v - 1)) * 2 * N, tmp);
+      }
+  free_trlwe(tmp);
+}
+
+static TRLWE_KS_Key trlwe_ks_header(void *dev, int entry, int owner, int t, int base_bit) {
+  TRLWE_KS_Key res = (TRLWE_KS_Key)xmalloc(sizeof(*res));
+  res->s = NULL; res->base_bit = base_bit; res->t = t; res->k = 1;
+  res->device = dev; res->entry = entry; res->owner = owner;
+  return res;
+}
+
+TRLWE_KS_Key trlwe_new_KS_key(TRLWE_Key out_key, TRLWE_Key in_key, int t, int base_bit) {
+  const int N = out_key->s[0]->N;
+  if (out_key->k != 1 || in_key->k != 1) { fprintf(stderr, "mosfhet_amd: trlwe_new_KS_key: k = 1 only\n"); abort(); }
+  Torus *flat = (Torus *)xmalloc(sizeof(Torus) * (size_t)t * 2 * N);
+  mosfhet_gen_trlwe_ks_key_flat(flat, in_key->s[0]->coeffs, out_key, t, base_bit);
+  mosfhet_hip_gak_t dev = NULL;
+  if (mosfhet_hip_trlwe_ksk_create((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, flat, 1, N, t, base_bit)) die("trlwe_new_KS_key");
+  free(flat);
+  return trlwe_ks_header(dev, 0, 1, t, base_bit);
+}
+
+TRLWE_KS_Key *trlwe_new_priv_KS_key(TRLWE_Key out_key, TRLWE_Key in_key, int t, int base_bit) {
+  const int N = out_key->s[0]->N;
+  if (out_key->k != 1 || in_key->k != 1) { fprintf(stderr, "mosfhet_amd: trlwe_new_priv_KS_key: k = 1 only\n"); abort(); }
+  Torus *flat = (Torus *)xmalloc(sizeof(Torus) * (size_t)2 * t * 2 * N);
+  mosfhet_gen_priv_ks_key_flat(flat, out_key, in_key, t, base_bit);
+  mosfhet_hip_gak_t dev = NULL;
+  if (mosfhet_hip_trlwe_ksk_create((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, flat, 2, N, t, base_bit)) die("trlwe_new_priv_KS_key");
+  free(flat);
+  TRLWE_KS_Key *res = (TRLWE_KS_Key *)xmalloc(sizeof(TRLWE_KS_Key) * 2);
+  res[0] = trlwe_ks_header(dev, 0, 1, t, base_bit);   /* entry 0 owns the shared device key set */
+  res[1] = trlwe_ks_header(dev, 1, 0, t, base_bit);
+  return res;
+}
+
+void free_trlwe_ks_key(TRLWE_KS_Key key) {
+  if (!key) return;
+  if (key->owner) mosfhet_hip_gak_destroy((mosfhet_hip_gak_t)key->device);
+  free(key);
+}
+
+static void trlwe_ks_run(int mode, TRLWE out, TRLWE in, TRLWE_KS_Key key) {
+  mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
+  const int N = in->b->N;
+  const size_t w = (size_t)2 * N;
+  Torus *h = (Torus *)xmalloc(sizeof(Torus) * w);
+  trlwe_to_flat(h, in);
+  Torus *d = (Torus *)dev_alloc(sizeof(Torus) * 2 * w);
+  dev_copy(d, h, sizeof(Torus) * w, HIP_H2D);
+  int rc = mode ? mosfhet_hip_trlwe_priv_keyswitch_2_batch(ctx, (mosfhet_hip_gak_t)key->device, d + w, d, 1, NULL)
+                : mosfhet_hip_trlwe_keyswitch_batch(ctx, (mosfhet_hip_gak_t)key->device, key->entry, d + w, d, 1, NULL);
+  if (rc || mosfhet_hip_ctx_sync(ctx, NULL)) die(mode ? "trlwe_priv_keyswitch_2" : "trlwe_keyswitch");
+  dev_copy(h, d + w, sizeof(Torus) * w, HIP_D2H);
+  trlwe_from_flat(out, h);
+  hipFree(d);
+  free(h);
+}
+
+void trlwe_keyswitch(TRLWE out, TRLWE in, TRLWE_KS_Key ks_key) { trlwe_ks_run(0, out, in, ks_key); }
+void trlwe_priv_keyswitch_2(TRLWE out, TRLWE in, TRLWE_KS_Key *ks_key) { trlwe_ks_run(1, out, in, ks_key[0]); }
+
+Generic_KS_Key trlwe_new_packing1_KS_key(TRLWE_Key out_key, TLWE_Key in_key, int t, int base_bit) {
+  const int N = out_key->s[0]->N, base = 1 << base_bit;
+  if (out_key->k != 1) { fprintf(stderr, "mosfhet_amd: trlwe_new_packing1_KS_key: k = 1 only\n"); abort(); }
+  Generic_KS_Key res = (Generic_KS_Key)xmalloc(sizeof(*res));
+  res->s = NULL; res->base_bit = base_bit; res->t = t; res->n = in_key->n; res->include_b = 0;
+  Torus *flat = (Torus *)xmalloc(sizeof(Torus) * (size_t)in_key->n * t * (base - 1) * 2 * N);
+  mosfhet_gen_packing1_ks_key_flat(flat, out_key, in_key, t, base_bit);
+  mosfhet_hip_ksk_t dev = NULL;
+  if (mosfhet_hip_packing1_ksk_create((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, flat, in_key->n, N, t, base_bit)) die("trlwe_new_packing1_KS_key");
+  free(flat);
+  res->device = dev;
+  return res;
+}
+
+void free_trlwe_generic_ks_key(Generic_KS_Key key) {
+  if (!key) return;
+  mosfhet_hip_ksk_destroy((mosfhet_hip_ksk_t)key->device);
+  free(key);
+}
+
+void trlwe_packing1_keyswitch(TRLWE out, TLWE in, Generic_KS_Key ks) {
+  mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
+  const int N = out->b->N, n = ks->n;
+  const size_t in_w = (size_t)n + 1, out_w = (size_t)2 * N;
+  Torus *h = (Torus *)xmalloc(sizeof(Torus) * (in_w + out_w));
+  tlwe_array_to_flat(h, &in, 1, n);
+  Torus *d = (Torus *)dev_alloc(sizeof(Torus) * (in_w + out_w));
+  dev_copy(d, h, sizeof(Torus) * in_w, HIP_H2D);
+  if (mosfhet_hip_trlwe_packing1_keyswitch_batch(ctx, (mosfhet_hip_ksk_t)ks->device, d + in_w, d, 1, NULL) || mosfhet_hip_ctx_sync(ctx, NULL))
+    die("trlwe_packing1_keyswitch");
+  dev_copy(h + in_w, d + in_w, sizeof(Torus) * out_w, HIP_D2H);
+  trlwe_from_flat(out, h + in_w);
+  hipFree(d);
+  free(h);
+}
+
+void circuit_bootstrap_3_batch(TRGSW *out, TLWE *in, int count, Bootstrap_Key key, TRLWE_KS_Key *kska, Generic_KS_Key kskb) {
+  mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
+  const int n = key->n, N = key->N, l = key->l;
+  const size_t in_w = (size_t)count * (n + 1), row = (size_t)2 * N, out_w = (size_t)count * 2 * l * row;
+  Torus *h = (Torus *)xmalloc(sizeof(Torus) * (in_w + out_w));
+  tlwe_array_to_flat(h, in, count, n);
+  Torus *d = (Torus *)dev_alloc(sizeof(Torus) * (in_w + out_w));
+  dev_copy(d, h, sizeof(Torus) * in_w, HIP_H2D);
+  if (mosfhet_hip_circuit_bootstrap_3_batch(ctx, (mosfhet_hip_bsk_t)key->s[0], (mosfhet_hip_gak_t)kska[0]->device, (mosfhet_hip_ksk_t)kskb->device,
+                                            d + in_w, d, count, NULL) ||
+      mosfhet_hip_ctx_sync(ctx, NULL))
+    die("circuit_bootstrap_3");
+  dev_copy(h + in_w, d + in_w, sizeof(Torus) * out_w, HIP_D2H);
+  for (int b = 0; b < count; b++)
+    for (int q = 0; q < 2 * l; q++) trlwe_from_flat(out[b]->samples[q], h + in_w + ((size_t)b * 2 * l + q) * row);
+  hipFree(d);
+  free(h);
+}
+
+void circuit_bootstrap_3(TRGSW out, TLWE in, Bootstrap_Key key, TRLWE_KS_Key *kska, Generic_KS_Key kskb) {
+  circuit_bootstrap_3_batch(&out, &in, 1, key, kska, kskb);
+}

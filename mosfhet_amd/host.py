@@ -147,3 +147,21 @@ def gen_automorphism_keyset(rlwe_key, t, base_bit):
     L.mosfhet_gen_automorphism_keyset_flat.argtypes = [C.c_void_p, C.POINTER(_TRLWEKey), C.c_int, C.c_int]
     L.mosfhet_gen_automorphism_keyset_flat(out.ctypes.data_as(C.c_void_p), rlwe_key.p, t, base_bit)
     return out
+
+
+def gen_priv_ks_key(out_key, in_key, t, base_bit):
+    """trlwe_new_priv_KS_key (src/keyswitch.c:39-50) as u64[2][t][2][N]: entry 0 from -s_out*s_in, entry 1 from -s_out."""
+    L = _lib()
+    out = np.empty((2, t, 2, out_key.N), dtype=np.uint64)
+    L.mosfhet_gen_priv_ks_key_flat.argtypes = [C.c_void_p, C.POINTER(_TRLWEKey), C.POINTER(_TRLWEKey), C.c_int, C.c_int]
+    L.mosfhet_gen_priv_ks_key_flat(out.ctypes.data_as(C.c_void_p), out_key.p, in_key.p, t, base_bit)
+    return out
+
+
+def gen_packing1_ks_key(out_key, in_key, t, base_bit):
+    """trlwe_new_packing1_KS_key (src/keyswitch.c:368-390), rows uncompressed: u64[n][t][2^bb-1][2][N]."""
+    L = _lib()
+    out = np.empty((in_key.n, t, (1 << base_bit) - 1, 2, out_key.N), dtype=np.uint64)
+    L.mosfhet_gen_packing1_ks_key_flat.argtypes = [C.c_void_p, C.POINTER(_TRLWEKey), C.POINTER(_TLWEKey), C.c_int, C.c_int]
+    L.mosfhet_gen_packing1_ks_key_flat(out.ctypes.data_as(C.c_void_p), out_key.p, in_key.p, t, base_bit)
+    return out

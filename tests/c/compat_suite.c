@@ -1,0 +1,231 @@
+/*
+ * GPU test of the MOSFHET-compatible C API (include/mosfhet_compat.h): a plain C program written the way a
+ * mosfhet.h caller is (cf. the reference's test/tests.c cases named per function below), linked against
+ * libmosfhet_hip.so only.  Every case decrypts with the secret keys and applies the reference test's own tolerance.
+ * Run by tests/test_gpu_parity.py::test_compat_c_api_suite; exit status = number of failed cases.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "mosfhet_compat.h"
+
+static int failures = 0;
+static uint64_t tdist(Torus a, Torus b) {
+  int64_t d = (int64_t)(a - b);
+  return (uint64_t)(d < 0 ? -d : d);
+}
+#define CHECK(cond, ...) do { if (!(cond)) { failures++; printf("FAIL %s:%d: ", __func__, __LINE__); printf(__VA_ARGS__); printf("\n"); } } while (0)
+#define WITHIN(tol, want, got, what) CHECK(tdist((want), (got)) < (tol), "%s: want %016llx got %016llx", what, (unsigned long long)(want), (unsigned long long)(got))
+
+/* SET_1 of test/benchmark.c:53-54 with a shortened LWE key so that the suite runs in seconds */
+enum { n = 96, N = 1024, k = 1, l = 2, Bg_bit = 8, ks_t = 5, ks_bb = 2 };
+static const double lwe_sigma = 9.1418e-5 / 4, rlwe_sigma = 2.989e-8;
+
+static TLWE_Key lwe_key, extracted_key;
+static TRLWE_Key rlwe_key;
+static TRGSW_Key trgsw_key;
+static Bootstrap_Key bk;
+
+/* test_functional_bootstrap (test/tests.c:1446-1480): m = j/8 on a 4-slot LUT, tolerance 2^58 */
+static void case_functional_bootstrap(void) {
+  Torus lut[4] = {int2torus(1, 4), int2torus(5, 4), int2torus(9, 4), int2torus(13, 4)};
+  TRLWE tv = trlwe_alloc_new_sample(k, N);
+  trlwe_torus_packing(tv, lut, 4);
+  TLWE out = tlwe_alloc_sample(N);
+  for (int j = 0; j < 4; j++) {
+    TLWE in = tlwe_new_sample(double2torus(j / 8.), lwe_key);
+    functional_bootstrap(out, tv, in, bk, 4);
+    WITHIN(1ULL << 58, lut[j], tlwe_phase(out, extracted_key), "functional_bootstrap");
+    free_tlwe(in);
+  }
+  /* wo_extract + host sample extract is the same ciphertext */
+  TLWE in = tlwe_new_sample(double2torus(2 / 8.), lwe_key);
+  TRLWE acc = trlwe_alloc_new_sample(k, N);
+  TLWE out2 = tlwe_alloc_sample(N);
+  functional_bootstrap(out, tv, in, bk, 4);
+  functional_bootstrap_wo_extract(acc, tv, in, bk, 4);
+  trlwe_extract_tlwe(out2, acc, 0);
+  CHECK(out->b == out2->b && !memcmp(out->a, out2->a, sizeof(Torus) * N), "wo_extract + extract differs from functional_bootstrap");
+  free_tlwe(in); free_tlwe(out); free_tlwe(out2); free_trlwe(acc); free_trlwe(tv);
+}
+
+/* test_programmable_bootstrap (test/tests.c:1483-1520): precision 3, messages on the half torus; batch entry point too */
+static void case_programmable_bootstrap(void) {
+  enum { COUNT = 70 };
+  Torus lut[4] = {int2torus(3, 4), int2torus(7, 4), int2torus(11, 4), int2torus(15, 4)};
+  TRLWE tv = trlwe_alloc_new_sample(k, N);
+  trlwe_torus_packing(tv, lut, 4);
+  TLWE *in = tlwe_alloc_sample_array(COUNT, n), *out = tlwe_alloc_sample_array(COUNT, N);
+  for (int i = 0; i < COUNT; i++) tlwe_sample(in[i], double2torus((i % 4) / 8.), lwe_key);
+  programmable_bootstrap_batch(out, tv, in, COUNT, bk, 3, 0, 0);
+  for (int i = 0; i < COUNT; i++) WITHIN(1ULL << 58, lut[i % 4], tlwe_phase(out[i], extracted_key), "programmable_bootstrap_batch");
+  TLWE one = tlwe_alloc_sample(N);
+  programmable_bootstrap(one, tv, in[5], bk, 3, 0, 0);
+  CHECK(one->b == out[5]->b && !memcmp(one->a, out[5]->a, sizeof(Torus) * N), "single call differs from the batch entry");
+  free_tlwe(one); free_tlwe_array(in, COUNT); free_tlwe_array(out, COUNT); free_trlwe(tv);
+}
+
+/* blind_rotate with the reference's signature (src/bootstrap.c:107-122): the caller rotates the test vector by the body
+ * itself (as functional_bootstrap_wo_extract does, :192-198), then blind_rotate + sample extract == functional_bootstrap */
+static void case_blind_rotate(void) {
+  Torus lut[4] = {int2torus(2, 4), int2torus(6, 4), int2torus(10, 4), int2torus(14, 4)};
+  TRLWE tv = trlwe_alloc_new_sample(k, N), acc = trlwe_alloc_new_sample(k, N);
+  trlwe_torus_packing(tv, lut, 4);
+  TLWE in = tlwe_new_sample(double2torus(1 / 8.), lwe_key);
+  /* acc = tv * X^(2N - b~) on the host, then blind_rotate, then extract == functional_bootstrap */
+  const int log2N = 11;
+  const uint64_t bt = torus2int(in->b + double2torus(1. / 16), log2N), rot = (2 * N - bt) & (2 * N - 1);
+  for (int j = 0; j < N; j++) {
+    const uint64_t idx = j + rot;
+    acc->a[0]->coeffs[idx & (N - 1)] = 0;
+    acc->b->coeffs[idx & (N - 1)] = (idx & N) ? (Torus)0 - tv->b->coeffs[j] : tv->b->coeffs[j];
+  }
+  blind_rotate(acc, in->a, bk->s, n);   /* takes the raw mask: the mod switch is inside (src/bootstrap.c:113) */
+  TLWE got = tlwe_alloc_sample(N), want = tlwe_alloc_sample(N);
+  trlwe_extract_tlwe(got, acc, 0);
+  functional_bootstrap(want, tv, in, bk, 4);
+  CHECK(got->b == want->b && !memcmp(got->a, want->a, sizeof(Torus) * N), "blind_rotate + extract differs from functional_bootstrap");
+  WITHIN(1ULL << 58, lut[1], tlwe_phase(got, extracted_key), "blind_rotate");
+  free_tlwe(in); free_tlwe(got); free_tlwe(want); free_trlwe(tv); free_trlwe(acc);
+}
+
+/* test_tlwe_ks (test/tests.c:751-790): N -> n key switch; SET_1's t * base_bit = 10 bits leaves ~2^57 of rounding noise
+ * (the set "should fail most tests", test/tests.c:39), hence 2^60 here */
+static void case_tlwe_keyswitch(void) {
+  enum { COUNT = 33 };
+  TLWE_KS_Key ksk = tlwe_new_KS_key(lwe_key, extracted_key, ks_t, ks_bb);
+  TLWE *in = tlwe_alloc_sample_array(COUNT, N), *out = tlwe_alloc_sample_array(COUNT, n);
+  for (int i = 0; i < COUNT; i++) tlwe_sample(in[i], double2torus((i % 8) / 8.), extracted_key);
+  tlwe_keyswitch_batch(out, in, COUNT, ksk);
+  for (int i = 0; i < COUNT; i++) WITHIN(1ULL << 60, double2torus((i % 8) / 8.), tlwe_phase(out[i], lwe_key), "tlwe_keyswitch_batch");
+  TLWE one = tlwe_alloc_sample(n);
+  tlwe_keyswitch(one, in[3], ksk);
+  CHECK(one->b == out[3]->b && !memcmp(one->a, out[3]->a, sizeof(Torus) * n), "single key switch differs from the batch entry");
+  /* test_FDFB_new (test/tests.c:1095-1127): messages i/8 on the WHOLE torus, LUT packed as 2 interleaved tables of 4 */
+  Torus lut[8];
+  for (int i = 0; i < 8; i++) lut[i] = int2torus((uint64_t)((3 * i + 1) & 7), 3);
+  TRLWE tv = trlwe_alloc_new_sample(k, N);
+  trlwe_torus_packing_many_LUT(tv, lut, 4, 2);
+  TLWE fout = tlwe_alloc_sample(N);
+  for (int m = 0; m < 8; m++) {
+    TLWE c = tlwe_new_sample(int2torus((uint64_t)m, 3), lwe_key);
+    full_domain_functional_bootstrap(fout, tv, c, bk, ksk, 3);
+    WITHIN(1ULL << 59, lut[m], tlwe_phase(fout, extracted_key), "full_domain_functional_bootstrap");
+    free_tlwe(c);
+  }
+  free_tlwe(fout); free_trlwe(tv); free_tlwe(one);
+  free_tlwe_array(in, COUNT); free_tlwe_array(out, COUNT); free_tlwe_ks_key(ksk);
+}
+
+/* test_multivalue_bootstrap_CLOT21 (test/tests.c:931-963): several LUTs evaluated with ONE blind rotation */
+static void case_multivalue(void) {
+  enum { LUTS = 4, SLOTS = 4 };
+  Torus lut[LUTS * SLOTS];
+  for (int j = 0; j < LUTS; j++)
+    for (int i = 0; i < SLOTS; i++) lut[j * SLOTS + i] = int2torus((uint64_t)((5 * j + 3 * i + 1) & 15), 4);
+  TRLWE tv = trlwe_alloc_new_sample(k, N);
+  trlwe_torus_packing_many_LUT(tv, lut, SLOTS, LUTS);
+  TLWE *out = tlwe_alloc_sample_array(LUTS, N);
+  for (int m = 0; m < SLOTS; m++) {
+    TLWE in = tlwe_new_sample(double2torus(m / 8.), lwe_key);
+    multivalue_bootstrap_CLOT21(out, tv, in, bk, SLOTS, LUTS);
+    for (int j = 0; j < LUTS; j++) WITHIN(1ULL << 58, lut[j * SLOTS + m], tlwe_phase(out[j], extracted_key), "multivalue_bootstrap_CLOT21");
+    free_tlwe(in);
+  }
+  free_tlwe_array(out, LUTS); free_trlwe(tv);
+}
+
+/* test_functional_bootstrap_ga (test/tests.c:1615-1650) */
+static void case_bootstrap_ga(void) {
+  enum { n_ga = 32 };  /* short key: the forced-odd mask drift of blind_rotate_ga grows with n */
+  TLWE_Key key = tlwe_new_binary_key(n_ga, lwe_sigma);
+  Bootstrap_GA_Key gk = new_bootstrap_key_ga(trgsw_key, key);
+  Torus lut[4] = {int2torus(1, 4), int2torus(5, 4), int2torus(9, 4), int2torus(13, 4)};
+  TRLWE tv = trlwe_alloc_new_sample(k, N);
+  trlwe_torus_packing(tv, lut, 4);
+  TLWE out = tlwe_alloc_sample(N);
+  for (int j = 0; j < 4; j++) {
+    TLWE in = tlwe_new_sample(double2torus(j / 8.), key);
+    functional_bootstrap_ga(out, tv, in, gk, 4);
+    WITHIN(1ULL << 58, lut[j], tlwe_phase(out, extracted_key), "functional_bootstrap_ga");
+    free_tlwe(in);
+  }
+  free_tlwe(out); free_trlwe(tv); free_bootstrap_key_ga(gk); free_tlwe_key(key);
+}
+
+/* test_circuit_bootstrap (test/tests.c:965-1022) + test_trlwe_pack_key_priv_ks (:893-925), gadget l=4 Bg=2^9 */
+static void case_circuit_bootstrap(void) {
+  enum { cl = 4, cBg = 9 };
+  /* the l = 4, Bg = 2^9 gadget belongs to the 2^-44 noise level of the reference's lvl2 set (test/tests.c:24-33) */
+  TRLWE_Key ckey = trlwe_new_binary_key(N, k, 5.684341886080802e-14);
+  TLWE_Key ckey_extracted = tlwe_alloc_key(N, ckey->sigma);
+  trlwe_extract_tlwe_key(ckey_extracted, ckey);
+  TRGSW_Key gkey = trgsw_new_key(ckey, cl, cBg);
+  Bootstrap_Key cbk = new_bootstrap_key(gkey, lwe_key, 1);
+  TRLWE_KS_Key *kska = trlwe_new_priv_KS_key(ckey, ckey, 20, 2);
+  Generic_KS_Key kskb = trlwe_new_packing1_KS_key(ckey, ckey_extracted, 12, 2);
+  TorusPolynomial ph = polynomial_new_torus_polynomial(N), msg = polynomial_new_torus_polynomial(N);
+  /* private key switch: TRLWE(m) -> TRLWE(-s m), tolerance 2^52 */
+  TRLWE c = trlwe_alloc_new_sample(k, N), c2 = trlwe_alloc_new_sample(k, N);
+  memset(msg->coeffs, 0, sizeof(Torus) * N);
+  msg->coeffs[0] = double2torus(0.125);
+  trlwe_sample(c, msg, ckey);
+  trlwe_priv_keyswitch_2(c2, c, kska);
+  trlwe_phase(ph, c2, ckey);
+  for (int i = 0; i < N; i++) WITHIN(1ULL << 52, (Torus)0 - ckey->s[0]->coeffs[i] * msg->coeffs[0], ph->coeffs[i], "trlwe_priv_keyswitch_2");
+  /* packing key switch: LWE(1/8) under the extracted key -> TRLWE with the message in coefficient 0 */
+  TLWE lw = tlwe_new_sample(double2torus(0.125), ckey_extracted);
+  trlwe_packing1_keyswitch(c2, lw, kskb);
+  trlwe_phase(ph, c2, ckey);
+  WITHIN(1ULL << 58, double2torus(0.125), ph->coeffs[0], "trlwe_packing1_keyswitch coefficient 0");
+  for (int i = 1; i < N; i++) WITHIN(1ULL << 58, (Torus)0, ph->coeffs[i], "trlwe_packing1_keyswitch");
+  /* LWE(1/4) -> TRGSW(1), LWE(0) -> TRGSW(0): every row decrypts to m * gadget on its component (first two levels;
+   * the 24-bit packing key switch leaves ~2^44 of rounding noise, the private one multiplies it by the key) */
+  TRGSW out[2] = {trgsw_alloc_new_sample(cl, cBg, k, N), trgsw_alloc_new_sample(cl, cBg, k, N)};
+  TLWE in[2] = {tlwe_new_sample(double2torus(0.25), lwe_key), tlwe_new_sample(0, lwe_key)};
+  circuit_bootstrap_3_batch(out, in, 2, cbk, kska, kskb);
+  for (int b = 0; b < 2; b++) {
+    const Torus m = b == 0 ? 1 : 0;
+    for (int i = 0; i < 2; i++) {
+      const Torus h = m << (64 - (i + 1) * cBg);
+      trlwe_phase(ph, out[b]->samples[cl + i], ckey);                /* b rows: m h on X^0 */
+      WITHIN(1ULL << 48, h, ph->coeffs[0], "circuit_bootstrap_3 b row");
+      for (int j = 1; j < N; j++) WITHIN(1ULL << 48, (Torus)0, ph->coeffs[j], "circuit_bootstrap_3 b row tail");
+      trlwe_phase(ph, out[b]->samples[i], ckey);                     /* a rows: -s m h */
+      for (int j = 0; j < N; j++) WITHIN(1ULL << 52, (Torus)0 - ckey->s[0]->coeffs[j] * h, ph->coeffs[j], "circuit_bootstrap_3 a row");
+    }
+  }
+  TRGSW single = trgsw_alloc_new_sample(cl, cBg, k, N);
+  circuit_bootstrap_3(single, in[0], cbk, kska, kskb);
+  for (int q = 0; q < 2 * cl; q++)
+    CHECK(!memcmp(single->samples[q]->b->coeffs, out[0]->samples[q]->b->coeffs, sizeof(Torus) * N) &&
+          !memcmp(single->samples[q]->a[0]->coeffs, out[0]->samples[q]->a[0]->coeffs, sizeof(Torus) * N), "single circuit bootstrap differs from the batch entry, row %d", q);
+  free_trgsw(single); free_trgsw(out[0]); free_trgsw(out[1]); free_tlwe(in[0]); free_tlwe(in[1]); free_tlwe(lw);
+  free_trlwe(c); free_trlwe(c2); free_polynomial(ph); free_polynomial(msg);
+  free_trlwe_generic_ks_key(kskb); free_trlwe_ks_key(kska[0]); free_trlwe_ks_key(kska[1]); free(kska);
+  free_bootstrap_key(cbk); free_trgsw_key(gkey); free_tlwe_key(ckey_extracted); free_trlwe_key(ckey);
+}
+
+int main(int argc, char **argv) {
+  mosfhet_seed(0x4D4F5346);
+  lwe_key = tlwe_new_binary_key(n, lwe_sigma);
+  rlwe_key = trlwe_new_binary_key(N, k, rlwe_sigma);
+  trgsw_key = trgsw_new_key(rlwe_key, l, Bg_bit);
+  extracted_key = tlwe_alloc_key(N, rlwe_sigma);
+  trlwe_extract_tlwe_key(extracted_key, rlwe_key);
+  bk = new_bootstrap_key(trgsw_key, lwe_key, 1);
+  struct { const char *name; void (*fn)(void); } cases[] = {
+    {"functional_bootstrap", case_functional_bootstrap}, {"programmable_bootstrap", case_programmable_bootstrap},
+    {"blind_rotate", case_blind_rotate},                 {"tlwe_keyswitch+fdfb", case_tlwe_keyswitch},
+    {"multivalue", case_multivalue},                     {"bootstrap_ga", case_bootstrap_ga},
+    {"circuit_bootstrap", case_circuit_bootstrap},
+  };
+  for (unsigned i = 0; i < sizeof(cases) / sizeof(cases[0]); i++) {
+    if (argc > 1 && strcmp(argv[1], cases[i].name)) continue;
+    const int before = failures;
+    cases[i].fn();
+    printf("%-24s %s\n", cases[i].name, failures == before ? "ok" : "FAILED");
+  }
+  free_bootstrap_key(bk); free_trgsw_key(trgsw_key); free_trlwe_key(rlwe_key); free_tlwe_key(lwe_key); free_tlwe_key(extracted_key);
+  return failures > 255 ? 255 : failures;
+}

@@ -98,3 +98,39 @@ def test_host_keygen_decrypts_under_the_oracle(native_lib, oracle):
     # seeded generator is reproducible
     host.seed(42)
     assert (host.LweKey(n, 2.0 ** -30).s == lk.s).all()
+
+
+def test_host_circuit_bootstrap_keygen_matches_the_oracle_algorithm(native_lib, oracle):
+    """The host layer's private / packing key-switch keys (src/keyswitch.c:39-50,368-390) carry the messages the oracle's
+    key switches expect: fed to the ORACLE's trlwe_priv_keyswitch_2 / trlwe_packing1_keyswitch they give the right phases."""
+    from mosfhet_amd import host
+    host.seed(77)
+    N, sigma = 1024, 2.0 ** -44
+    rk = host.RlweKey(N, 1, sigma)
+    s = rk.s
+    ks = host.gen_priv_ks_key(rk, rk, 10, 3)
+    assert ks.shape == (2, 10, 2, N)
+    r = oracle.Rng(5)
+    msg = oracle.u64(r.words(N))
+    ct = oracle.trlwe_sample(r, msg, s, sigma)
+    out = oracle.trlwe_priv_keyswitch_2(ct, oracle.ks_to_dft(ks[0]), oracle.ks_to_dft(ks[1]), 10, 3)
+    want = oracle.poly_naive_mul(np.uint64(0) - s[0], msg)
+    assert oracle.torus_dist(oracle.trlwe_phase(out, s), want).max() < 2.0 ** 52
+    lk = host.LweKey(24, 2.0 ** -30)
+    pk = host.gen_packing1_ks_key(rk, lk, 6, 3)
+    assert pk.shape == (24, 6, 7, 2, N)
+    c = oracle.tlwe_sample(r, oracle.double2torus(0.125), lk.s, 2.0 ** -30)
+    ph = oracle.trlwe_phase(oracle.trlwe_packing1_keyswitch(c, pk, 3), s)
+    assert oracle.torus_dist(ph[0], oracle.double2torus(0.125)) < 2.0 ** 50
+    assert oracle.torus_dist(ph[1:], np.zeros(N - 1, dtype=np.uint64)).max() < 2.0 ** 50
+
+
+def test_compat_c_suite_compiles_and_links(native_lib, tmp_path):
+    """tests/c/compat_suite.c (a plain C mosfhet.h-style caller, run under -m gpu) builds against the header and library."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "mosfhet_amd")
+    subprocess.check_call(["gcc", "-O1", "-std=gnu11", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c", "compat_suite.c"), "-o", str(tmp_path / "compat_suite"),
+                           "-L" + libdir, "-lmosfhet_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
