@@ -138,6 +138,34 @@ void orc_gen_packing1_ks_key(orc_rng *r, Torus *ksk, const Torus *s_in /*[n]*/, 
 void orc_gen_priv_ks_key(orc_rng *r, Torus *ks0 /*[t][2][N]*/, Torus *ks1, const Torus *s_out, const Torus *s_in, int N, int t, int base_bit,
                          double sigma);                                                  /* keyswitch.c:39-50 */
 
+/* ---- callers either side of the bootstrap (oracle_ext.c; k = 1) ---- */
+void orc_public_mux(const orc_fft_plan *p, Torus *out /*[2][N]*/, const Torus *p0, const Torus *p1, const double *sel_dft /*[l][2][N]*/, int l,
+                    int Bg_bit);                                                          /* bootstrap.c:369-389 */
+void orc_full_domain_functional_bootstrap_KS21(const orc_fft_plan *p, Torus *out /*[N+1]*/, const Torus *tv /*[2N]*/, const Torus *in,
+                    const double *bk_dft, const Torus *ksk /*[N][t][2^bb-1][2][N]*/, int n, int l, int Bg_bit, int t, int base_bit, int torus_base,
+                    int variant /*0: _KS21, 1: _KS21_2*/);                                /* bootstrap.c:391-463 */
+void orc_multivalue_bootstrap_phase1(const orc_fft_plan *p, Torus *out /*[torus_base+1][2][N]*/, const Torus *in, const double *bk_dft, int n, int l,
+                    int Bg_bit, int torus_base);                                          /* bootstrap.c:232-243 */
+void orc_trlwe_mv_extract_tlwe_scaling_addto(Torus *out /*[N+1]*/, const Torus *in /*[2][N]*/, int N, int scale); /* trlwe.c:603-611 */
+void orc_multivalue_bootstrap_phase2(Torus *out /*[N+1]*/, const int *lut_in /*[torus_base]*/, const Torus *rotated_tv, int N, int torus_base,
+                    int log_torus_base);                                                  /* bootstrap.c:245-265 */
+void orc_gen_priv_sk_ks_key(orc_rng *r, Torus *ksk /*[n+1][t][2^bb-1][2][N]*/, const Torus *s_in, int n, const Torus *s_out, int N, int t,
+                    int base_bit, double sigma);                                          /* keyswitch.c:611-637 */
+void orc_trlwe_priv_keyswitch(Torus *out /*[2][N]*/, const Torus *in /*[n+1]*/, const Torus *ksk, int n, int N, int t, int base_bit); /* keyswitch.c:639-656 */
+void orc_circuit_bootstrap(const orc_fft_plan *p, Torus *out /*[2l][2][N]*/, const Torus *in, const double *bk_dft, const Torus *kska, int ta, int bba,
+                    const Torus *kskb, int tb, int bbb, int n, int l, int Bg_bit, int variant /*0: circuit_bootstrap, 1: _2*/); /* bootstrap.c:309-344 */
+void orc_functional_bootstrap_trgsw_phase1(const orc_fft_plan *p, double *out_dft /*[2l][2][N]*/, const Torus *in, const double *bk_dft, int n, int l,
+                    int Bg_bit, int torus_base);                                          /* bootstrap.c:267-295 */
+void orc_functional_bootstrap_trgsw_phase2(const orc_fft_plan *p, Torus *out /*[N+1]*/, const double *in_dft, const Torus *tv, int l, int Bg_bit); /* bootstrap.c:297-306 */
+void orc_gen_rl_key(orc_rng *r, Torus *ks /*[t][2][N]*/, const Torus *s, int N, int t, int base_bit, double sigma);   /* keyswitch.c:3-10 */
+void orc_trlwe_tensor_prod_fft(const orc_fft_plan *p, Torus *out, const Torus *in1, const Torus *in2, int precision, const double *rl_dft, int t,
+                    int base_bit);                                                        /* trlwe.c:727-771 */
+void orc_tlwe_mul(const orc_fft_plan *p, Torus *out /*[N+1]*/, const Torus *in1, const Torus *in2, int precision, const Torus *ksk, int tk, int bbk,
+                    const double *rl_dft, int tr, int bbr);                               /* tlwe.c:322-332 */
+void orc_full_domain_functional_bootstrap_CLOT21(const orc_fft_plan *p, Torus *out, const Torus *tv, const Torus *in, const double *bk_dft,
+                    const Torus *ksk, int tk, int bbk, const double *rl_dft, int tr, int bbr, int n, int l, int Bg_bit, int precision,
+                    int variant /*0: _CLOT21 (tv = [2][2][N]), 1: _CLOT21_2 (tv = 2^(precision-1) LUT words)*/); /* bootstrap.c:465-517 */
+
 /* ---- deterministic test-input generation (own code; the reference's RNG is RDRAND-seeded
  *      and not reproducible, src/misc.c:34-49) ---- */
 uint64_t orc_rng_next(orc_rng *r);                       /* splitmix64 */

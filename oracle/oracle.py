@@ -397,6 +397,108 @@ def gen_priv_ks_key(rng, s_out, s_in, t, base_bit, sigma):
     return ks0, ks1
 
 
+# ---------------- callers either side of the bootstrap (oracle_ext.c) ----------------
+def public_mux(p0, p1, sel_dft, l, Bg_bit):
+    N = p0.size
+    out = np.empty((2, N), dtype=np.uint64)
+    lib().orc_public_mux(plan(N).h, _u(out), _u(p0), _u(p1), _d(sel_dft), l, Bg_bit)
+    return out
+
+
+def full_domain_functional_bootstrap_KS21(tv, c, bk_dft, ksk, base_bit, l, Bg_bit, torus_base, variant=0):
+    N = bk_dft.shape[-1]
+    out = np.empty(N + 1, dtype=np.uint64)
+    lib().orc_full_domain_functional_bootstrap_KS21(plan(N).h, _u(out), _u(tv), _u(c), _d(bk_dft), _u(ksk), C.c_int(c.size - 1), l, Bg_bit,
+                                                    C.c_int(ksk.shape[1]), base_bit, torus_base, variant)
+    return out
+
+
+def multivalue_bootstrap_phase1(c, bk_dft, l, Bg_bit, torus_base):
+    N = bk_dft.shape[-1]
+    out = np.empty((torus_base + 1, 2, N), dtype=np.uint64)
+    lib().orc_multivalue_bootstrap_phase1(plan(N).h, _u(out), _u(c), _d(bk_dft), C.c_int(c.size - 1), l, Bg_bit, torus_base)
+    return out
+
+
+def multivalue_bootstrap_phase2(lut_in, rotated, torus_base, log_torus_base):
+    N = rotated.shape[-1]
+    out = np.empty(N + 1, dtype=np.uint64)
+    li = np.ascontiguousarray(lut_in, dtype=np.int32)
+    lib().orc_multivalue_bootstrap_phase2(_u(out), li.ctypes.data_as(C.POINTER(C.c_int)), _u(rotated), N, torus_base, log_torus_base)
+    return out
+
+
+def trlwe_mv_extract_tlwe_scaling_addto(acc, c, scale):
+    out = acc.copy()
+    lib().orc_trlwe_mv_extract_tlwe_scaling_addto(_u(out), _u(c), C.c_int(c.shape[1]), scale)
+    return out
+
+
+def gen_priv_sk_ks_key(rng, s_in, s_out, t, base_bit, sigma):
+    n, N = s_in.size, s_out.size
+    ksk = np.empty((n + 1, t, (1 << base_bit) - 1, 2, N), dtype=np.uint64)
+    lib().orc_gen_priv_sk_ks_key(rng.ref(), _u(ksk), _u(s_in), n, _u(s_out), N, t, base_bit, C.c_double(sigma))
+    return ksk
+
+
+def trlwe_priv_keyswitch(c, ksk, base_bit):
+    n1, t, _, _, N = ksk.shape
+    out = np.empty((2, N), dtype=np.uint64)
+    lib().orc_trlwe_priv_keyswitch(_u(out), _u(c), _u(ksk), n1 - 1, N, t, base_bit)
+    return out
+
+
+def circuit_bootstrap(c, bk_dft, kska, bba, kskb, bbb, l, Bg_bit, variant=0):
+    N = bk_dft.shape[-1]
+    out = np.empty((2 * l, 2, N), dtype=np.uint64)
+    lib().orc_circuit_bootstrap(plan(N).h, _u(out), _u(c), _d(bk_dft), _u(kska), C.c_int(kska.shape[1]), bba, _u(kskb), C.c_int(kskb.shape[1]), bbb,
+                                C.c_int(c.size - 1), l, Bg_bit, variant)
+    return out
+
+
+def functional_bootstrap_trgsw_phase1(c, bk_dft, l, Bg_bit, torus_base):
+    N = bk_dft.shape[-1]
+    out = np.empty((2 * l, 2, N), dtype=np.float64)
+    lib().orc_functional_bootstrap_trgsw_phase1(plan(N).h, _d(out), _u(c), _d(bk_dft), C.c_int(c.size - 1), l, Bg_bit, torus_base)
+    return out
+
+
+def functional_bootstrap_trgsw_phase2(g_dft, tv, l, Bg_bit):
+    N = tv.shape[-1]
+    out = np.empty(N + 1, dtype=np.uint64)
+    lib().orc_functional_bootstrap_trgsw_phase2(plan(N).h, _u(out), _d(g_dft), _u(tv), l, Bg_bit)
+    return out
+
+
+def gen_rl_key(rng, s, t, base_bit, sigma):
+    N = s.size
+    ks = np.empty((t, 2, N), dtype=np.uint64)
+    lib().orc_gen_rl_key(rng.ref(), _u(ks), _u(s), N, t, base_bit, C.c_double(sigma))
+    return ks
+
+
+def trlwe_tensor_prod_fft(c1, c2, precision, rl_dft, base_bit):
+    N = c1.shape[1]
+    out = np.empty_like(c1)
+    lib().orc_trlwe_tensor_prod_fft(plan(N).h, _u(out), _u(c1), _u(c2), precision, _d(rl_dft), C.c_int(rl_dft.shape[0]), base_bit)
+    return out
+
+
+def tlwe_mul(c1, c2, precision, ksk, bbk, rl_dft, bbr):
+    N = c1.size - 1
+    out = np.empty(N + 1, dtype=np.uint64)
+    lib().orc_tlwe_mul(plan(N).h, _u(out), _u(c1), _u(c2), precision, _u(ksk), C.c_int(ksk.shape[1]), bbk, _d(rl_dft), C.c_int(rl_dft.shape[0]), bbr)
+    return out
+
+
+def full_domain_functional_bootstrap_CLOT21(tv, c, bk_dft, ksk, bbk, rl_dft, bbr, l, Bg_bit, precision, variant=0):
+    N = bk_dft.shape[-1]
+    out = np.empty(N + 1, dtype=np.uint64)
+    lib().orc_full_domain_functional_bootstrap_CLOT21(plan(N).h, _u(out), _u(tv), _u(c), _d(bk_dft), _u(ksk), C.c_int(ksk.shape[1]), bbk, _d(rl_dft),
+                                                      C.c_int(rl_dft.shape[0]), bbr, C.c_int(c.size - 1), l, Bg_bit, precision, variant)
+    return out
+
+
 # ---------------- deterministic inputs ----------------
 def gen_binary_key(rng, n):
     s = np.empty(n, dtype=np.uint64)

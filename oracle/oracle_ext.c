@@ -1,0 +1,311 @@
+/*
+ * oracle_ext.c -- the callers either side of the bootstrap:
+ * public_mux and the KS21 / CLOT21 full-domain bootstraps, multi-value phase 1/2, the table-lookup private key
+ * switch and circuit_bootstrap / _2, the TRGSW-accumulator bootstrap, the FFT tensor product and tlwe_mul.
+ * TEST INFRASTRUCTURE ONLY (see mosfhet_oracle.h).  k = 1 throughout.
+ */
+#include "mosfhet_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define W 64
+
+static int plan_N(const orc_fft_plan *p) {
+  int cnt = 0;
+  (void)orc_fft_twiddles(p, &cnt);
+  return 2 * (cnt + 1);
+}
+
+static Torus *talloc(size_t words) { return (Torus *)calloc(words ? words : 1, sizeof(Torus)); }
+
+/* src/bootstrap.c:369-389  public_mux: out = (0, p0) + sum_i selector[i] (.) DFT(dec_i(p1 - p0)), UN-rounded decomposition
+ * (polynomial_decompose, src/polynomial.c:55-72); accumulation order i = 0 .. l-1, a then b. */
+void orc_public_mux(const orc_fft_plan *p, Torus *out, const Torus *p0, const Torus *p1, const double *sel_dft, int l, int Bg_bit) {
+  const int N = plan_N(p);
+  Torus *d = talloc(N), *dec = talloc((size_t)l * N);
+  double *dd = (double *)malloc(sizeof(double) * (size_t)N), *acc = (double *)calloc((size_t)2 * N, sizeof(double));
+  for (int c = 0; c < N; c++) d[c] = p1[c] - p0[c];
+  orc_poly_decompose(dec, d, N, Bg_bit, l);
+  for (int i = 0; i < l; i++) {
+    orc_torus_to_dft(p, dd, dec + (size_t)i * N);
+    for (int c = 0; c < 2; c++) orc_dft_mul_addto(acc + (size_t)c * N, sel_dft + ((size_t)i * 2 + c) * N, dd, N);
+  }
+  for (int c = 0; c < 2; c++) orc_dft_to_torus(p, out + (size_t)c * N, acc + (size_t)c * N);
+  for (int c = 0; c < N; c++) out[N + c] += p0[c];
+  free(d); free(dec); free(dd); free(acc);
+}
+
+/* src/bootstrap.c:391-432 (variant 0, _KS21) and :434-463 (variant 1, _KS21_2).  tv has 2N coefficients. */
+void orc_full_domain_functional_bootstrap_KS21(const orc_fft_plan *p, Torus *out, const Torus *tv, const Torus *in, const double *bk_dft,
+                                               const Torus *ksk, int n, int l, int Bg_bit, int t, int base_bit, int torus_base, int variant) {
+  const int N = plan_N(p);
+  Torus *tmp_trlwe = talloc((size_t)2 * N), *tmp_trlwe2 = talloc((size_t)2 * N), *tmp = talloc((size_t)N + 1);
+  double *sign_dec = (double *)malloc(sizeof(double) * (size_t)l * 2 * N);
+  if (variant == 0) {
+    const int slot_size = N / (l * torus_base / 2);
+    Torus *lut = talloc((size_t)l * torus_base / 2);
+    for (int i = 0; i < l; i++)
+      for (int j = 0; j < torus_base / 2; j++) lut[i * torus_base / 2 + j] = (Torus)-1 << (W - (i + 1) * Bg_bit - 1);
+    orc_trlwe_torus_packing_many_LUT(tmp_trlwe, lut, 1, N, torus_base / 2, l);
+    orc_functional_bootstrap_wo_extract(p, tmp_trlwe2, tmp_trlwe, in, bk_dft, n, 1, l, Bg_bit, l * torus_base / 2);
+    for (int i = 0; i < l; i++) {
+      const Torus sign = (Torus)-1 << (W - (i + 1) * Bg_bit - 1);
+      orc_trlwe_extract_tlwe(tmp, tmp_trlwe2, 1, N, i * slot_size);
+      tmp[N] -= sign;
+      orc_trlwe_packing1_keyswitch(tmp_trlwe, tmp, ksk, N, N, t, base_bit);
+      for (int c = 0; c < 2; c++) orc_torus_to_dft(p, sign_dec + ((size_t)i * 2 + c) * N, tmp_trlwe + (size_t)c * N);
+    }
+    free(lut);
+  } else {
+    for (int i = 0; i < l; i++) {
+      const Torus sign = (Torus)-1 << (W - (i + 1) * Bg_bit - 1);
+      orc_trlwe_torus_packing(tmp_trlwe, &sign, 1, N, 1);
+      orc_functional_bootstrap(p, tmp, tmp_trlwe, in, bk_dft, n, 1, l, Bg_bit, torus_base / 2);
+      tmp[N] -= sign;
+      orc_trlwe_packing1_keyswitch(tmp_trlwe, tmp, ksk, N, N, t, base_bit);
+      for (int c = 0; c < 2; c++) orc_torus_to_dft(p, sign_dec + ((size_t)i * 2 + c) * N, tmp_trlwe + (size_t)c * N);
+    }
+  }
+  Torus *p0 = talloc(N), *p1 = talloc(N);
+  for (int i = 0; i < N; i++) {
+    p0[i] = tv[i];
+    p1[i] = (Torus)0 - tv[i + N];
+  }
+  orc_public_mux(p, tmp_trlwe, p0, p1, sign_dec, l, Bg_bit);
+  orc_functional_bootstrap(p, out, tmp_trlwe, in, bk_dft, n, 1, l, Bg_bit, torus_base / 2);
+  free(tmp_trlwe); free(tmp_trlwe2); free(tmp); free(sign_dec); free(p0); free(p1);
+}
+
+/* src/bootstrap.c:232-243  multivalue_bootstrap_phase1: out[0] = BR of the constant vector 1/(4 torus_base);
+ * out[i] = out[0] X^(i N / torus_base); out[torus_base] = out[0] X^torus_base + out[0]. */
+void orc_multivalue_bootstrap_phase1(const orc_fft_plan *p, Torus *out, const Torus *in, const double *bk_dft, int n, int l, int Bg_bit,
+                                     int torus_base) {
+  const int N = plan_N(p);
+  const size_t sz = (size_t)2 * N;
+  Torus *tv = talloc(sz);
+  for (int i = 0; i < N; i++) tv[N + i] = orc_double2torus(1. / (4 * torus_base));
+  orc_functional_bootstrap_wo_extract(p, out, tv, in, bk_dft, n, 1, l, Bg_bit, torus_base);
+  for (int i = 1; i < torus_base; i++)
+    for (int c = 0; c < 2; c++) orc_poly_mul_by_xai(out + i * sz + (size_t)c * N, out + (size_t)c * N, N, i * N / torus_base);
+  for (int c = 0; c < 2; c++) {
+    Torus *dst = out + torus_base * sz + (size_t)c * N;
+    orc_poly_mul_by_xai(dst, out + (size_t)c * N, N, torus_base);
+    for (int i = 0; i < N; i++) dst[i] += out[(size_t)c * N + i];
+  }
+  free(tv);
+}
+
+/* src/trlwe.c:554-578  extract with += / -= */
+static void extract_acc(Torus *out, const Torus *in, int N, int idx, int sign) {
+  for (int j = 0; j <= idx; j++) out[j] += sign > 0 ? in[idx - j] : (Torus)0 - in[idx - j];
+  for (int j = idx + 1; j < N; j++) out[j] += sign > 0 ? (Torus)0 - in[N + idx - j] : in[N + idx - j];
+  out[N] += sign > 0 ? in[N + idx] : (Torus)0 - in[N + idx];
+}
+
+/* src/trlwe.c:603-611  trlwe_mv_extract_tlwe_scaling_addto */
+void orc_trlwe_mv_extract_tlwe_scaling_addto(Torus *out, const Torus *in, int N, int scale) {
+  const int amount = scale;
+  for (int i = amount / 2; i < amount; i++) extract_acc(out, in, N, N - 1 - (i - amount / 2), -1);
+  for (int i = 0; i < amount / 2; i++) extract_acc(out, in, N, i, +1);
+}
+
+/* src/bootstrap.c:245-265  multivalue_bootstrap_phase2: cleartext LUT `lut_in` (torus_base small integers) against the rotated
+ * accumulators of phase 1; bit j of the LUT selects signed sums of them, extracted with weight 2^j. */
+void orc_multivalue_bootstrap_phase2(Torus *out, const int *lut_in, const Torus *rotated_tv, int N, int torus_base, int log_torus_base) {
+  const size_t sz = (size_t)2 * N;
+  Torus *tmp = talloc(sz);
+  memset(out, 0, sizeof(Torus) * ((size_t)N + 1));
+  for (int j = 0; j < log_torus_base; j++) {
+    const int in_over_tv_0 = ((lut_in[0] >> j) & 1) + ((lut_in[torus_base - 1] >> j) & 1);
+    if (in_over_tv_0 == 2) memcpy(tmp, rotated_tv + torus_base * sz, sizeof(Torus) * sz);
+    else if (in_over_tv_0 == 1) memcpy(tmp, rotated_tv, sizeof(Torus) * sz);
+    else memset(tmp, 0, sizeof(Torus) * sz);
+    for (int i = 1; i < torus_base; i++) {
+      const int d = ((lut_in[i] >> j) & 1) - ((lut_in[i - 1] >> j) & 1);
+      if (d == 1) for (size_t c = 0; c < sz; c++) tmp[c] += rotated_tv[i * sz + c];
+      else if (d == -1) for (size_t c = 0; c < sz; c++) tmp[c] -= rotated_tv[i * sz + c];
+    }
+    orc_trlwe_mv_extract_tlwe_scaling_addto(out, tmp, N, 1 << j);
+  }
+  free(tmp);
+}
+
+/* src/keyswitch.c:611-637  trlwe_new_priv_SK_KS_key_N2: entries i <= n (i = n stands for the b word, key -1),
+ * s[i][j][v-1] = TRLWE( -s_out * s_i v 2^(64-(j+1)bb) ), rows uncompressed. */
+void orc_gen_priv_sk_ks_key(orc_rng *r, Torus *ksk, const Torus *s_in, int n, const Torus *s_out, int N, int t, int base_bit, double sigma) {
+  const int base = 1 << base_bit;
+  const size_t row = (size_t)2 * N;
+  for (int i = 0; i <= n; i++) {
+    const Torus s_i = i < n ? s_in[i] : (Torus)-1;
+    for (int j = 0; j < t; j++)
+      for (int v = 1; v < base; v++) {
+        Torus *dst = ksk + (((size_t)i * t + j) * (base - 1) + (v - 1)) * row;
+        const Torus dec_key = s_i * (Torus)v * ((Torus)1 << (W - (j + 1) * base_bit));
+        orc_trlwe_sample(r, dst, NULL, s_out, 1, N, sigma);
+        for (int e = 0; e < N; e++) dst[N + e] += ((Torus)0 - s_out[e]) * dec_key;
+      }
+  }
+}
+
+/* src/keyswitch.c:639-656  trlwe_priv_keyswitch: LWE(m) under s_in -> TRLWE(-s_out m); the b word is digit-decomposed too. */
+void orc_trlwe_priv_keyswitch(Torus *out, const Torus *in, const Torus *ksk, int n, int N, int t, int base_bit) {
+  const Torus prec_offset = (Torus)1 << (W - (1 + base_bit * t));
+  const Torus mask = ((Torus)1 << base_bit) - 1;
+  const int base = 1 << base_bit;
+  const size_t row = (size_t)2 * N;
+  memset(out, 0, sizeof(Torus) * row);
+  for (int i = 0; i <= n; i++) {
+    const Torus aibar = in[i] + prec_offset;   /* in[n] is the b word */
+    for (int j = 0; j < t; j++) {
+      const Torus aij = (aibar >> (W - (j + 1) * base_bit)) & mask;
+      if (aij != 0) {
+        const Torus *src = ksk + (((size_t)i * t + j) * (base - 1) + (aij - 1)) * row;
+        for (size_t c = 0; c < row; c++) out[c] -= src[c];
+      }
+    }
+  }
+}
+
+/* src/bootstrap.c:309-322 (variant 0, circuit_bootstrap) and :324-344 (variant 1, circuit_bootstrap_2) */
+void orc_circuit_bootstrap(const orc_fft_plan *p, Torus *out, const Torus *in, const double *bk_dft, const Torus *kska, int ta, int bba,
+                           const Torus *kskb, int tb, int bbb, int n, int l, int Bg_bit, int variant) {
+  const int N = plan_N(p);
+  const size_t row = (size_t)2 * N;
+  Torus *tv = talloc(row), *tmp = talloc(row), *tmp_out = talloc((size_t)N + 1);
+  if (variant == 0) {
+    for (int i = 0; i < l; i++) {
+      const Torus lut[2] = {0, (Torus)1 << (W - (i + 1) * Bg_bit)};
+      orc_trlwe_torus_packing(tv, lut, 1, N, 2);
+      orc_functional_bootstrap(p, tmp_out, tv, in, bk_dft, n, 1, l, Bg_bit, 2);
+      orc_trlwe_priv_keyswitch(out + (size_t)i * row, tmp_out, kska, N, N, ta, bba);
+      orc_trlwe_packing1_keyswitch(out + (size_t)(l + i) * row, tmp_out, kskb, N, N, tb, bbb);
+    }
+  } else {
+    const int slot_size = N / (2 * l);
+    Torus *lut = talloc((size_t)2 * l);
+    for (int i = 0; i < l; i++) lut[l + i] = (Torus)1 << (W - (i + 1) * Bg_bit);
+    orc_trlwe_torus_packing(tv, lut, 1, N, 2 * l);
+    orc_functional_bootstrap_wo_extract(p, tmp, tv, in, bk_dft, n, 1, l, Bg_bit, 2 * l);
+    for (int i = 0; i < l; i++) {
+      orc_trlwe_extract_tlwe(tmp_out, tmp, 1, N, i * slot_size);
+      orc_trlwe_priv_keyswitch(out + (size_t)i * row, tmp_out, kska, N, N, ta, bba);
+      orc_trlwe_packing1_keyswitch(out + (size_t)(l + i) * row, tmp_out, kskb, N, N, tb, bbb);
+    }
+    free(lut);
+  }
+  free(tv); free(tmp); free(tmp_out);
+}
+
+/* src/bootstrap.c:267-295  functional_bootstrap_trgsw_phase1: blind rotation with a TRGSW accumulator.  trgsw_mul_DFT is the
+ * row-wise external product (src/trgsw.c:425-431), so every one of the 2l rows of the trivial TRGSW(1) is rotated independently. */
+void orc_functional_bootstrap_trgsw_phase1(const orc_fft_plan *p, double *out_dft, const Torus *in, const double *bk_dft, int n, int l,
+                                           int Bg_bit, int torus_base) {
+  const int N = plan_N(p);
+  int log_N2 = 0;
+  while ((1 << log_N2) < 2 * N) log_N2++;
+  const size_t row = (size_t)2 * N;
+  Torus *tv = talloc(row), *acc = talloc((size_t)2 * l * row);
+  const int rot = 2 * N - (int)orc_torus2int(in[n] + orc_double2torus(1. / (4 * torus_base)), log_N2);
+  for (int q = 0; q < 2 * l; q++) {
+    memset(tv, 0, sizeof(Torus) * row);
+    tv[(size_t)(q / l) * N] = (Torus)1 << (W - (q % l + 1) * Bg_bit);   /* rows < l: gadget on a; rows >= l: on b (src/trgsw.c:130-142) */
+    for (int c = 0; c < 2; c++) orc_poly_mul_by_xai(acc + q * row + (size_t)c * N, tv + (size_t)c * N, N, rot);
+    orc_blind_rotate(p, acc + q * row, in, bk_dft, n, 1, l, Bg_bit);
+  }
+  orc_trgsw_to_dft(p, out_dft, acc, 1, l);
+  free(tv); free(acc);
+}
+
+/* src/bootstrap.c:297-306  phase 2: tv (.) TRGSW_DFT(X^-phase), sample extract at 0 */
+void orc_functional_bootstrap_trgsw_phase2(const orc_fft_plan *p, Torus *out, const double *in_dft, const Torus *tv, int l, int Bg_bit) {
+  const int N = plan_N(p);
+  Torus *tmp = talloc((size_t)2 * N);
+  orc_external_product(p, tmp, tv, in_dft, 1, l, Bg_bit);
+  orc_trlwe_extract_tlwe(out, tmp, 1, N, 0);
+  free(tmp);
+}
+
+/* src/keyswitch.c:3-10  trlwe_new_RL_key: switches from s^2 to s */
+void orc_gen_rl_key(orc_rng *r, Torus *ks, const Torus *s, int N, int t, int base_bit, double sigma) {
+  Torus *s2 = talloc(N);
+  orc_poly_naive_mul(s2, s, s, N);
+  orc_gen_trlwe_ks_key(r, ks, s2, s, N, t, base_bit, sigma);
+  free(s2);
+}
+
+/* src/trlwe.c:727-771  trlwe_tensor_prod_FFT: operands are rescaled to (64 - precision)/2-ish bits (polynomial_torus_scale =
+ * torus2int, src/polynomial.c:322-326), multiplied in the DFT domain, the s^2 term is relinearised with rl_key. */
+void orc_trlwe_tensor_prod_fft(const orc_fft_plan *p, Torus *out, const Torus *in1, const Torus *in2, int precision, const double *rl_dft,
+                               int t, int base_bit) {
+  const int N = plan_N(p);
+  const int half_prec1 = W - (W - precision) / 2, half_prec2 = W - (W - precision + 1) / 2;
+  Torus *tmp = talloc(N), *t2 = talloc((size_t)2 * N), *res = talloc((size_t)2 * N);
+  double *A1 = (double *)malloc(sizeof(double) * (size_t)6 * N), *A2 = A1 + N, *B1 = A2 + N, *B2 = B1 + N, *tmp_dft = B2 + N, *ta = tmp_dft + N;
+  for (int i = 0; i < N; i++) tmp[i] = orc_torus2int(in1[i], half_prec1);
+  orc_torus_to_dft(p, A1, tmp);
+  for (int i = 0; i < N; i++) tmp[i] = orc_torus2int(in2[i], half_prec2);
+  orc_torus_to_dft(p, A2, tmp);
+  orc_dft_mul(ta, A1, A2, N);
+  for (int i = 0; i < N; i++) tmp[i] = orc_torus2int(in1[N + i], half_prec1);
+  orc_torus_to_dft(p, B1, tmp);
+  for (int i = 0; i < N; i++) tmp[i] = orc_torus2int(in2[N + i], half_prec2);
+  orc_torus_to_dft(p, B2, tmp);
+  orc_dft_mul(tmp_dft, A1, B2, N);
+  orc_dft_mul_addto(tmp_dft, B1, A2, N);
+  orc_dft_to_torus(p, res, tmp_dft);
+  orc_dft_mul(tmp_dft, B1, B2, N);
+  orc_dft_to_torus(p, res + N, tmp_dft);
+  orc_dft_to_torus(p, t2, ta);           /* t = (A1 A2, 0) */
+  memset(t2 + N, 0, sizeof(Torus) * (size_t)N);
+  orc_trlwe_keyswitch(p, t2, t2, rl_dft, t, base_bit);
+  for (int i = 0; i < 2 * N; i++) out[i] = res[i] - t2[i];
+  free(tmp); free(t2); free(res); free(A1);
+}
+
+/* src/tlwe.c:322-332  tlwe_mul: pack both operands, tensor product, extract coefficient 0 */
+void orc_tlwe_mul(const orc_fft_plan *p, Torus *out, const Torus *in1, const Torus *in2, int precision, const Torus *ksk, int tk, int bbk,
+                  const double *rl_dft, int tr, int bbr) {
+  const int N = plan_N(p);
+  Torus *tmp1 = talloc((size_t)2 * N), *tmp2 = talloc((size_t)2 * N);
+  orc_trlwe_packing1_keyswitch(tmp1, in1, ksk, N, N, tk, bbk);
+  orc_trlwe_packing1_keyswitch(tmp2, in2, ksk, N, N, tk, bbk);
+  orc_trlwe_tensor_prod_fft(p, tmp1, tmp1, tmp2, precision, rl_dft, tr, bbr);
+  orc_trlwe_extract_tlwe(out, tmp1, 1, N, 0);
+  free(tmp1); free(tmp2);
+}
+
+/* src/bootstrap.c:465-491 (variant 0, _CLOT21: tv = two test vectors [2][2][N]) and :493-517 (variant 1, _CLOT21_2: tv =
+ * 2 torus_base cleartext LUT words, torus_base = 2^(precision-2)) */
+void orc_full_domain_functional_bootstrap_CLOT21(const orc_fft_plan *p, Torus *out, const Torus *tv, const Torus *in, const double *bk_dft,
+                                                 const Torus *ksk, int tk, int bbk, const double *rl_dft, int tr, int bbr, int n, int l,
+                                                 int Bg_bit, int precision, int variant) {
+  const int N = plan_N(p);
+  const size_t row = (size_t)2 * N;
+  Torus *tmp_trlwe = talloc(row), *tmp_trlwe2 = talloc(row);
+  Torus *ct_sign = talloc((size_t)N + 1), *ct_f0 = talloc((size_t)N + 1), *ct_f1 = talloc((size_t)N + 1);
+  const Torus sign = (Torus)1 << (W - precision - 1);
+  if (variant == 0) {
+    orc_trlwe_torus_packing(tmp_trlwe, &sign, 1, N, 1);
+    orc_functional_bootstrap(p, ct_f0, tv, in, bk_dft, n, 1, l, Bg_bit, 1 << (precision - 1));
+    orc_functional_bootstrap(p, ct_f1, tv + row, in, bk_dft, n, 1, l, Bg_bit, 1 << (precision - 1));
+    orc_functional_bootstrap(p, ct_sign, tmp_trlwe, in, bk_dft, n, 1, l, Bg_bit, 1 << (precision - 1));
+  } else {
+    const int torus_base = 1 << (precision - 2), slot_size = N / (4 * torus_base);
+    Torus *lut = talloc((size_t)4 * torus_base);
+    memcpy(lut, tv, sizeof(Torus) * 2 * (size_t)torus_base);
+    for (int i = 2 * torus_base; i < 3 * torus_base; i++) lut[i] = sign;
+    orc_trlwe_torus_packing_many_LUT(tmp_trlwe, lut, 1, N, torus_base, 4);
+    orc_functional_bootstrap_wo_extract(p, tmp_trlwe2, tmp_trlwe, in, bk_dft, n, 1, l, Bg_bit, 4 * torus_base);
+    orc_trlwe_extract_tlwe(ct_f0, tmp_trlwe2, 1, N, 0);
+    orc_trlwe_extract_tlwe(ct_f1, tmp_trlwe2, 1, N, slot_size);
+    orc_trlwe_extract_tlwe(ct_sign, tmp_trlwe2, 1, N, 2 * slot_size);
+    free(lut);
+  }
+  ct_sign[N] -= sign;
+  orc_tlwe_mul(p, ct_f1, ct_f1, ct_sign, precision, ksk, tk, bbk, rl_dft, tr, bbr);
+  ct_sign[N] += 2 * sign;
+  orc_tlwe_mul(p, ct_f0, ct_f0, ct_sign, precision, ksk, tk, bbk, rl_dft, tr, bbr);
+  for (int i = 0; i <= N; i++) out[i] = ct_f0[i] + ct_f1[i];
+  free(tmp_trlwe); free(tmp_trlwe2); free(ct_sign); free(ct_f0); free(ct_f1);
+}

@@ -414,6 +414,198 @@ void ref_trlwe_priv_keyswitch_2(Torus *out, const Torus *in, const Torus *ks0_fl
   free_trlwe_ks_key(ks[1]);
 }
 
+/* ---------- callers either side of the bootstrap ----------
+ * Table-lookup TRLWE keys are made by the REFERENCE's own key generation from secret words we pass in, and exported to flat
+ * rows for the oracle: this library is built with USE_COMPRESSED_TRLWE, so a row is a seed + b; trlwe_compressed_subto
+ * (src/trlwe_compressed*.c) regenerates the mask, and 0 - (0 - row) is the row. */
+static TRLWE_Key trlwe_key_from_words(const Torus *s, int N, double sigma) {
+  TRLWE_Key key = trlwe_alloc_key(N, 1, sigma);
+  memcpy(key->s[0]->coeffs, s, sizeof(Torus) * N);
+  polynomial_torus_to_DFT(key->s_dft[0], key->s[0]);
+  return key;
+}
+
+static TLWE_Key tlwe_key_from_words(const Torus *s, int n, double sigma) {
+  TLWE_Key key = tlwe_alloc_key(n, sigma);
+  memcpy(key->s, s, sizeof(Torus) * n);
+  return key;
+}
+
+/* kind 0: trlwe_new_packing1_KS_key (keyswitch.c:368-390); kind 1: trlwe_new_priv_SK_KS_key_N2 (keyswitch.c:611-637) */
+void *ref_generic_key_new(int kind, const Torus *s_out, int N, const Torus *s_in, int n, int t, int base_bit, double sigma) {
+  TRLWE_Key ko = trlwe_key_from_words(s_out, N, sigma);
+  TLWE_Key ki = tlwe_key_from_words(s_in, n, sigma);
+  Generic_KS_Key res = kind == 0 ? trlwe_new_packing1_KS_key(ko, ki, t, base_bit) : trlwe_new_priv_SK_KS_key_N2(ko, ki, t, base_bit);
+  free_trlwe_key(ko);
+  free_tlwe_key(ki);
+  return res;
+}
+
+void ref_generic_key_free(void *h) { free_trlwe_generic_ks_key((Generic_KS_Key)h); }
+
+void ref_generic_key_export(void *h, Torus *flat, int N) {
+  Generic_KS_Key key = (Generic_KS_Key)h;
+  const int per_j = (1 << key->base_bit) - 1, entries = key->n + (key->include_b ? 1 : 0);
+  TRLWE tmp = trlwe_alloc_new_sample(1, N);
+  for (int i = 0; i < entries; i++)
+    for (int j = 0; j < key->t; j++)
+      for (int v = 0; v < per_j; v++) {
+        trlwe_noiseless_trivial_sample(tmp, NULL);
+        trlwe_compressed_subto(tmp, key->s[i][j][v]);
+        Torus *dst = flat + (((size_t)i * key->t + j) * per_j + v) * 2 * N;
+        for (int c = 0; c < N; c++) {
+          dst[c] = (Torus)0 - tmp->a[0]->coeffs[c];
+          dst[N + c] = (Torus)0 - tmp->b->coeffs[c];
+        }
+      }
+  free_trlwe(tmp);
+}
+
+/* kind 0: trlwe_packing1_keyswitch (keyswitch.c:458-475); kind 1: trlwe_priv_keyswitch (keyswitch.c:639-656) -- the library's own loops */
+void ref_generic_keyswitch(int kind, Torus *out, const Torus *in, void *h, int N) {
+  Generic_KS_Key key = (Generic_KS_Key)h;
+  TLWE c = tlwe_from_flat(in, key->n);
+  TRLWE o = trlwe_alloc_new_sample(1, N);
+  if (kind == 0) trlwe_packing1_keyswitch(o, c, key);
+  else trlwe_priv_keyswitch(o, c, key);
+  trlwe_to_flat(out, o, N);
+  free_tlwe(c);
+  free_trlwe(o);
+}
+
+void ref_public_mux(Torus *out, const Torus *p0, const Torus *p1, const Torus *sel_flat /*[l][2][N]*/, int N, int l, int Bg_bit) {
+  TRLWE_DFT *sel = trlwe_alloc_new_DFT_sample_array(l, 1, N);
+  for (int i = 0; i < l; i++) {
+    TRLWE tmp = trlwe_from_flat(sel_flat + (size_t)i * 2 * N, 1, N);
+    trlwe_to_DFT(sel[i], tmp);
+    free_trlwe(tmp);
+  }
+  TorusPolynomial q0 = poly_from_flat(p0, N), q1 = poly_from_flat(p1, N);
+  TRLWE o = trlwe_alloc_new_sample(1, N);
+  public_mux(o, q0, q1, sel, l, Bg_bit);
+  trlwe_to_flat(out, o, N);
+  free_trlwe(o);
+  free_polynomial(q0);
+  free_polynomial(q1);
+  free_trlwe_array(sel, l);
+}
+
+void ref_full_domain_functional_bootstrap_KS21(Torus *out, const Torus *tv /*[2N]*/, const Torus *in, void *bkh, void *kskh, int torus_base, int variant) {
+  Bootstrap_Key bk = (Bootstrap_Key)bkh;
+  TorusPolynomial t = poly_from_flat(tv, 2 * bk->N);
+  TLWE c = tlwe_from_flat(in, bk->n), o = tlwe_alloc_sample(bk->N);
+  if (variant == 0) full_domain_functional_bootstrap_KS21(o, t, c, bk, (Generic_KS_Key)kskh, torus_base);
+  else full_domain_functional_bootstrap_KS21_2(o, t, c, bk, (Generic_KS_Key)kskh, torus_base);
+  tlwe_to_flat(out, o);
+  free_polynomial(t);
+  free_tlwe(c);
+  free_tlwe(o);
+}
+
+void ref_multivalue_bootstrap_phase1(Torus *out /*[tb+1][2][N]*/, const Torus *in, void *bkh, int torus_base) {
+  Bootstrap_Key bk = (Bootstrap_Key)bkh;
+  TRLWE *o = trlwe_alloc_new_sample_array(torus_base + 1, 1, bk->N);
+  TLWE c = tlwe_from_flat(in, bk->n);
+  multivalue_bootstrap_phase1(o, c, bk, torus_base);
+  for (int i = 0; i <= torus_base; i++) trlwe_to_flat(out + (size_t)i * 2 * bk->N, o[i], bk->N);
+  free_tlwe(c);
+  free_trlwe_array(o, torus_base + 1);
+}
+
+void ref_multivalue_bootstrap_phase2(Torus *out, int *lut_in, const Torus *rotated /*[tb+1][2][N]*/, int N, int torus_base, int log_torus_base) {
+  TRLWE *r = (TRLWE *)safe_malloc(sizeof(TRLWE) * (torus_base + 1));
+  for (int i = 0; i <= torus_base; i++) r[i] = trlwe_from_flat(rotated + (size_t)i * 2 * N, 1, N);
+  TLWE o = tlwe_alloc_sample(N);
+  multivalue_bootstrap_phase2(o, lut_in, r, torus_base, log_torus_base);
+  tlwe_to_flat(out, o);
+  free_tlwe(o);
+  for (int i = 0; i <= torus_base; i++) free_trlwe(r[i]);
+  free(r);
+}
+
+/* variant 0: circuit_bootstrap, 1: circuit_bootstrap_2 (kska = priv SK key), 3: circuit_bootstrap_3 (kska_flat = [2][ta][2][N] rows) */
+void ref_circuit_bootstrap(Torus *out /*[2l][2][N]*/, const Torus *in, void *bkh, void *kskah, const Torus *kska_flat, int ta, int bba, void *kskbh,
+                           int variant) {
+  Bootstrap_Key bk = (Bootstrap_Key)bkh;
+  TRGSW o = trgsw_alloc_new_sample(bk->l, bk->Bg_bit, 1, bk->N);
+  TLWE c = tlwe_from_flat(in, bk->n);
+  if (variant == 0) circuit_bootstrap(o, c, bk, (Generic_KS_Key)kskah, (Generic_KS_Key)kskbh);
+  else if (variant == 1) circuit_bootstrap_2(o, c, bk, (Generic_KS_Key)kskah, (Generic_KS_Key)kskbh);
+  else {
+    TRLWE_KS_Key ks[2] = {trlwe_ks_from_flat(kska_flat, 1, bk->N, ta, bba), trlwe_ks_from_flat(kska_flat + (size_t)ta * 2 * bk->N, 1, bk->N, ta, bba)};
+    circuit_bootstrap_3(o, c, bk, ks, (Generic_KS_Key)kskbh);
+    free_trlwe_ks_key(ks[0]);
+    free_trlwe_ks_key(ks[1]);
+  }
+  for (int q = 0; q < 2 * bk->l; q++) trlwe_to_flat(out + (size_t)q * 2 * bk->N, o->samples[q], bk->N);
+  free_tlwe(c);
+  free_trgsw(o);
+}
+
+/* functional_bootstrap_trgsw_phase1 (+ trgsw_from_DFT so the accumulator can be compared in the torus domain) and phase2 */
+void ref_functional_bootstrap_trgsw(Torus *acc_out /*[2l][2][N] or NULL*/, Torus *out /*[N+1]*/, const Torus *tv, const Torus *in, void *bkh,
+                                    int torus_base) {
+  Bootstrap_Key bk = (Bootstrap_Key)bkh;
+  TRGSW_DFT g = trgsw_alloc_new_DFT_sample(bk->l, bk->Bg_bit, 1, bk->N);
+  TLWE c = tlwe_from_flat(in, bk->n), o = tlwe_alloc_sample(bk->N);
+  functional_bootstrap_trgsw_phase1(g, c, bk, torus_base);
+  if (acc_out) {
+    TRGSW gt = trgsw_alloc_new_sample(bk->l, bk->Bg_bit, 1, bk->N);
+    trgsw_from_DFT(gt, g);
+    for (int q = 0; q < 2 * bk->l; q++) trlwe_to_flat(acc_out + (size_t)q * 2 * bk->N, gt->samples[q], bk->N);
+    free_trgsw(gt);
+  }
+  TRLWE t = trlwe_from_flat(tv, 1, bk->N);
+  functional_bootstrap_trgsw_phase2(o, g, t);
+  tlwe_to_flat(out, o);
+  free_trlwe(t);
+  free_tlwe(c);
+  free_tlwe(o);
+  free_trgsw(g);
+}
+
+void ref_trlwe_tensor_prod_FFT(Torus *out, const Torus *in1, const Torus *in2, int precision, const Torus *rl_flat, int N, int t, int base_bit) {
+  TRLWE_KS_Key rl = trlwe_ks_from_flat(rl_flat, 1, N, t, base_bit);
+  TRLWE a = trlwe_from_flat(in1, 1, N), b = trlwe_from_flat(in2, 1, N), o = trlwe_alloc_new_sample(1, N);
+  trlwe_tensor_prod_FFT(o, a, b, precision, rl);
+  trlwe_to_flat(out, o, N);
+  free_trlwe(a);
+  free_trlwe(b);
+  free_trlwe(o);
+  free_trlwe_ks_key(rl);
+}
+
+void ref_tlwe_mul(Torus *out, const Torus *in1, const Torus *in2, int precision, void *kskh, const Torus *rl_flat, int N, int t, int base_bit) {
+  TRLWE_KS_Key rl = trlwe_ks_from_flat(rl_flat, 1, N, t, base_bit);
+  TLWE a = tlwe_from_flat(in1, N), b = tlwe_from_flat(in2, N), o = tlwe_alloc_sample(N);
+  tlwe_mul(o, a, b, precision, (Generic_KS_Key)kskh, rl);
+  tlwe_to_flat(out, o);
+  free_tlwe(a);
+  free_tlwe(b);
+  free_tlwe(o);
+  free_trlwe_ks_key(rl);
+}
+
+/* variant 0: full_domain_functional_bootstrap_CLOT21 (tv = two TRLWE test vectors [2][2][N]); 1: _CLOT21_2 (tv = 2^(precision-1) LUT words) */
+void ref_full_domain_functional_bootstrap_CLOT21(Torus *out, const Torus *tv, const Torus *in, void *bkh, void *kskh, const Torus *rl_flat, int t,
+                                                 int base_bit, int precision, int variant) {
+  Bootstrap_Key bk = (Bootstrap_Key)bkh;
+  TRLWE_KS_Key rl = trlwe_ks_from_flat(rl_flat, 1, bk->N, t, base_bit);
+  TLWE c = tlwe_from_flat(in, bk->n), o = tlwe_alloc_sample(bk->N);
+  if (variant == 0) {
+    TRLWE tvs[2] = {trlwe_from_flat(tv, 1, bk->N), trlwe_from_flat(tv + (size_t)2 * bk->N, 1, bk->N)};
+    full_domain_functional_bootstrap_CLOT21(o, tvs, c, bk, (Generic_KS_Key)kskh, rl, precision);
+    free_trlwe(tvs[0]);
+    free_trlwe(tvs[1]);
+  } else {
+    full_domain_functional_bootstrap_CLOT21_2(o, (Torus *)tv, c, bk, (Generic_KS_Key)kskh, rl, precision);
+  }
+  tlwe_to_flat(out, o);
+  free_tlwe(c);
+  free_tlwe(o);
+  free_trlwe_ks_key(rl);
+}
+
 /* ---------- CPU baseline: time `reps` reference programmable bootstraps on the calling thread.
  * Re-entrant across threads once ref_init(N) has run on the main thread (FFT processors are
  * __thread, src/polynomial.c:338-349). Returns elapsed seconds. ---------- */

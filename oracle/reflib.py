@@ -236,6 +236,78 @@ class Ref:
         self.l.ref_trlwe_priv_keyswitch_2(_u(out), _u(c), _u(ks0), _u(ks1), N, t, base_bit)
         return out
 
+    # ---- callers either side of the bootstrap; table-lookup keys are made by the reference's own key generation ----
+    def generic_key_new(self, kind, s_out, s_in, t, base_bit, sigma):
+        """kind 0: trlwe_new_packing1_KS_key, 1: trlwe_new_priv_SK_KS_key_N2.  Returns (handle, flat rows)."""
+        self.l.ref_generic_key_new.restype = C.c_void_p
+        N, n = s_out.size, s_in.size
+        h = C.c_void_p(self.l.ref_generic_key_new(kind, _u(s_out), N, _u(s_in), n, t, base_bit, C.c_double(sigma)))
+        flat = np.empty((n + kind, t, (1 << base_bit) - 1, 2, N), dtype=np.uint64)
+        self.l.ref_generic_key_export(h, _u(flat), N)
+        return h, flat
+
+    def generic_key_free(self, h):
+        self.l.ref_generic_key_free(h)
+
+    def generic_keyswitch(self, kind, c, h, N):
+        out = np.empty((2, N), dtype=np.uint64)
+        self.l.ref_generic_keyswitch(kind, _u(out), _u(c), h, N)
+        return out
+
+    def public_mux(self, p0, p1, sel, Bg_bit):
+        l, _, N = sel.shape
+        out = np.empty((2, N), dtype=np.uint64)
+        self.l.ref_public_mux(_u(out), _u(p0), _u(p1), _u(sel), N, l, Bg_bit)
+        return out
+
+    def full_domain_functional_bootstrap_KS21(self, tv, c, bkh, kskh, N, torus_base, variant=0):
+        out = np.empty(N + 1, dtype=np.uint64)
+        self.l.ref_full_domain_functional_bootstrap_KS21(_u(out), _u(tv), _u(c), bkh, kskh, torus_base, variant)
+        return out
+
+    def multivalue_bootstrap_phase1(self, c, bkh, N, torus_base):
+        out = np.empty((torus_base + 1, 2, N), dtype=np.uint64)
+        self.l.ref_multivalue_bootstrap_phase1(_u(out), _u(c), bkh, torus_base)
+        return out
+
+    def multivalue_bootstrap_phase2(self, lut_in, rotated, torus_base, log_torus_base):
+        N = rotated.shape[-1]
+        out = np.empty(N + 1, dtype=np.uint64)
+        li = np.ascontiguousarray(lut_in, dtype=np.int32)
+        self.l.ref_multivalue_bootstrap_phase2(_u(out), li.ctypes.data_as(C.POINTER(C.c_int)), _u(rotated), N, torus_base, log_torus_base)
+        return out
+
+    def circuit_bootstrap(self, c, bkh, l, N, kskah, kskbh, variant, kska_flat=None, bba=0):
+        out = np.empty((2 * l, 2, N), dtype=np.uint64)
+        ta = 0 if kska_flat is None else kska_flat.shape[1]
+        self.l.ref_circuit_bootstrap(_u(out), _u(c), bkh, kskah, None if kska_flat is None else _u(kska_flat), ta, bba, kskbh, variant)
+        return out
+
+    def functional_bootstrap_trgsw(self, tv, c, bkh, l, torus_base):
+        N = tv.shape[-1]
+        acc = np.empty((2 * l, 2, N), dtype=np.uint64)
+        out = np.empty(N + 1, dtype=np.uint64)
+        self.l.ref_functional_bootstrap_trgsw(_u(acc), _u(out), _u(tv), _u(c), bkh, torus_base)
+        return acc, out
+
+    def trlwe_tensor_prod_FFT(self, c1, c2, precision, rl, base_bit):
+        t, _, N = rl.shape
+        out = np.empty_like(c1)
+        self.l.ref_trlwe_tensor_prod_FFT(_u(out), _u(c1), _u(c2), precision, _u(rl), N, t, base_bit)
+        return out
+
+    def tlwe_mul(self, c1, c2, precision, kskh, rl, base_bit):
+        t, _, N = rl.shape
+        out = np.empty(N + 1, dtype=np.uint64)
+        self.l.ref_tlwe_mul(_u(out), _u(c1), _u(c2), precision, kskh, _u(rl), N, t, base_bit)
+        return out
+
+    def full_domain_functional_bootstrap_CLOT21(self, tv, c, bkh, kskh, rl, base_bit, precision, variant=0):
+        t, _, N = rl.shape
+        out = np.empty(N + 1, dtype=np.uint64)
+        self.l.ref_full_domain_functional_bootstrap_CLOT21(_u(out), _u(tv), _u(c), bkh, kskh, _u(rl), t, base_bit, precision, variant)
+        return out
+
     def bench_programmable_bootstrap(self, tv, c, h, precision, reps):
         """Seconds for `reps` programmable_bootstrap calls on the calling thread (GIL released)."""
         return self.l.ref_bench_programmable_bootstrap(_u(tv), _u(c), h, precision, reps)

@@ -175,3 +175,183 @@ def test_circuit_bootstrap_pieces(oracle, ref):
         assert (mine == ref.trlwe_packing1_keyswitch(c, kskb, 3)).all()
         ph = oracle.trlwe_phase(mine, s.reshape(1, N))
         assert oracle.torus_dist(ph[0], oracle.double2torus(m)) < 2.0 ** 58 and oracle.torus_dist(ph[1:], np.zeros(N - 1, dtype=np.uint64)).max() < 2.0 ** 58
+
+
+# ---------------- callers either side of the bootstrap (oracle_ext.c) ----------------
+@pytest.fixture(scope="module")
+def wide(oracle):
+    """Key material shared by the wider-path tests: N = 1024 ring, 40-word LWE key, gadget l = 3 / Bg = 2^10 at the 2^-44
+    noise level; packing and private table-lookup keys are produced by the REFERENCE's key generation (per backend)."""
+    rng = oracle.Rng(0x51DE)
+    N, n, l, Bg, sigma = 1024, 40, 3, 10, 2.0 ** -44
+    lwe_s = oracle.gen_binary_key(rng, n)
+    s = oracle.gen_binary_key(rng, N)
+    bk = oracle.gen_bootstrap_key(rng, lwe_s, s.reshape(1, N), l, Bg, sigma)
+    return dict(rng=rng, N=N, n=n, l=l, Bg=Bg, sigma=sigma, lwe_sigma=2.0 ** -22, lwe_s=lwe_s, s=s, bk=bk, bk_dft=oracle.bk_to_dft(bk, 1, l), per_ref={})
+
+
+def _ref_keys(wide, ref):
+    """Reference-made table-lookup keys (packing t=12 bb=2, private t=4 bb=3), exported to flat rows for the oracle."""
+    K = wide["per_ref"].get(ref.backend)
+    if K is None:
+        bkh = ref.bk_new(wide["bk"], 1, wide["l"], wide["Bg"])
+        pkh, pk = ref.generic_key_new(0, wide["s"], wide["s"], 12, 2, wide["sigma"])
+        skh, sk = ref.generic_key_new(1, wide["s"], wide["s"], 4, 3, wide["sigma"])
+        K = wide["per_ref"][ref.backend] = dict(bkh=bkh, pkh=pkh, pk=pk, skh=skh, sk=sk)
+    return K
+
+
+def test_reference_made_table_keys_and_their_key_switches(oracle, ref, wide):
+    """trlwe_packing1_keyswitch / trlwe_priv_keyswitch (src/keyswitch.c:458-475,639-656) -- the LIBRARY's loops on the library's
+    own (seed-compressed) keys vs the oracle on the exported rows: integer work, bit-exact.  Also checks the exported rows
+    decrypt to what the oracle's key generators encrypt."""
+    K, N, s, rng = _ref_keys(wide, ref), wide["N"], wide["s"], wide["rng"]
+    assert K["pk"].shape == (N, 12, 3, 2, N) and K["sk"].shape == (N + 1, 4, 7, 2, N)
+    for i, j, v in ((0, 0, 1), (5, 3, 3), (N - 1, 11, 2)):
+        ph = oracle.trlwe_phase(np.ascontiguousarray(K["pk"][i, j, v - 1]), s.reshape(1, N))
+        want = (int(s[i]) * v << (64 - (j + 1) * 2)) % 2 ** 64
+        assert oracle.torus_dist(ph[0], want) < 2.0 ** 30 and oracle.torus_dist(ph[1:], np.zeros(N - 1, dtype=np.uint64)).max() < 2.0 ** 30
+    for i, j, v in ((0, 0, 1), (7, 2, 5), (N, 3, 7)):
+        ph = oracle.trlwe_phase(np.ascontiguousarray(K["sk"][i, j, v - 1]), s.reshape(1, N))
+        s_i = int(s[i]) if i < N else 2 ** 64 - 1
+        dec = (s_i * v << (64 - (j + 1) * 3)) % 2 ** 64
+        want = (np.uint64(0) - s) * np.uint64(dec)
+        assert oracle.torus_dist(ph, want).max() < 2.0 ** 30
+    for m in (0.125, -0.3):
+        c = oracle.tlwe_sample(rng, oracle.double2torus(m), s, wide["sigma"])
+        assert (ref.generic_keyswitch(0, c, K["pkh"], N) == oracle.trlwe_packing1_keyswitch(c, K["pk"], 2)).all()
+        mine = oracle.trlwe_priv_keyswitch(c, K["sk"], 3)
+        assert (ref.generic_keyswitch(1, c, K["skh"], N) == mine).all()
+        want = (np.uint64(0) - s) * np.uint64(oracle.double2torus(m))
+        assert oracle.torus_dist(oracle.trlwe_phase(mine, s.reshape(1, N)), want).max() < 2.0 ** 58
+    # the oracle's own generator of the private key encrypts the same messages
+    sk2 = oracle.gen_priv_sk_ks_key(rng, s[:6].copy(), s, 2, 2, wide["sigma"])
+    ph = oracle.trlwe_phase(np.ascontiguousarray(sk2[6, 1, 2]), s.reshape(1, N))
+    assert oracle.torus_dist(ph, (np.uint64(0) - s) * np.uint64(((2 ** 64 - 1) * 3 << 60) % 2 ** 64)).max() < 2.0 ** 30
+
+
+def test_public_mux_and_fdfb_KS21(oracle, ref, wide):
+    """public_mux (src/bootstrap.c:369-389) and full_domain_functional_bootstrap_KS21 / _KS21_2 (:391-463) vs the reference."""
+    K, N, l, Bg, rng, s = _ref_keys(wide, ref), wide["N"], wide["l"], wide["Bg"], wide["rng"], wide["s"]
+    p0, p1 = oracle.u64(rng.words(N)), oracle.u64(rng.words(N))
+    sel = np.stack([oracle.trlwe_sample(rng, None, s.reshape(1, N), wide["sigma"]) for _ in range(l)])
+    for i in range(l):
+        sel[i, 1, 0] += np.uint64(1 << (64 - (i + 1) * Bg))      # selector = gadget encryption of 1 -> picks p1
+    mine = oracle.public_mux(p0, p1, oracle.ks_to_dft(sel), l, Bg)
+    assert oracle.torus_dist(mine, ref.public_mux(p0, p1, sel, Bg)).max() < 2.0 ** 34
+    assert oracle.torus_dist(oracle.trlwe_phase(mine, s.reshape(1, N)), p1).max() < 2.0 ** 40
+    lut = oracle.u64(rng.words(8))
+    tv = np.repeat(lut, 2 * N // 8)
+    for variant in (0, 1):
+        for i in (0, 3, 5, 7):
+            c = oracle.tlwe_sample(rng, (i << 61) % 2 ** 64, wide["lwe_s"], wide["lwe_sigma"])
+            mine = oracle.full_domain_functional_bootstrap_KS21(tv, c, wide["bk_dft"], K["pk"], 2, l, Bg, 8, variant)
+            theirs = ref.full_domain_functional_bootstrap_KS21(tv, c, K["bkh"], K["pkh"], N, 8, variant)
+            # test_FDFB_KS21 (test/tests.c:1058-1092): phase within 2^58 of in[i]
+            assert oracle.torus_dist(oracle.tlwe_phase(mine, s), lut[i]) < 2.0 ** 58, (variant, i)
+            assert oracle.torus_dist(oracle.tlwe_phase(theirs, s), lut[i]) < 2.0 ** 58, (variant, i)
+            assert oracle.torus_dist(oracle.tlwe_phase(mine, s), oracle.tlwe_phase(theirs, s)) < 2.0 ** 54, (variant, i)
+
+
+def test_multivalue_phases(oracle, ref, wide):
+    """multivalue_bootstrap_phase1 / phase2 (src/bootstrap.c:232-265) vs the reference; phase 2 is integer work: bit-exact
+    on the same rotated accumulators."""
+    K, N, l, Bg, rng, s = _ref_keys(wide, ref), wide["N"], wide["l"], wide["Bg"], wide["rng"], wide["s"]
+    tb, log_tb = 4, 2
+    for m in range(4):
+        c = oracle.tlwe_sample(rng, oracle.double2torus(m / 8.0), wide["lwe_s"], wide["lwe_sigma"])
+        mine = oracle.multivalue_bootstrap_phase1(c, wide["bk_dft"], l, Bg, tb)
+        theirs = ref.multivalue_bootstrap_phase1(c, K["bkh"], N, tb)
+        # the constant test vector puts coefficients exactly on digit-rounding ties, so the two FFTs pick different (equally
+        # valid) decompositions and the masks diverge completely: compare by phase
+        ph_m, ph_t = (np.stack([oracle.trlwe_phase(np.ascontiguousarray(x[i]), s.reshape(1, N)) for i in range(tb + 1)]) for x in (mine, theirs))
+        assert oracle.torus_dist(ph_m, ph_t).max() < 2.0 ** 46
+        for lut_in in ([0, 1, 2, 3], [3, 1, 0, 2], [1, 1, 1, 1]):
+            out = oracle.multivalue_bootstrap_phase2(lut_in, theirs, tb, log_tb)
+            assert (out == ref.multivalue_bootstrap_phase2(lut_in, theirs, tb, log_tb)).all()
+    acc = oracle.u64(rng.words(N + 1))
+    c2 = oracle.u64(rng.words(2 * N)).reshape(2, N)
+    for scale in (1, 2, 4, 8):
+        assert oracle.trlwe_mv_extract_tlwe_scaling_addto(acc, c2, scale).shape == (N + 1,)
+
+
+def test_circuit_bootstrap_variants(oracle, ref, wide):
+    """circuit_bootstrap / _2 (src/bootstrap.c:309-344, table-lookup private key switch) and _3 as a whole vs the reference."""
+    K, N, l, Bg, rng, s = _ref_keys(wide, ref), wide["N"], wide["l"], wide["Bg"], wide["rng"], wide["s"]
+    ks0, ks1 = oracle.gen_priv_ks_key(rng, s, s, 10, 3, wide["sigma"])
+    kska3 = np.stack([ks0, ks1])
+    for m in (0.25, 0.0):
+        c = oracle.tlwe_sample(rng, oracle.double2torus(m), wide["lwe_s"], wide["lwe_sigma"])
+        outs = {}
+        for variant in (0, 1):
+            mine = oracle.circuit_bootstrap(c, wide["bk_dft"], K["sk"], 3, K["pk"], 2, l, Bg, variant)
+            theirs = ref.circuit_bootstrap(c, K["bkh"], l, N, K["skh"], K["pkh"], variant)
+            outs[variant] = (mine, theirs)
+        mine = oracle.circuit_bootstrap_3(c, wide["bk_dft"], oracle.ks_to_dft(ks0), oracle.ks_to_dft(ks1), 3, K["pk"], 2, l, Bg)
+        outs[3] = (mine, ref.circuit_bootstrap(c, K["bkh"], l, N, None, K["pkh"], 3, kska_flat=kska3, bba=3))
+        for variant, (mine, theirs) in outs.items():
+            for q in range(2 * l):
+                ph_m = oracle.trlwe_phase(np.ascontiguousarray(mine[q]), s.reshape(1, N))
+                ph_t = oracle.trlwe_phase(np.ascontiguousarray(theirs[q]), s.reshape(1, N))
+                h = np.uint64((1 << (64 - (q % l + 1) * Bg)) if m else 0)
+                want = np.zeros(N, dtype=np.uint64)
+                if q >= l:
+                    want[0] = h
+                else:
+                    want = (np.uint64(0) - s) * h
+                tol = 2.0 ** 50 if q >= l else 2.0 ** 56     # 24 / 12-bit key-switch rounding; the private switch multiplies by s
+                assert oracle.torus_dist(ph_m, want).max() < tol, (variant, q)
+                assert oracle.torus_dist(ph_t, want).max() < tol, (variant, q)
+
+
+def test_trgsw_accumulator_bootstrap(oracle, ref, wide):
+    """functional_bootstrap_trgsw_phase1 / phase2 (src/bootstrap.c:267-306)."""
+    K, N, l, Bg, rng, s = _ref_keys(wide, ref), wide["N"], wide["l"], wide["Bg"], wide["rng"], wide["s"]
+    lut = oracle.u64(rng.words(4))
+    tv = oracle.trlwe_torus_packing(lut, 1, N)
+    for m in range(4):
+        c = oracle.tlwe_sample(rng, oracle.double2torus(m / 8.0), wide["lwe_s"], wide["lwe_sigma"])
+        g_dft = oracle.functional_bootstrap_trgsw_phase1(c, wide["bk_dft"], l, Bg, 4)
+        mine = oracle.functional_bootstrap_trgsw_phase2(g_dft, tv, l, Bg)
+        acc_t, theirs = ref.functional_bootstrap_trgsw(tv, c, K["bkh"], l, 4)
+        acc_m = np.stack([oracle.dft_to_torus(np.ascontiguousarray(g_dft[q, cc])) for q in range(2 * l) for cc in range(2)]).reshape(2 * l, 2, N)
+        ph_m = np.stack([oracle.trlwe_phase(np.ascontiguousarray(acc_m[q]), s.reshape(1, N)) for q in range(2 * l)])
+        ph_t = np.stack([oracle.trlwe_phase(np.ascontiguousarray(acc_t[q]), s.reshape(1, N)) for q in range(2 * l)])
+        assert oracle.torus_dist(ph_m, ph_t).max() < 2.0 ** 46
+        assert oracle.torus_dist(oracle.tlwe_phase(mine, s), lut[m]) < 2.0 ** 58
+        assert oracle.torus_dist(oracle.tlwe_phase(theirs, s), lut[m]) < 2.0 ** 58
+        # phase 2 multiplies the accumulator's noise (agreeing to 2^46 above) by the digits of a random 64-bit LUT
+        assert oracle.torus_dist(oracle.tlwe_phase(mine, s), oracle.tlwe_phase(theirs, s)) < 2.0 ** 58
+
+
+def test_tensor_product_tlwe_mul_and_fdfb_CLOT21(oracle, ref, wide):
+    """trlwe_tensor_prod_FFT (src/trlwe.c:727-771), tlwe_mul (src/tlwe.c:322-332), full_domain_functional_bootstrap_CLOT21 / _2
+    (src/bootstrap.c:465-517), parameters of test_FDFB_CLOT21_2 (test/tests.c:1179-1218): relinearisation key t=2, bb=20, precision 4."""
+    K, N, l, Bg, rng, s = _ref_keys(wide, ref), wide["N"], wide["l"], wide["Bg"], wide["rng"], wide["s"]
+    rl = oracle.gen_rl_key(rng, s, 2, 20, wide["sigma"])
+    rl_dft = oracle.ks_to_dft(rl)
+    precision = 4
+    m1 = np.zeros(N, dtype=np.uint64); m2 = np.zeros(N, dtype=np.uint64)
+    m1[0], m2[0] = 3 << 60, 2 << 60
+    c1, c2 = (oracle.trlwe_sample(rng, m, s.reshape(1, N), wide["sigma"]) for m in (m1, m2))
+    mine = oracle.trlwe_tensor_prod_fft(c1, c2, precision, rl_dft, 20)
+    theirs = ref.trlwe_tensor_prod_FFT(c1, c2, precision, rl, 20)
+    ph_m, ph_t = oracle.trlwe_phase(mine, s.reshape(1, N)), oracle.trlwe_phase(theirs, s.reshape(1, N))
+    assert oracle.torus_dist(ph_m, ph_t).max() < 2.0 ** 56
+    assert oracle.torus_dist(ph_m[0], (6 << 60) % 2 ** 64) < 2.0 ** 58       # 3/16 * 2/16 * 2^precision = 6/16
+    t1 = oracle.tlwe_sample(rng, 3 << 60, s, wide["sigma"])
+    t2 = oracle.tlwe_sample(rng, 2 << 60, s, wide["sigma"])
+    mine = oracle.tlwe_mul(t1, t2, precision, K["pk"], 2, rl_dft, 20)
+    theirs = ref.tlwe_mul(t1, t2, precision, K["pkh"], rl, 20)
+    assert oracle.torus_dist(oracle.tlwe_phase(mine, s), oracle.tlwe_phase(theirs, s)) < 2.0 ** 57
+    assert oracle.torus_dist(oracle.tlwe_phase(mine, s), (6 << 60) % 2 ** 64) < 2.0 ** 58
+    lut = oracle.u64([(int(x) & 15) << 60 for x in rng.words(8)])
+    tvs = np.stack([oracle.trlwe_torus_packing(lut[:4], 1, N), oracle.trlwe_torus_packing(lut[4:], 1, N)])
+    for i in (0, 2, 5, 7):
+        c = oracle.tlwe_sample(rng, (i << 61) % 2 ** 64, wide["lwe_s"], wide["lwe_sigma"])
+        for variant, tv in ((0, tvs), (1, lut)):
+            mine = oracle.full_domain_functional_bootstrap_CLOT21(tv, c, wide["bk_dft"], K["pk"], 2, rl_dft, 20, l, Bg, precision, variant)
+            theirs = ref.full_domain_functional_bootstrap_CLOT21(tv, c, K["bkh"], K["pkh"], rl, 20, precision, variant)
+            tol = 2.0 ** (64 - precision - 1)       # the reference test's own bound (test/tests.c:1207)
+            assert oracle.torus_dist(oracle.tlwe_phase(mine, s), lut[i]) < tol, (variant, i)
+            assert oracle.torus_dist(oracle.tlwe_phase(theirs, s), lut[i]) < tol, (variant, i)
