@@ -180,6 +180,17 @@ int mosfhet_hip_circuit_bootstrap_3_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk
                                           uint64_t *d_out /*[count][2l][2][N]*/, const uint64_t *d_in /*[count][n+1]*/, int count,
                                           void *stream);
 
+/* ---- callers either side of the bootstrap ---- */
+/* public_mux over a batch (src/bootstrap.c:369-389): d_out[b] = (0, p0) + sum_i sel[b][i] * dec_i(p1 - p0); selector rows are
+ * torus-domain TRLWEs [count][l][2][N] (the reference takes TRLWE_DFT; the transform is fused); p0, p1 shared by the batch. */
+int mosfhet_hip_public_mux_batch(mosfhet_hip_ctx_t ctx, uint64_t *d_out /*[count][2][N]*/, const uint64_t *d_p0 /*[N]*/, const uint64_t *d_p1,
+                                 const uint64_t *d_sel, int N, int l, int Bg_bit, int count, void *stream);
+/* full_domain_functional_bootstrap_KS21 (variant 0, src/bootstrap.c:391-432) / _KS21_2 (variant 1, :434-463) over a batch;
+ * d_tv = the 2N-coefficient cleartext test polynomial, pksk = packing key N -> TRLWE(N). */
+int mosfhet_hip_full_domain_functional_bootstrap_KS21_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, mosfhet_hip_ksk_t pksk,
+                                                            uint64_t *d_out /*[count][N+1]*/, const uint64_t *d_tv /*[2N]*/,
+                                                            const uint64_t *d_in, int count, int torus_base, int variant, void *stream);
+
 /* Timing hook for bench.py: runs `reps` launches of the programmable-bootstrap kernel on `stream`
  * bracketed by hipEvents ON THAT STREAM and returns the average kernel time in milliseconds
  * (synchronises the stream). */

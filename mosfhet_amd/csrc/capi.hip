@@ -14,6 +14,7 @@
 
 #include "bootstrap_kernels.h"
 #include "keyswitch_kernels.h"
+#include "ext_kernels.h"
 
 using namespace mosfhet;
 
@@ -46,6 +47,8 @@ struct mosfhet_hip_bsk {
   size_t bytes;
   uint64_t *scratch = nullptr;  // FDFB / multi-value temporaries, grown on demand
   size_t scratch_words = 0;
+  uint64_t *ext_scratch[2] = {nullptr, nullptr};  // temporaries of the wider compositions (capi_ext.inc); slot 1 = nested (tlwe_mul)
+  size_t ext_words[2] = {0, 0};
 };
 
 struct mosfhet_hip_ksk {
@@ -198,6 +201,8 @@ extern "C" int mosfhet_hip_bsk_destroy(mosfhet_hip_bsk_t bsk) {
   hipSetDevice(bsk->ctx->device);
   hipFree(bsk->d_bk);
   if (bsk->scratch) hipFree(bsk->scratch);
+  for (int i = 0; i < 2; i++)
+    if (bsk->ext_scratch[i]) hipFree(bsk->ext_scratch[i]);
   delete bsk;
   return MOSFHET_HIP_OK;
 }
@@ -689,3 +694,5 @@ extern "C" int mosfhet_hip_time_programmable_bootstrap(mosfhet_hip_ctx_t ctx, mo
   *ms_per_launch = ms / (float)reps;
   return MOSFHET_HIP_OK;
 }
+
+#include "capi_ext.inc"

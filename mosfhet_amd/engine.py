@@ -212,6 +212,21 @@ class Engine:
         _check(lib().mosfhet_hip_circuit_bootstrap_3_batch(self.h, bsk.h, kska.h, kskb.h, _ptr(out), _ptr(ct), count, self._stream()))
         return out
 
+    def public_mux(self, p0, p1, sel, Bg_bit, out=None):
+        count, l, two, N = sel.shape
+        if out is None:
+            out = self.empty(count, 2, N)
+        _check(lib().mosfhet_hip_public_mux_batch(self.h, _ptr(out), _ptr(p0), _ptr(p1), _ptr(sel), N, l, Bg_bit, count, self._stream()))
+        return out
+
+    def full_domain_functional_bootstrap_KS21(self, bsk, pksk, tv, ct, torus_base, variant=0, out=None):
+        count = ct.shape[0]
+        if out is None:
+            out = self.empty(count, bsk.N + 1)
+        _check(lib().mosfhet_hip_full_domain_functional_bootstrap_KS21_batch(self.h, bsk.h, pksk.h, _ptr(out), _ptr(tv), _ptr(ct), count, torus_base,
+                                                                             variant, self._stream()))
+        return out
+
     def trlwe_eval_automorphism(self, gak, ct, gen, out=None):
         count = ct.shape[0]
         if out is None:
