@@ -191,6 +191,22 @@ int mosfhet_hip_full_domain_functional_bootstrap_KS21_batch(mosfhet_hip_ctx_t ct
                                                             uint64_t *d_out /*[count][N+1]*/, const uint64_t *d_tv /*[2N]*/,
                                                             const uint64_t *d_in, int count, int torus_base, int variant, void *stream);
 
+/* multivalue_bootstrap_phase1 (src/bootstrap.c:232-243): d_out[b] = torus_base + 1 rotated accumulators [2][N]. */
+int mosfhet_hip_multivalue_bootstrap_phase1_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_out /*[count][torus_base+1][2][N]*/,
+                                                  const uint64_t *d_in, int count, int torus_base, void *stream);
+/* multivalue_bootstrap_phase2 (src/bootstrap.c:245-265) for a batch sharing one cleartext LUT h_lut[torus_base] (HOST ints). */
+int mosfhet_hip_multivalue_bootstrap_phase2_batch(mosfhet_hip_ctx_t ctx, uint64_t *d_out /*[count][N+1]*/, const int *h_lut,
+                                                  const uint64_t *d_rotated, int N, int torus_base, int log_torus_base, int count, void *stream);
+/* Table-lookup private key switch LWE(m) -> TRLWE(-s m): key of trlwe_new_priv_SK_KS_key_N2 (src/keyswitch.c:611-637), rows
+ * uncompressed, h_rows = Torus[n+1][t][2^base_bit-1][2][N] (entry n belongs to the b word); trlwe_priv_keyswitch (:639-656). */
+int mosfhet_hip_priv_ksk_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t *out, const uint64_t *h_rows, int n, int N, int t, int base_bit);
+int mosfhet_hip_trlwe_priv_keyswitch_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t ksk, uint64_t *d_out /*[count][2][N]*/,
+                                           const uint64_t *d_in /*[count][n+1]*/, int count, void *stream);
+/* circuit_bootstrap (variant 0, src/bootstrap.c:309-322) / circuit_bootstrap_2 (variant 1, :324-344): kska = private key-switch
+ * key (priv_ksk_create, n = N), kskb = packing key. */
+int mosfhet_hip_circuit_bootstrap_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, mosfhet_hip_ksk_t kska, mosfhet_hip_ksk_t kskb,
+                                        uint64_t *d_out /*[count][2l][2][N]*/, const uint64_t *d_in, int count, int variant, void *stream);
+
 /* Timing hook for bench.py: runs `reps` launches of the programmable-bootstrap kernel on `stream`
  * bracketed by hipEvents ON THAT STREAM and returns the average kernel time in milliseconds
  * (synchronises the stream). */

@@ -90,4 +90,69 @@ __global__ void ks21_split_tv_kernel(const uint64_t *__restrict__ tv, uint64_t *
   if (i < N) { p0[i] = tv[i]; p1[i] = 0 - tv[N + i]; }
 }
 
+// two-slot test vector {0, h} of circuit_bootstrap [src/bootstrap.c:314-315]
+__global__ void circuit_bootstrap_lut2_kernel(uint64_t *__restrict__ tv, int N, uint64_t h) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) { tv[i] = 0; tv[N + i] = i >= N / 2 ? h : 0; }
+}
+
+// multivalue_bootstrap_phase1 rotations [src/bootstrap.c:236-241]: out[b][i] = acc[b] X^(i N / torus_base) for i < torus_base
+// (i = 0: copy) and out[b][torus_base] = acc[b] X^torus_base + acc[b].  grid = (2N / 256, torus_base + 1, count)
+__global__ void mv_phase1_rotate_kernel(const uint64_t *__restrict__ acc, uint64_t *__restrict__ out, int N, int torus_base) {
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (pos >= 2 * N) return;
+  const uint64_t *c = acc + (size_t)blockIdx.z * 2 * N + (pos >= N ? N : 0);
+  const int j = pos & (N - 1), a = i < torus_base ? i * N / torus_base : torus_base;
+  uint64_t v = j >= a ? c[j - a] : (uint64_t)0 - c[N + j - a];   // torus_polynomial_mul_by_xai, a < N (src/polynomial.c:184-199)
+  if (i == torus_base) v += c[j];
+  out[((size_t)blockIdx.z * (torus_base + 1) + i) * 2 * N + pos] = v;
+}
+
+// multivalue_bootstrap_phase2 [src/bootstrap.c:245-265] for a batch sharing one cleartext LUT: coef.c[j][i] in {-1, 0, 1} is the
+// multiplier of rotated_tv[i] (i <= torus_base) in the signed sum of bit j (computed on the host from the LUT), then
+// trlwe_mv_extract_tlwe_scaling_addto with weight 2^j [src/trlwe.c:554-578,603-611].  One workgroup of 256 per ciphertext.
+struct MvCoef { signed char c[6][65]; };
+__global__ __launch_bounds__(256) void mv_phase2_kernel(const uint64_t *__restrict__ rot, uint64_t *__restrict__ out, MvCoef coef, int N, int torus_base,
+                                                      int log_torus_base) {
+  extern __shared__ uint64_t tmp[];  // [2][N]
+  const int tid = threadIdx.x;
+  const uint64_t *r = rot + (size_t)blockIdx.x * (torus_base + 1) * 2 * N;
+  uint64_t acc[8], acc_b = 0;        // a words x = tid + 256 k
+#pragma unroll
+  for (int k = 0; k < 8; k++) acc[k] = 0;
+  for (int j = 0; j < log_torus_base; j++) {
+    for (int pos = tid; pos < 2 * N; pos += 256) {
+      uint64_t v = 0;
+      for (int i = 0; i <= torus_base; i++) {
+        const int cf = coef.c[j][i];
+        if (cf == 1) v += r[(size_t)i * 2 * N + pos];
+        else if (cf == -1) v -= r[(size_t)i * 2 * N + pos];
+      }
+      tmp[pos] = v;
+    }
+    __syncthreads();
+    const int amount = 1 << j;
+    // subtracted extractions: idx = N - 1 - (i - amount/2), i in [amount/2, amount); added: idx = i < amount/2
+    for (int e = 0; e < amount; e++) {
+      const bool add = e < amount / 2;
+      const int idx = add ? e : N - 1 - (e - amount / 2);
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int x = tid + 256 * k;
+        if (x < N) {
+          const uint64_t v = x <= idx ? tmp[idx - x] : (uint64_t)0 - tmp[N + idx - x];
+          acc[k] += add ? v : (uint64_t)0 - v;
+        }
+      }
+      if (tid == 0) acc_b += add ? tmp[N + idx] : (uint64_t)0 - tmp[N + idx];
+    }
+    __syncthreads();
+  }
+  uint64_t *o = out + (size_t)blockIdx.x * (N + 1);
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+    if (tid + 256 * k < N) o[tid + 256 * k] = acc[k];
+  if (tid == 0) o[N] = acc_b;
+}
+
 }  // namespace mosfhet

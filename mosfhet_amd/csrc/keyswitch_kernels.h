@@ -191,7 +191,7 @@ struct KsWorkspace {
 };
 
 // Returns hipSuccess or the failing error.  ws is grown on demand (kept by the key handle between calls).
-// in: rows of n_in + 1 words spaced in_stride words apart; out: rows of `row` words spaced out_stride apart.
+// in: rows of n_in + 1 words (n_in when b_word < 0) spaced in_stride words apart; out: rows of `row` words spaced out_stride apart.
 inline hipError_t launch_tlwe_keyswitch(const uint64_t *ksk, uint64_t *out, size_t out_stride, const uint64_t *in, size_t in_stride, int count,
                                         int n_in, int row, int b_word, int t, int base_bit, KsWorkspace &ws, hipStream_t s) {
   constexpr int W = KS_W, NW = KS_NW, TILE = 64 * NW;
@@ -204,7 +204,8 @@ inline hipError_t launch_tlwe_keyswitch(const uint64_t *ksk, uint64_t *out, size
   if (split < 1) split = 1;
   const int i_per_split = (n_in + split - 1) / split;
   split = (n_in + i_per_split - 1) / i_per_split;
-  const size_t need_in = (size_t)(n_in + 1) * Bp, need_out = (size_t)split * row * Bp;
+  const int in_words = n_in + (b_word >= 0 ? 1 : 0);  // b_word < 0: every input word is a digit source, none is copied (private key switch)
+  const size_t need_in = (size_t)in_words * Bp, need_out = (size_t)split * row * Bp;
   hipError_t e;
   if (ws.words_in < need_in) {
     if (ws.inT) (void)hipFree(ws.inT);
@@ -218,7 +219,7 @@ inline hipError_t launch_tlwe_keyswitch(const uint64_t *ksk, uint64_t *out, size
   }
   if (Bp != (size_t)count && (e = hipMemsetAsync(ws.inT, 0, need_in * sizeof(uint64_t), s)) != hipSuccess) return e;
   // in[count][n_in + 1] -> inT[n_in + 1][Bp]
-  hipLaunchKernelGGL(transpose_u64_kernel, dim3((n_in + 1 + 31) / 32, (count + 31) / 32), dim3(32, 8), 0, s, in, ws.inT, count, n_in + 1,
+  hipLaunchKernelGGL(transpose_u64_kernel, dim3((in_words + 31) / 32, (count + 31) / 32), dim3(32, 8), 0, s, in, ws.inT, count, in_words,
                      in_stride, Bp, 1, (size_t)0);
   const int cands = (1 << base_bit) - 1;
   int JB = KS_LDS_BYTES / ((cands + 1) * (W + 2) * 8);          // per LDS buffer

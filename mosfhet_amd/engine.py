@@ -227,6 +227,45 @@ class Engine:
                                                                              variant, self._stream()))
         return out
 
+    def multivalue_bootstrap_phase1(self, bsk, ct, torus_base, out=None):
+        count = ct.shape[0]
+        if out is None:
+            out = self.empty(count, torus_base + 1, 2, bsk.N)
+        _check(lib().mosfhet_hip_multivalue_bootstrap_phase1_batch(self.h, bsk.h, _ptr(out), _ptr(ct), count, torus_base, self._stream()))
+        return out
+
+    def multivalue_bootstrap_phase2(self, lut, rotated, torus_base, log_torus_base, out=None):
+        count, _, _, N = rotated.shape
+        if out is None:
+            out = self.empty(count, N + 1)
+        h_lut = (C.c_int * torus_base)(*[int(x) for x in lut])
+        _check(lib().mosfhet_hip_multivalue_bootstrap_phase2_batch(self.h, _ptr(out), h_lut, _ptr(rotated), N, torus_base, log_torus_base, count,
+                                                                   self._stream()))
+        return out
+
+    def load_priv_key(self, rows, base_bit):
+        """rows: numpy uint64 [n+1][t][2^bb-1][2][N] -> device table-lookup private key-switch key."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        n1, t, per_j, two, N = rows.shape
+        h = C.c_void_p()
+        _check(lib().mosfhet_hip_priv_ksk_create(self.h, C.byref(h), rows.ctypes.data_as(C.c_void_p), n1 - 1, N, t, base_bit))
+        return KeySwitchKey(self, h, n1, 2 * N - 1, t, base_bit)
+
+    def trlwe_priv_keyswitch(self, ksk, ct, out=None):
+        count = ct.shape[0]
+        N = (ksk.n_out + 1) // 2
+        if out is None:
+            out = self.empty(count, 2, N)
+        _check(lib().mosfhet_hip_trlwe_priv_keyswitch_batch(self.h, ksk.h, _ptr(out), _ptr(ct), count, self._stream()))
+        return out
+
+    def circuit_bootstrap(self, bsk, kska, kskb, ct, variant=0, out=None):
+        count = ct.shape[0]
+        if out is None:
+            out = self.empty(count, 2 * bsk.l, 2, bsk.N)
+        _check(lib().mosfhet_hip_circuit_bootstrap_batch(self.h, bsk.h, kska.h, kskb.h, _ptr(out), _ptr(ct), count, variant, self._stream()))
+        return out
+
     def trlwe_eval_automorphism(self, gak, ct, gen, out=None):
         count = ct.shape[0]
         if out is None:
