@@ -207,6 +207,14 @@ int mosfhet_hip_trlwe_priv_keyswitch_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_ks
 int mosfhet_hip_circuit_bootstrap_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, mosfhet_hip_ksk_t kska, mosfhet_hip_ksk_t kskb,
                                         uint64_t *d_out /*[count][2l][2][N]*/, const uint64_t *d_in, int count, int variant, void *stream);
 
+/* functional_bootstrap_trgsw_phase1 (src/bootstrap.c:284-295): blind rotation with a TRGSW accumulator; d_out_dft[b] = TRGSW_DFT(X^-phase)
+ * as [2l][2][N/2] complex in the engine's slot order (the layout of one bootstrap-key entry).  phase2 (:297-306): d_out[b] =
+ * SampleExtract_0(tv (.) d_in_dft[b]); tv_count = 1 (shared) or count.  bsk supplies N, l, Bg_bit in phase 2. */
+int mosfhet_hip_functional_bootstrap_trgsw_phase1_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, double *d_out_dft, const uint64_t *d_in,
+                                                        int count, int torus_base, void *stream);
+int mosfhet_hip_functional_bootstrap_trgsw_phase2_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_out /*[count][N+1]*/,
+                                                        const double *d_in_dft, const uint64_t *d_tv, int tv_count, int count, void *stream);
+
 /* Timing hook for bench.py: runs `reps` launches of the programmable-bootstrap kernel on `stream`
  * bracketed by hipEvents ON THAT STREAM and returns the average kernel time in milliseconds
  * (synchronises the stream). */

@@ -44,6 +44,8 @@ struct PbsParams {
   uint64_t prec_offset;              // double2torus(1 / (4 torus_base))
   int extract;                       // 1: write TLWE (sample extract at 0); 0: write the rotated TRLWE
   int skip_init;                     // 1: blind_rotate only -- acc is loaded from `out` as is
+  int rows = 1;                      // > 1: TRGSW accumulator (blind_rotate_trgsw, src/bootstrap.c:267-282): groups of `rows` consecutive
+                                     // blocks share input ciphertext b / rows and start from test vector b % rows of one shared set
 };
 
 // src/misc.c:18-22 with log_scale = log2(2N)
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
   __shared__ __attribute__((aligned(16))) uint64_t acc1[N];
   const int t = threadIdx.x;
   const size_t b = blockIdx.x;
-  const uint64_t *__restrict__ ct = p.in + b * (size_t)(p.n + 1);
+  const uint64_t *__restrict__ ct = p.in + (p.rows > 1 ? b / (size_t)p.rows : b) * (size_t)(p.n + 1);
   const int Bg_bit = BG > 0 ? BG : p.Bg_bit;
 
   F fft;
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
     }
   } else {
     // src/bootstrap.c:194-195: acc = tv * X^(2N - bbar), gathered straight from global memory
-    const uint64_t *__restrict__ tv = p.tv + b * (size_t)p.tv_stride;
+    const uint64_t *__restrict__ tv = p.rows > 1 ? p.tv + (b % (size_t)p.rows) * (size_t)(2 * N) : p.tv + b * (size_t)p.tv_stride;
     const uint32_t bbar = modswitch<LOG2N2>(pbs_pre(ct[p.n], p, LOG2N2) + p.prec_offset);
     const int rot = (2 * N - (int)bbar) & (2 * N - 1);
     const int a_lo = rot & (N - 1);
@@ -677,11 +679,14 @@ __global__ __launch_bounds__(F::THREADS) void dft_to_torus_kernel(const d2 *__re
 template <class F, int L>
 __global__ __launch_bounds__(F::THREADS) void external_product_kernel(const d2 *__restrict__ bkrow, const d2 *__restrict__ tw,
                                                                     const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
-                                                                    int Bg_bit) {
+                                                                    int Bg_bit, size_t key_stride = 0, size_t in_stride = 2 * F::N) {
+  // key_stride (in d2): 0 = one TRGSW for the whole batch, else TRGSW b starts at bkrow + b * key_stride (per-ciphertext
+  // selectors, functional_bootstrap_trgsw_phase2); in_stride (words): 0 = one shared TRLWE input
   constexpr int N = F::N, M = F::M, T = F::THREADS;
   __shared__ __attribute__((aligned(16))) d2 xch[F::XCH_SLOTS];
   const int t = threadIdx.x;
-  const uint64_t *ct = in + (size_t)blockIdx.x * 2 * N;
+  const uint64_t *ct = in + (size_t)blockIdx.x * in_stride;
+  bkrow += (size_t)blockIdx.x * key_stride;
   F fft;
   fft.init(tw, t);
   uint64_t off = 1ull << (63 - L * Bg_bit);

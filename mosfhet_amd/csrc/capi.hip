@@ -249,9 +249,9 @@ static int launch_pbs_f(int l, int Bg_bit, const PbsParams &p, int count, hipStr
 
 static int bootstrap_common(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_out,
                             const uint64_t *d_tv, int tv_count, const uint64_t *d_in, int count, int pre, int kappa,
-                            int theta, int torus_base, int extract, int skip_init, void *stream) {
+                            int theta, int torus_base, int extract, int skip_init, void *stream, int rows = 1) {
   if (!ctx || !bsk || !d_out || !d_in || count < 0) return fail(MOSFHET_HIP_EINVAL, "%s: bad argument", who);
-  if (!skip_init && (!d_tv || (tv_count != 1 && tv_count != count)))
+  if (!skip_init && rows == 1 && (!d_tv || (tv_count != 1 && tv_count != count)))
     return fail(MOSFHET_HIP_EINVAL, "%s: tv_count must be 1 or count (got %d, count %d)", who, tv_count, count);
   if (!skip_init && torus_base < 1) return fail(MOSFHET_HIP_EINVAL, "%s: torus_base %d", who, torus_base);
   if (pre && (kappa < 0 || kappa > 63 || theta < 0 || theta > 52)) return fail(MOSFHET_HIP_EINVAL, "%s: kappa/theta out of range", who);
@@ -273,6 +273,7 @@ static int bootstrap_common(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hip_
   p.prec_offset = skip_init ? 0 : (uint64_t)((int64_t)(18446744073709551616.0 * (1. / (4 * (double)torus_base))));
   p.extract = extract;
   p.skip_init = skip_init;
+  p.rows = rows;
   return bsk->N == 1024 ? launch_pbs_f<Fft1024>(bsk->l, bsk->Bg_bit, p, count, pick(ctx, stream))
                         : launch_pbs_f<Fft2048>(bsk->l, bsk->Bg_bit, p, count, pick(ctx, stream));
 }

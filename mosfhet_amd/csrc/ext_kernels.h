@@ -90,6 +90,14 @@ __global__ void ks21_split_tv_kernel(const uint64_t *__restrict__ tv, uint64_t *
   if (i < N) { p0[i] = tv[i]; p1[i] = 0 - tv[N + i]; }
 }
 
+// trivial TRGSW(1) [src/trgsw.c:130-142]: row q < l carries 2^(64-(q+1)Bg) on a[0], row l + q on b[0]; grid = (2N / 256, 2l)
+__global__ void trgsw_trivial_one_kernel(uint64_t *__restrict__ g, int N, int l, int Bg_bit) {
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;
+  if (pos >= 2 * N) return;
+  const int hot = (q / l) * N;
+  g[(size_t)q * 2 * N + pos] = pos == hot ? 1ull << (64 - (q % l + 1) * Bg_bit) : 0;
+}
+
 // two-slot test vector {0, h} of circuit_bootstrap [src/bootstrap.c:314-315]
 __global__ void circuit_bootstrap_lut2_kernel(uint64_t *__restrict__ tv, int N, uint64_t h) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -266,6 +266,21 @@ class Engine:
         _check(lib().mosfhet_hip_circuit_bootstrap_batch(self.h, bsk.h, kska.h, kskb.h, _ptr(out), _ptr(ct), count, variant, self._stream()))
         return out
 
+    def functional_bootstrap_trgsw_phase1(self, bsk, ct, torus_base, out=None):
+        count = ct.shape[0]
+        if out is None:
+            out = self.torch.empty(count, 2 * bsk.l, 2, bsk.N, dtype=self.torch.float64, device=self.device)
+        _check(lib().mosfhet_hip_functional_bootstrap_trgsw_phase1_batch(self.h, bsk.h, _ptr(out), _ptr(ct), count, torus_base, self._stream()))
+        return out
+
+    def functional_bootstrap_trgsw_phase2(self, bsk, g_dft, tv, out=None):
+        count = g_dft.shape[0]
+        if out is None:
+            out = self.empty(count, bsk.N + 1)
+        _check(lib().mosfhet_hip_functional_bootstrap_trgsw_phase2_batch(self.h, bsk.h, _ptr(out), _ptr(g_dft), _ptr(tv), tv.shape[0], count,
+                                                                         self._stream()))
+        return out
+
     def trlwe_eval_automorphism(self, gak, ct, gen, out=None):
         count = ct.shape[0]
         if out is None:
