@@ -215,6 +215,18 @@ int mosfhet_hip_functional_bootstrap_trgsw_phase1_batch(mosfhet_hip_ctx_t ctx, m
 int mosfhet_hip_functional_bootstrap_trgsw_phase2_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_out /*[count][N+1]*/,
                                                         const double *d_in_dft, const uint64_t *d_tv, int tv_count, int count, void *stream);
 
+/* trlwe_tensor_prod_FFT (src/trlwe.c:727-771) over a batch of pairs; rlk = 1-entry key set (mosfhet_hip_trlwe_ksk_create) holding the rows of
+ * trlwe_new_RL_key (src/keyswitch.c:3-10).  tlwe_mul (src/tlwe.c:322-332): LWE x LWE under the extracted key, pksk = packing key. */
+int mosfhet_hip_trlwe_tensor_prod_FFT_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_gak_t rlk, uint64_t *d_out /*[count][2][N]*/, const uint64_t *d_in1,
+                                            const uint64_t *d_in2, int precision, int count, void *stream);
+int mosfhet_hip_tlwe_mul_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t pksk, mosfhet_hip_gak_t rlk, uint64_t *d_out /*[count][N+1]*/, const uint64_t *d_in1,
+                               const uint64_t *d_in2, int precision, int count, void *stream);
+/* full_domain_functional_bootstrap_CLOT21 (variant 0, src/bootstrap.c:465-491: d_tv = two TRLWE test vectors [2][2][N]) and _CLOT21_2
+ * (variant 1, :493-517: d_tv = 2^(precision-1) cleartext LUT words, on the device). */
+int mosfhet_hip_full_domain_functional_bootstrap_CLOT21_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, mosfhet_hip_ksk_t pksk, mosfhet_hip_gak_t rlk,
+                                                              uint64_t *d_out /*[count][N+1]*/, const uint64_t *d_tv, const uint64_t *d_in, int count,
+                                                              int precision, int variant, void *stream);
+
 /* Timing hook for bench.py: runs `reps` launches of the programmable-bootstrap kernel on `stream`
  * bracketed by hipEvents ON THAT STREAM and returns the average kernel time in milliseconds
  * (synchronises the stream). */

@@ -563,11 +563,14 @@ __device__ __forceinline__ void ks_rows_rt(const uint64_t (&dd_lo)[8], const uin
 
 // mode 0: out = trlwe_keyswitch(in, ks0)                       = (0, in.b) - as(in.a; ks0)
 // mode 1: out = trlwe_priv_keyswitch_2(in, {ks0, ks1})         = -as(in.a; ks0) - as(-in.b; ks1)
+// mode 2: out = base - trlwe_keyswitch(in, ks0)                = base - (0, in.b) + as(in.a; ks0)   (relinearisation step of
+//         trlwe_tensor_prod_FFT, src/trlwe.c:758-761)
 template <class F>
 __global__ __launch_bounds__(F::THREADS, 2) void trlwe_fft_keyswitch_kernel(const d2 *__restrict__ ks0, const d2 *__restrict__ ks1,
                                                                           const d2 *__restrict__ tw, const uint64_t *__restrict__ in,
                                                                           size_t in_stride, uint64_t *__restrict__ out, size_t out_stride,
-                                                                          int t, int base_bit, int mode) {
+                                                                          int t, int base_bit, int mode,
+                                                                          const uint64_t *__restrict__ base = nullptr, size_t base_stride = 0) {
   constexpr int N = F::N, M = F::M, T = F::THREADS;
   __shared__ __attribute__((aligned(16))) d2 xch[F::XCH_SLOTS];
   const int tid = threadIdx.x;
@@ -585,6 +588,13 @@ __global__ __launch_bounds__(F::THREADS, 2) void trlwe_fft_keyswitch_kernel(cons
     res_a_hi[m] = 0;
     res_b_lo[m] = mode == 0 ? c[N + m * T + tid] : 0;
     res_b_hi[m] = mode == 0 ? c[N + M + m * T + tid] : 0;
+    if (mode == 2) {  // kept negated: res = -(base - (0, in.b)), the common "-=" below then yields -(out), negated at the store
+      const uint64_t *bs = base + (size_t)blockIdx.x * base_stride;
+      res_a_lo[m] = 0 - bs[m * T + tid];
+      res_a_hi[m] = 0 - bs[M + m * T + tid];
+      res_b_lo[m] = c[N + m * T + tid] - bs[N + m * T + tid];
+      res_b_hi[m] = c[N + M + m * T + tid] - bs[N + M + m * T + tid];
+    }
   }
   const int passes = mode == 1 ? 2 : 1;
 #pragma unroll 1
@@ -621,10 +631,10 @@ __global__ __launch_bounds__(F::THREADS, 2) void trlwe_fft_keyswitch_kernel(cons
   }
 #pragma unroll
   for (int m = 0; m < 8; m++) {
-    o[m * T + tid] = res_a_lo[m];
-    o[M + m * T + tid] = res_a_hi[m];
-    o[N + m * T + tid] = res_b_lo[m];
-    o[N + M + m * T + tid] = res_b_hi[m];
+    o[m * T + tid] = mode == 2 ? 0 - res_a_lo[m] : res_a_lo[m];
+    o[M + m * T + tid] = mode == 2 ? 0 - res_a_hi[m] : res_a_hi[m];
+    o[N + m * T + tid] = mode == 2 ? 0 - res_b_lo[m] : res_b_lo[m];
+    o[N + M + m * T + tid] = mode == 2 ? 0 - res_b_hi[m] : res_b_hi[m];
   }
 }
 

@@ -38,6 +38,8 @@ static int fail(int code, const char *fmt, ...) {
 struct mosfhet_hip_ctx {
   int device;
   d2 *tw1024, *tw2048;  // device twiddle tables
+  uint64_t *scratch[3] = {nullptr, nullptr, nullptr};  // temporaries of compositions without a bootstrap key (tlwe_mul, tensor product)
+  size_t scratch_words[3] = {0, 0, 0};
 };
 
 struct mosfhet_hip_bsk {
@@ -137,6 +139,8 @@ extern "C" int mosfhet_hip_ctx_destroy(mosfhet_hip_ctx_t ctx) {
   hipDeviceSynchronize();
   hipFree(ctx->tw1024);
   hipFree(ctx->tw2048);
+  for (int i = 0; i < 3; i++)
+    if (ctx->scratch[i]) hipFree(ctx->scratch[i]);
   delete ctx;
   return MOSFHET_HIP_OK;
 }

@@ -163,4 +163,77 @@ __global__ __launch_bounds__(256) void mv_phase2_kernel(const uint64_t *__restri
   if (tid == 0) o[N] = acc_b;
 }
 
+// trlwe_tensor_prod_FFT before relinearisation [src/trlwe.c:727-757]: operands rescaled with torus2int (polynomial_torus_scale,
+// src/polynomial.c:322-326) to half_prec1 / half_prec2 bits, res = (A1 B2 + B1 A2, B1 B2), t2 = (A1 A2, 0); products in the order
+// of the reference's calls (mul, then mul_addto).  The relinearisation (trlwe_keyswitch of t2, res - that) is the FFT key-switch
+// kernel in mode 2.  One team per pair.
+template <class F>
+__global__ __launch_bounds__(F::THREADS, 2) void trlwe_tensor_prod_kernel(const uint64_t *__restrict__ in1, size_t in1_stride,
+                                                                        const uint64_t *__restrict__ in2, size_t in2_stride, const d2 *__restrict__ tw,
+                                                                        uint64_t *__restrict__ res, uint64_t *__restrict__ t2, int precision) {
+  constexpr int N = F::N, M = F::M, T = F::THREADS;
+  __shared__ __attribute__((aligned(16))) d2 xch[F::XCH_SLOTS];
+  const int tid = threadIdx.x;
+  const uint64_t *c1 = in1 + (size_t)blockIdx.x * in1_stride, *c2 = in2 + (size_t)blockIdx.x * in2_stride;
+  uint64_t *r = res + (size_t)blockIdx.x * 2 * N, *tt = t2 + (size_t)blockIdx.x * 2 * N;
+  F fft;
+  fft.init(tw, tid);
+  const int hp1 = 64 - (64 - precision) / 2, hp2 = 64 - (64 - precision + 1) / 2;
+  const double scale = 0x1p-64 / (double)M;
+  auto load = [&](const uint64_t *src, int hp, double (&re)[8], double (&im)[8]) {
+#pragma unroll
+    for (int m = 0; m < 8; m++) {   // torus2int(x, hp) = (x + 2^(63-hp)) >> (64-hp)   [src/misc.c:18-22]
+      re[m] = torus_to_double((src[m * T + tid] + (1ull << (63 - hp))) >> (64 - hp));
+      im[m] = torus_to_double((src[M + m * T + tid] + (1ull << (63 - hp))) >> (64 - hp));
+    }
+    fft.forward(re, im, xch, tid);
+  };
+  auto store = [&](uint64_t *dst, double (&re)[8], double (&im)[8]) {
+    fft.inverse(re, im, xch, tid);
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      dst[m * T + tid] = round_mod_2_64(re[m], scale);
+      dst[M + m * T + tid] = round_mod_2_64(im[m], scale);
+    }
+  };
+  double a1r[8], a1i[8], a2r[8], a2i[8], xr[8], xi[8];
+  load(c1, hp1, a1r, a1i);
+  load(c2, hp2, a2r, a2i);
+#pragma unroll
+  for (int m = 0; m < 8; m++) {      // T = A1 A2
+    xr[m] = __builtin_fma(-a1i[m], a2i[m], __builtin_fma(a1r[m], a2r[m], 0.0));
+    xi[m] = __builtin_fma(a1i[m], a2r[m], __builtin_fma(a1r[m], a2i[m], 0.0));
+  }
+  store(tt, xr, xi);
+#pragma unroll
+  for (int m = 0; m < 8; m++) { tt[N + m * T + tid] = 0; tt[N + M + m * T + tid] = 0; }
+  double b1r[8], b1i[8], b2r[8], b2i[8];
+  load(c1 + N, hp1, b1r, b1i);
+  load(c2 + N, hp2, b2r, b2i);
+#pragma unroll
+  for (int m = 0; m < 8; m++) {      // A = A1 B2 + B1 A2
+    xr[m] = __builtin_fma(-a1i[m], b2i[m], __builtin_fma(a1r[m], b2r[m], 0.0));
+    xi[m] = __builtin_fma(a1i[m], b2r[m], __builtin_fma(a1r[m], b2i[m], 0.0));
+    xr[m] = __builtin_fma(-b1i[m], a2i[m], __builtin_fma(b1r[m], a2r[m], xr[m]));
+    xi[m] = __builtin_fma(b1i[m], a2r[m], __builtin_fma(b1r[m], a2i[m], xi[m]));
+  }
+  store(r, xr, xi);
+#pragma unroll
+  for (int m = 0; m < 8; m++) {      // B = B1 B2
+    xr[m] = __builtin_fma(-b1i[m], b2i[m], __builtin_fma(b1r[m], b2r[m], 0.0));
+    xi[m] = __builtin_fma(b1i[m], b2r[m], __builtin_fma(b1r[m], b2i[m], 0.0));
+  }
+  store(r + N, xr, xi);
+}
+
+// test vector of full_domain_functional_bootstrap_CLOT21_2 [src/bootstrap.c:503-508]: 4 interleaved LUTs of torus_base slots:
+// the two halves of the user's LUT, the constant `sign`, zero  (trlwe_torus_packing_many_LUT, src/trlwe.c:677-687)
+__global__ void clot21_lut_kernel(uint64_t *__restrict__ tv, const uint64_t *__restrict__ lut, uint64_t sign, int N, int torus_base) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= N) return;
+  const int span = N / (4 * torus_base), idx = x / span, j = idx % 4, i = idx / 4;
+  tv[x] = 0;
+  tv[N + x] = j < 2 ? lut[j * torus_base + i] : (j == 2 ? sign : 0);
+}
+
 }  // namespace mosfhet

@@ -281,6 +281,28 @@ class Engine:
                                                                          self._stream()))
         return out
 
+    def trlwe_tensor_prod_FFT(self, rlk, c1, c2, precision, out=None):
+        count = c1.shape[0]
+        if out is None:
+            out = self.empty(count, 2, rlk.N)
+        _check(lib().mosfhet_hip_trlwe_tensor_prod_FFT_batch(self.h, rlk.h, _ptr(out), _ptr(c1), _ptr(c2), precision, count, self._stream()))
+        return out
+
+    def tlwe_mul(self, pksk, rlk, c1, c2, precision, out=None):
+        count = c1.shape[0]
+        if out is None:
+            out = self.empty(count, rlk.N + 1)
+        _check(lib().mosfhet_hip_tlwe_mul_batch(self.h, pksk.h, rlk.h, _ptr(out), _ptr(c1), _ptr(c2), precision, count, self._stream()))
+        return out
+
+    def full_domain_functional_bootstrap_CLOT21(self, bsk, pksk, rlk, tv, ct, precision, variant=0, out=None):
+        count = ct.shape[0]
+        if out is None:
+            out = self.empty(count, bsk.N + 1)
+        _check(lib().mosfhet_hip_full_domain_functional_bootstrap_CLOT21_batch(self.h, bsk.h, pksk.h, rlk.h, _ptr(out), _ptr(tv), _ptr(ct), count,
+                                                                               precision, variant, self._stream()))
+        return out
+
     def trlwe_eval_automorphism(self, gak, ct, gen, out=None):
         count = ct.shape[0]
         if out is None:
