@@ -46,6 +46,8 @@ struct mosfhet_hip_bsk {
   mosfhet_hip_ctx_t ctx;
   d2 *d_bk;  // [n][(k+1)l][k+1][P][lanes]
   int n, k, N, l, Bg_bit;
+  int unfolding = 1;          // > 1: d_bk is null and d_su holds the torus-domain samples of new_bootstrap_key (src/bootstrap.c:23-48)
+  uint64_t *d_su = nullptr;   // [n 2^u / u][2l][2][N]
   size_t bytes;
   uint64_t *scratch = nullptr;  // FDFB / multi-value temporaries, grown on demand
   size_t scratch_words = 0;
@@ -203,7 +205,8 @@ extern "C" int mosfhet_hip_bsk_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t *
 extern "C" int mosfhet_hip_bsk_destroy(mosfhet_hip_bsk_t bsk) {
   if (!bsk) return MOSFHET_HIP_OK;
   hipSetDevice(bsk->ctx->device);
-  hipFree(bsk->d_bk);
+  if (bsk->d_bk) hipFree(bsk->d_bk);
+  if (bsk->d_su) hipFree(bsk->d_su);
   if (bsk->scratch) hipFree(bsk->scratch);
   for (int i = 0; i < 2; i++)
     if (bsk->ext_scratch[i]) hipFree(bsk->ext_scratch[i]);
@@ -215,6 +218,7 @@ extern "C" size_t mosfhet_hip_bsk_bytes(mosfhet_hip_bsk_t bsk) { return bsk ? bs
 
 extern "C" int mosfhet_hip_bsk_export_dft(mosfhet_hip_bsk_t bsk, double *h_out) {
   if (!bsk || !h_out) return fail(MOSFHET_HIP_EINVAL, "bsk_export: bad argument");
+  if (bsk->unfolding > 1) return fail(MOSFHET_HIP_EINVAL, "bsk_export: an unfolded key has no DFT form");
   HIP_TRY(hipSetDevice(bsk->ctx->device));
   std::vector<double> tmp(bsk->bytes / sizeof(double));
   HIP_TRY(hipMemcpy(tmp.data(), bsk->d_bk, bsk->bytes, hipMemcpyDeviceToHost));
@@ -251,6 +255,9 @@ static int launch_pbs_f(int l, int Bg_bit, const PbsParams &p, int count, hipStr
   return MOSFHET_HIP_OK;
 }
 
+static int bootstrap_unfolded(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_out, const uint64_t *d_tv, int tv_count,
+                              const uint64_t *d_in, int count, int pre, int torus_base, int extract, int skip_init, void *stream, int rows);
+
 static int bootstrap_common(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_out,
                             const uint64_t *d_tv, int tv_count, const uint64_t *d_in, int count, int pre, int kappa,
                             int theta, int torus_base, int extract, int skip_init, void *stream, int rows = 1) {
@@ -261,6 +268,7 @@ static int bootstrap_common(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hip_
   if (pre && (kappa < 0 || kappa > 63 || theta < 0 || theta > 52)) return fail(MOSFHET_HIP_EINVAL, "%s: kappa/theta out of range", who);
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
+  if (bsk->unfolding > 1) return bootstrap_unfolded(who, ctx, bsk, d_out, d_tv, tv_count, d_in, count, pre, torus_base, extract, skip_init, stream, rows);
   PbsParams p;
   p.bk = bsk->d_bk;
   p.tw = bsk->N == 1024 ? ctx->tw1024 : ctx->tw2048;
@@ -311,6 +319,7 @@ extern "C" int mosfhet_hip_external_product_batch(mosfhet_hip_ctx_t ctx, mosfhet
                                                   const uint64_t *d_in, int count, void *stream) {
   if (!ctx || !bsk || !d_out || !d_in || count < 0 || key_index < 0 || key_index >= bsk->n)
     return fail(MOSFHET_HIP_EINVAL, "external_product: bad argument");
+  if (bsk->unfolding > 1) return fail(MOSFHET_HIP_EINVAL, "external_product: an unfolded key has no DFT entries");
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
   const d2 *row = bsk->d_bk + (size_t)key_index * (2 * bsk->l * 2 * (bsk->N / 2));
@@ -565,6 +574,7 @@ extern "C" int mosfhet_hip_functional_bootstrap_ga_batch(mosfhet_hip_ctx_t ctx, 
   if (!ctx || !bsk || !gak || !d_out || !d_tv || !d_in || count < 0 || torus_base < 1)
     return fail(MOSFHET_HIP_EINVAL, "functional_bootstrap_ga: bad argument");
   if (tv_count != 1 && tv_count != count) return fail(MOSFHET_HIP_EINVAL, "functional_bootstrap_ga: tv_count must be 1 or count");
+  if (bsk->unfolding > 1) return fail(MOSFHET_HIP_EINVAL, "functional_bootstrap_ga: needs a key without unfolding");
   if (gak->N != bsk->N || gak->t != bsk->l || gak->base_bit != bsk->Bg_bit)
     return fail(MOSFHET_HIP_EINVAL, "functional_bootstrap_ga: automorphism keys must use the bootstrap key's N, l, Bg_bit");
   if (count == 0) return MOSFHET_HIP_OK;

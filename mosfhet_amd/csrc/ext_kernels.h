@@ -236,4 +236,120 @@ __global__ void clot21_lut_kernel(uint64_t *__restrict__ tv, const uint64_t *__r
   tv[N + x] = j < 2 ? lut[j * torus_base + i] : (j == 2 ? sign : 0);
 }
 
+// Blind rotation with unfolding u > 1 [src/bootstrap.c:124-149]: per group of u mask words, the TRGSW  xai = sum_j X^(rot_j) su_j  is
+// assembled row by row in the torus domain straight from HBM (rot_j = mod-switched SUM of the group's mask words selected by j),
+// transformed, and multiplied with the digits of the accumulator; the product replaces the accumulator.  A straightforward
+// kernel (run-time l, Bg, u; both accumulator components in registers): 3 forward transforms per TRGSW row instead of 1.
+struct UnfoldParams {
+  const uint64_t *__restrict__ su;   // [n 2^u / u][2l][2][N] torus domain
+  const d2 *__restrict__ tw;
+  const uint64_t *__restrict__ in;   // [B][n+1]
+  const uint64_t *__restrict__ tv;   // [tv_count][2][N]
+  uint64_t *__restrict__ out;        // [B][2][N]
+  long long tv_stride;
+  int n, l, Bg_bit, unfolding;
+  uint64_t prec_offset;
+};
+
+template <class F>
+__global__ __launch_bounds__(F::THREADS) void pbs_unfolded_kernel(UnfoldParams p) {
+  constexpr int N = F::N, M = F::M, T = F::THREADS, LOG2N2 = F::LOGM + 2;
+  __shared__ __attribute__((aligned(16))) d2 xch[F::XCH_SLOTS];
+  const int t = threadIdx.x;
+  const size_t b = blockIdx.x;
+  const uint64_t *__restrict__ ct = p.in + b * (size_t)(p.n + 1);
+  F fft;
+  fft.init(p.tw, t);
+  uint64_t acc[2][2][8];   // [component][half][m]
+  {
+    const uint64_t *__restrict__ tv = p.tv + b * (size_t)p.tv_stride;
+    const uint32_t bbar = modswitch<LOG2N2>(ct[p.n] + p.prec_offset);
+    const int rot = (2 * N - (int)bbar) & (2 * N - 1);
+    const int a_lo = rot & (N - 1);
+    const bool flip = (rot & N) != 0;
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        acc[c][0][m] = rot_coeff<N>(tv + c * N, m * T + t, a_lo, flip);
+        acc[c][1][m] = rot_coeff<N>(tv + c * N, M + m * T + t, a_lo, flip);
+      }
+  }
+  const int l = p.l, Bg = p.Bg_bit, u = p.unfolding, key_exp = 1 << u, final_exp = key_exp / u;
+  uint64_t off = 1ull << (63 - l * Bg);
+  for (int i = 0; i < l; i++) off += 1ull << (63 - i * Bg);
+  const uint32_t mask = (1u << Bg) - 1;
+  const int half = 1 << (Bg - 1);
+  const double scale = 0x1p-64 / (double)M;
+  const size_t trgsw_sz = (size_t)2 * l * 2 * N;
+#pragma unroll 1
+  for (int i = 0; i < p.n; i += u) {
+    double o_re[2][8], o_im[2][8];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int m = 0; m < 8; m++) { o_re[c][m] = 0.0; o_im[c][m] = 0.0; }
+#pragma unroll 1
+    for (int q = 0; q < 2 * l; q++) {
+      const int comp = q / l, shift = 64 - (q % l + 1) * Bg;
+      double dr[8], di[8];
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const uint64_t lo = comp ? acc[1][0][m] : acc[0][0][m], hi = comp ? acc[1][1][m] : acc[0][1][m];
+        dr[m] = (double)((int)((uint32_t)((lo + off) >> shift) & mask) - half);
+        di[m] = (double)((int)((uint32_t)((hi + off) >> shift) & mask) - half);
+      }
+      fft.forward(dr, di, xch, t);
+#pragma unroll 1
+      for (int c = 0; c < 2; c++) {
+        uint64_t xl[8], xh[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) { xl[m] = 0; xh[m] = 0; }
+#pragma unroll 1
+        for (int j = 0; j < key_exp; j++) {
+          uint64_t a_i = 0;
+          for (int bb = 0; bb < u; bb++)
+            if ((j >> bb) & 1) a_i += ct[i + bb];
+          const int rot = j ? (int)modswitch<LOG2N2>(a_i) : 0;
+          const int a_lo = rot & (N - 1);
+          const bool flip = (rot & N) != 0;
+          const uint64_t *__restrict__ src = p.su + ((size_t)i * final_exp + j) * trgsw_sz + ((size_t)q * 2 + c) * N;
+#pragma unroll
+          for (int m = 0; m < 8; m++) {
+            xl[m] += rot_coeff<N>(src, m * T + t, a_lo, flip);
+            xh[m] += rot_coeff<N>(src, M + m * T + t, a_lo, flip);
+          }
+        }
+        double kr[8], ki[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) { kr[m] = torus_to_double(xl[m]); ki[m] = torus_to_double(xh[m]); }
+        fft.forward(kr, ki, xch, t);
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          const double re = __builtin_fma(-di[m], ki[m], __builtin_fma(dr[m], kr[m], c ? o_re[1][m] : o_re[0][m]));
+          const double im = __builtin_fma(di[m], kr[m], __builtin_fma(dr[m], ki[m], c ? o_im[1][m] : o_im[0][m]));
+          if (c) { o_re[1][m] = re; o_im[1][m] = im; } else { o_re[0][m] = re; o_im[0][m] = im; }
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      fft.inverse(o_re[c], o_im[c], xch, t);
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        acc[c][0][m] = round_mod_2_64(o_re[c][m], scale);
+        acc[c][1][m] = round_mod_2_64(o_im[c][m], scale);
+      }
+    }
+  }
+  uint64_t *o = p.out + b * (size_t)(2 * N);
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      o[c * N + m * T + t] = acc[c][0][m];
+      o[c * N + M + m * T + t] = acc[c][1][m];
+    }
+}
+
 }  // namespace mosfhet

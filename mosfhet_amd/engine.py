@@ -143,6 +143,15 @@ class Engine:
         _check(lib().mosfhet_hip_bsk_create(self.h, C.byref(h), bk_torus.ctypes.data_as(C.c_void_p), n, k, N, l, Bg_bit))
         return BootstrapKey(self, h, n, k, N, l, Bg_bit)
 
+    def load_bootstrap_key_unfolded(self, su, l, Bg_bit, unfolding):
+        """su: numpy uint64 [n 2^u/u][2l][2][N] (torus domain) -> device key taking the unfolded blind rotation."""
+        su = np.ascontiguousarray(su, dtype=np.uint64)
+        cnt, rows, two, N = su.shape
+        n = cnt * unfolding >> unfolding
+        h = C.c_void_p()
+        _check(lib().mosfhet_hip_bsk_unfolded_create(self.h, C.byref(h), su.ctypes.data_as(C.c_void_p), n, N, l, Bg_bit, unfolding))
+        return BootstrapKey(self, h, n, 1, N, l, Bg_bit)
+
     def load_bootstrap_key_device(self, d_bk, k, l, Bg_bit):
         n, rows, k1, N = d_bk.shape
         h = C.c_void_p()

@@ -166,6 +166,13 @@ void orc_full_domain_functional_bootstrap_CLOT21(const orc_fft_plan *p, Torus *o
                     const Torus *ksk, int tk, int bbk, const double *rl_dft, int tr, int bbr, int n, int l, int Bg_bit, int precision,
                     int variant /*0: _CLOT21 (tv = [2][2][N]), 1: _CLOT21_2 (tv = 2^(precision-1) LUT words)*/); /* bootstrap.c:465-517 */
 
+/* ---- blind-rotate unfolding (oracle_ext.c) ---- */
+void orc_gen_bootstrap_key_unfolded(orc_rng *r, Torus *su /*[n 2^u/u][2l][2][N]*/, const Torus *lwe_s, int n, const Torus *rlwe_s, int N, int l,
+                    int Bg_bit, double sigma, int unfolding);                             /* bootstrap.c:23-48 */
+void orc_blind_rotate_unfolded(const orc_fft_plan *p, Torus *acc, const Torus *a, const Torus *su, int n, int l, int Bg_bit, int unfolding); /* bootstrap.c:124-149 */
+void orc_functional_bootstrap_unfolded(const orc_fft_plan *p, Torus *out, const Torus *tv, const Torus *in, const Torus *su, int n, int l, int Bg_bit,
+                    int torus_base, int unfolding, int extract);                          /* bootstrap.c:192-206 with key->unfolding > 1 */
+
 /* ---- deterministic test-input generation (own code; the reference's RNG is RDRAND-seeded
  *      and not reproducible, src/misc.c:34-49) ---- */
 uint64_t orc_rng_next(orc_rng *r);                       /* splitmix64 */

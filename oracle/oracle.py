@@ -499,6 +499,20 @@ def full_domain_functional_bootstrap_CLOT21(tv, c, bk_dft, ksk, bbk, rl_dft, bbr
     return out
 
 
+def gen_bootstrap_key_unfolded(rng, lwe_s, rlwe_s, l, Bg_bit, sigma, unfolding):
+    n, N = lwe_s.size, rlwe_s.size
+    su = np.empty((n * (1 << unfolding) // unfolding, 2 * l, 2, N), dtype=np.uint64)
+    lib().orc_gen_bootstrap_key_unfolded(rng.ref(), _u(su), _u(lwe_s), n, _u(rlwe_s), N, l, Bg_bit, C.c_double(sigma), unfolding)
+    return su
+
+
+def functional_bootstrap_unfolded(tv, c, su, l, Bg_bit, torus_base, unfolding, extract=True):
+    N = tv.shape[-1]
+    out = np.empty(N + 1, dtype=np.uint64) if extract else np.empty((2, N), dtype=np.uint64)
+    lib().orc_functional_bootstrap_unfolded(plan(N).h, _u(out), _u(tv), _u(c), _u(su), C.c_int(c.size - 1), l, Bg_bit, torus_base, unfolding, int(extract))
+    return out
+
+
 # ---------------- deterministic inputs ----------------
 def gen_binary_key(rng, n):
     s = np.empty(n, dtype=np.uint64)

@@ -309,3 +309,59 @@ void orc_full_domain_functional_bootstrap_CLOT21(const orc_fft_plan *p, Torus *o
   for (int i = 0; i <= N; i++) out[i] = ct_f0[i] + ct_f1[i];
   free(tmp_trlwe); free(tmp_trlwe2); free(ct_sign); free(ct_f0); free(ct_f1);
 }
+
+/* src/bootstrap.c:23-48  new_bootstrap_key with unfolding u > 1: for every group of u key bits, 2^u torus-domain TRGSW samples
+ * su[i 2^u/u + j] = TRGSW( prod_{b<u} (bit b of j ? s_{i+b} : 1 - s_{i+b}) ), i.e. the indicator of the group's bit pattern. */
+void orc_gen_bootstrap_key_unfolded(orc_rng *r, Torus *su, const Torus *lwe_s, int n, const Torus *rlwe_s, int N, int l, int Bg_bit, double sigma,
+                                    int unfolding) {
+  const int key_exp = 1 << unfolding, final_exp = key_exp / unfolding;
+  const size_t sz = (size_t)2 * l * 2 * N;
+  for (int i = 0; i < n; i += unfolding)
+    for (int j = 0; j < key_exp; j++) {
+      Torus key = 1;
+      for (int u = 0, j_ = j; u < unfolding; u++, j_ >>= 1) key *= (j_ & 1) ? lwe_s[i + u] : 1 - lwe_s[i + u];
+      orc_trgsw_monomial_sample(r, su + ((size_t)i * final_exp + j) * sz, (int64_t)key, 0, rlwe_s, 1, N, l, Bg_bit, sigma);
+    }
+}
+
+/* src/bootstrap.c:124-149  blind_rotate_unfolded: per group, xai = sum_j X^(modswitch(sum of the group's mask words selected by j)) su_j
+ * assembled in the torus domain, transformed (trgsw_to_DFT), and acc <- xai (.) acc (the product REPLACES the accumulator). */
+void orc_blind_rotate_unfolded(const orc_fft_plan *p, Torus *acc, const Torus *a, const Torus *su, int n, int l, int Bg_bit, int unfolding) {
+  const int N = plan_N(p);
+  int log_N2 = 0;
+  while ((1 << log_N2) < 2 * N) log_N2++;
+  const int key_exp = 1 << unfolding, final_exp = key_exp / unfolding;
+  const size_t sz = (size_t)2 * l * 2 * N;
+  Torus *xai = talloc(sz), *out = talloc((size_t)2 * N);
+  double *xai_dft = (double *)malloc(sizeof(double) * sz);
+  for (int i = 0; i < n; i += unfolding) {
+    memcpy(xai, su + (size_t)i * final_exp * sz, sizeof(Torus) * sz);
+    for (int j = 1; j < key_exp; j++) {
+      Torus a_i = 0;
+      for (int u = 0, j_ = j; u < unfolding; u++, j_ >>= 1)
+        if (j_ & 1) a_i += a[i + u];
+      const int rot = (int)orc_torus2int(a_i, log_N2);
+      const Torus *src = su + ((size_t)i * final_exp + j) * sz;
+      for (int q = 0; q < 2 * l * 2; q++) orc_poly_mul_by_xai_addto(xai + (size_t)q * N, src + (size_t)q * N, N, rot);
+    }
+    orc_trgsw_to_dft(p, xai_dft, xai, 1, l);
+    orc_external_product(p, out, acc, xai_dft, 1, l, Bg_bit);
+    memcpy(acc, out, sizeof(Torus) * (size_t)2 * N);
+  }
+  free(xai); free(out); free(xai_dft);
+}
+
+/* src/bootstrap.c:192-206 with key->unfolding > 1 */
+void orc_functional_bootstrap_unfolded(const orc_fft_plan *p, Torus *out, const Torus *tv, const Torus *in, const Torus *su, int n, int l, int Bg_bit,
+                                       int torus_base, int unfolding, int extract) {
+  const int N = plan_N(p);
+  int log_N2 = 0;
+  while ((1 << log_N2) < 2 * N) log_N2++;
+  Torus *acc = talloc((size_t)2 * N);
+  const int rot = 2 * N - (int)orc_torus2int(in[n] + orc_double2torus(1. / (4 * torus_base)), log_N2);
+  for (int c = 0; c < 2; c++) orc_poly_mul_by_xai(acc + (size_t)c * N, tv + (size_t)c * N, N, rot);
+  orc_blind_rotate_unfolded(p, acc, in, su, n, l, Bg_bit, unfolding);
+  if (extract) orc_trlwe_extract_tlwe(out, acc, 1, N, 0);
+  else memcpy(out, acc, sizeof(Torus) * (size_t)2 * N);
+  free(acc);
+}

@@ -606,6 +606,23 @@ void ref_full_domain_functional_bootstrap_CLOT21(Torus *out, const Torus *tv, co
   free_trlwe_ks_key(rl);
 }
 
+/* Bootstrap_Key with unfolding > 1 from torus-domain rows su[n 2^u/u][2l][2][N] (what new_bootstrap_key builds at src/bootstrap.c:23-48, minus the
+ * non-reproducible encryption); ref_functional_bootstrap* then take the blind_rotate_unfolded branch (src/bootstrap.c:196-197). */
+void *ref_bk_unfolded_new(const Torus *su_flat, int n, int N, int l, int Bg_bit, int unfolding) {
+  Bootstrap_Key res = (Bootstrap_Key)safe_malloc(sizeof(*res));
+  const int count = n * (1 << unfolding) / unfolding;
+  res->s = NULL;
+  res->n = n; res->k = 1; res->l = l; res->N = N; res->Bg_bit = Bg_bit; res->unfolding = unfolding;
+  res->su = trgsw_alloc_new_sample_array(count, l, Bg_bit, 1, N);
+  const size_t row = (size_t)2 * N, sz = (size_t)2 * l * row;
+  for (int i = 0; i < count; i++)
+    for (int q = 0; q < 2 * l; q++) {
+      memcpy(res->su[i]->samples[q]->a[0]->coeffs, su_flat + i * sz + q * row, sizeof(Torus) * N);
+      memcpy(res->su[i]->samples[q]->b->coeffs, su_flat + i * sz + q * row + N, sizeof(Torus) * N);
+    }
+  return res;
+}
+
 /* ---------- CPU baseline: time `reps` reference programmable bootstraps on the calling thread.
  * Re-entrant across threads once ref_init(N) has run on the main thread (FFT processors are
  * __thread, src/polynomial.c:338-349). Returns elapsed seconds. ---------- */

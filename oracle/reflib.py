@@ -308,6 +308,11 @@ class Ref:
         self.l.ref_full_domain_functional_bootstrap_CLOT21(_u(out), _u(tv), _u(c), bkh, kskh, _u(rl), t, base_bit, precision, variant)
         return out
 
+    def bk_unfolded_new(self, su, l, Bg_bit, unfolding):
+        count, _, _, N = su.shape
+        self.l.ref_bk_unfolded_new.restype = C.c_void_p
+        return C.c_void_p(self.l.ref_bk_unfolded_new(_u(su), count * unfolding >> unfolding, N, l, Bg_bit, unfolding))
+
     def bench_programmable_bootstrap(self, tv, c, h, precision, reps):
         """Seconds for `reps` programmable_bootstrap calls on the calling thread (GIL released)."""
         return self.l.ref_bench_programmable_bootstrap(_u(tv), _u(c), h, precision, reps)

@@ -355,3 +355,26 @@ def test_tensor_product_tlwe_mul_and_fdfb_CLOT21(oracle, ref, wide):
             tol = 2.0 ** (64 - precision - 1)       # the reference test's own bound (test/tests.c:1207)
             assert oracle.torus_dist(oracle.tlwe_phase(mine, s), lut[i]) < tol, (variant, i)
             assert oracle.torus_dist(oracle.tlwe_phase(theirs, s), lut[i]) < tol, (variant, i)
+
+
+@pytest.mark.parametrize("unfolding", [2, 4])
+def test_functional_bootstrap_unfolded(oracle, ref, unfolding):
+    """blind_rotate_unfolded through functional_bootstrap with key->unfolding > 1 (src/bootstrap.c:23-48,124-149,192-206;
+    test_functional_bootstrap_unfolded, test/tests.c:1486-1530): phases agree with the reference and decrypt within 2^58."""
+    rng = oracle.Rng(0xF01D + unfolding)
+    N, n, l, Bg, sigma = 1024, 24, 2, 8, 2.0 ** -40
+    lwe_s = oracle.gen_binary_key(rng, n)
+    s = oracle.gen_binary_key(rng, N)
+    su = oracle.gen_bootstrap_key_unfolded(rng, lwe_s, s, l, Bg, sigma, unfolding)
+    assert su.shape == (n * (1 << unfolding) // unfolding, 2 * l, 2, N)
+    h = ref.bk_unfolded_new(su, l, Bg, unfolding)
+    lut = oracle.u64(rng.words(4))
+    tv = oracle.trlwe_torus_packing(lut, 1, N)
+    for m in range(4):
+        c = oracle.tlwe_sample(rng, oracle.double2torus(m / 8.0), lwe_s, 2.0 ** -20)
+        mine = oracle.functional_bootstrap_unfolded(tv, c, su, l, Bg, 4, unfolding)
+        theirs = ref.functional_bootstrap(tv, c, h, 4)
+        assert oracle.torus_dist(oracle.tlwe_phase(mine, s), lut[m]) < 2.0 ** 58
+        assert oracle.torus_dist(oracle.tlwe_phase(theirs, s), lut[m]) < 2.0 ** 58
+        assert oracle.torus_dist(oracle.tlwe_phase(mine, s), oracle.tlwe_phase(theirs, s)) < 2.0 ** 50
+    ref.bk_free(h)
