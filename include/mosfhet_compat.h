@@ -101,7 +101,7 @@ void free_trgsw(void *p);
 void trgsw_monomial_sample(TRGSW out, int64_t m, int e, TRGSW_Key key);   /* :152-168 */
 
 /* ---- bootstrap (src/bootstrap.c)  -> GPU ---- */
-Bootstrap_Key new_bootstrap_key(TRGSW_Key out_key, TLWE_Key in_key, int unfolding);   /* :3-48 (unfolding must be 1) */
+Bootstrap_Key new_bootstrap_key(TRGSW_Key out_key, TLWE_Key in_key, int unfolding);   /* :3-48 (unfolding 1..8; n divisible by it) */
 void free_bootstrap_key(Bootstrap_Key key);                                            /* :51-61 */
 void blind_rotate(TRLWE tv, Torus *a, TRGSW_DFT *s, int size);                         /* :107-122 */
 void functional_bootstrap_wo_extract(TRLWE out, TRLWE tv, TLWE in, Bootstrap_Key key, int torus_base);  /* :192-198 */
@@ -144,6 +144,33 @@ void circuit_bootstrap_3_batch(TRGSW *out, TLWE *in, int count, Bootstrap_Key ke
 void mosfhet_gen_trlwe_ks_key_flat(Torus *out /*[t][2][N]*/, const Torus *s_in /*[N]*/, TRLWE_Key out_key, int t, int base_bit);
 void mosfhet_gen_priv_ks_key_flat(Torus *out /*[2][t][2][N]*/, TRLWE_Key out_key, TRLWE_Key in_key, int t, int base_bit);
 void mosfhet_gen_packing1_ks_key_flat(Torus *out /*[n][t][2^bb-1][2][N]*/, TRLWE_Key out_key, TLWE_Key in_key, int t, int base_bit);
+
+/* ---- callers either side of the bootstrap  -> GPU compositions ---- */
+Generic_KS_Key trlwe_new_priv_SK_KS_key_N2(TRLWE_Key out_key, TLWE_Key in_key, int t, int base_bit);       /* keyswitch.c:611-637 */
+void trlwe_priv_keyswitch(TRLWE out, TLWE in, Generic_KS_Key ks_key);                                      /* keyswitch.c:639-656 */
+void circuit_bootstrap(TRGSW out, TLWE in, Bootstrap_Key key, Generic_KS_Key kska, Generic_KS_Key kskb);   /* bootstrap.c:309-322 */
+void circuit_bootstrap_2(TRGSW out, TLWE in, Bootstrap_Key key, Generic_KS_Key kska, Generic_KS_Key kskb); /* bootstrap.c:324-344 */
+void circuit_bootstrap_2_batch(TRGSW *out, TLWE *in, int count, Bootstrap_Key key, Generic_KS_Key kska, Generic_KS_Key kskb); /* new */
+/* public_mux: `selector` is an array of l torus-domain TRLWEs (reference: TRLWE_DFT *, bootstrap.c:369; the transform is fused on the GPU) */
+void public_mux(TRLWE out, TorusPolynomial p0, TorusPolynomial p1, TRLWE *selector, int l, int Bg_bit);    /* bootstrap.c:369-389 */
+void full_domain_functional_bootstrap_KS21(TLWE out, TorusPolynomial tv, TLWE in, Bootstrap_Key key, Generic_KS_Key ksk, int torus_base);   /* :391-432 */
+void full_domain_functional_bootstrap_KS21_2(TLWE out, TorusPolynomial tv, TLWE in, Bootstrap_Key key, Generic_KS_Key ksk, int torus_base); /* :434-463 */
+void full_domain_functional_bootstrap_KS21_batch(TLWE *out, TorusPolynomial tv, TLWE *in, int count, Bootstrap_Key key, Generic_KS_Key ksk, int torus_base); /* new */
+TRLWE_KS_Key trlwe_new_RL_key(TRLWE_Key key, int t, int base_bit);                                         /* keyswitch.c:3-10 */
+void trlwe_tensor_prod_FFT(TRLWE out, TRLWE in1, TRLWE in2, int precision, TRLWE_KS_Key rl_key);           /* trlwe.c:727-771 */
+void tlwe_mul(TLWE out, TLWE in1, TLWE in2, int precision, Generic_KS_Key ksk, TRLWE_KS_Key rlk);          /* tlwe.c:322-332 */
+void full_domain_functional_bootstrap_CLOT21(TLWE out, TRLWE tv[2], TLWE in, Bootstrap_Key key, Generic_KS_Key ksk, TRLWE_KS_Key rlk, int precision);   /* bootstrap.c:465-491 */
+void full_domain_functional_bootstrap_CLOT21_2(TLWE out, Torus *tv, TLWE in, Bootstrap_Key key, Generic_KS_Key ksk, TRLWE_KS_Key rlk, int precision);   /* :493-517 */
+void full_domain_functional_bootstrap_CLOT21_2_batch(TLWE *out, Torus *tv, TLWE *in, int count, Bootstrap_Key key, Generic_KS_Key ksk, TRLWE_KS_Key rlk,
+                                                     int precision);                                       /* new */
+void multivalue_bootstrap_phase1(TRLWE *out, TLWE in, Bootstrap_Key key, int torus_base);                  /* bootstrap.c:232-243 */
+void multivalue_bootstrap_phase2(TLWE out, int *in, TRLWE *rotated_tv, int torus_base, int log_torus_base);/* bootstrap.c:245-265 */
+TRGSW_DFT trgsw_alloc_new_DFT_sample(int l, int Bg_bit, int k, int N);                                     /* trgsw.c:61-72; device resident */
+void free_trgsw_DFT(TRGSW_DFT p);                                                                          /* (reference: free_trgsw) */
+void functional_bootstrap_trgsw_phase1(TRGSW_DFT out, TLWE in, Bootstrap_Key key, int torus_base);         /* bootstrap.c:284-295 */
+void functional_bootstrap_trgsw_phase2(TLWE out, TRGSW_DFT in, TRLWE tv);                                  /* bootstrap.c:297-306 */
+void mosfhet_gen_priv_sk_ks_key_flat(Torus *out /*[n+1][t][2^bb-1][2][N]*/, TRLWE_Key out_key, TLWE_Key in_key, int t, int base_bit);
+void mosfhet_gen_bootstrap_key_unfolded_flat(Torus *out /*[n 2^u/u][2l][2][N]*/, TRGSW_Key out_key, TLWE_Key in_key, int unfolding);
 
 /* ---- batch extensions (new): arrays of `count` samples, one shared test vector ---- */
 void functional_bootstrap_batch(TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_Key key, int torus_base);

@@ -14,12 +14,12 @@ LIB = os.path.join(HERE, "libmosfhet_hip.so")
 
 HIP_SOURCES = ["capi.hip"]
 HOST_C_SOURCES = ["host/mosfhet_compat.c"]
-DEPS = ["negacyclic_fft.h", "bootstrap_kernels.h", "keyswitch_kernels.h", "../../include/mosfhet_hip.h",
-        "../../include/mosfhet_compat.h"]
+DEPS = ["negacyclic_fft.h", "bootstrap_kernels.h", "keyswitch_kernels.h", "ext_kernels.h", "capi_ext.inc", "../../include/mosfhet_hip.h",
+        "../../include/mosfhet_compat.h", "../build.py"]
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value",
                "-Wno-comment"]
-CC_FLAGS = ["-O2", "-std=gnu11", "-fPIC", "-ffp-contract=off", "-Wall"]
+CC_FLAGS = ["-O3", "-mavx2", "-std=gnu11", "-fPIC", "-ffp-contract=off", "-Wall"]  # -O3 -mavx2: vectorised host key generation
 
 
 def _hipcc():

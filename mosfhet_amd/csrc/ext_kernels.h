@@ -79,9 +79,9 @@ __global__ __launch_bounds__(F::THREADS, 2) void public_mux_kernel(const uint64_
 __global__ void ks21_sign_lut_kernel(uint64_t *__restrict__ tv, int N, int l, int Bg_bit, int half_base) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= N) return;
-  const int span = N / (half_base * l), j = (x / span) % l;
+  const int span = N / (half_base * l), idx = x / span, j = idx % l;   // integer division as the reference: a tail stays zero
   tv[x] = 0;
-  tv[N + x] = ~0ull << (64 - (j + 1) * Bg_bit - 1);
+  tv[N + x] = idx < half_base * l ? ~0ull << (64 - (j + 1) * Bg_bit - 1) : 0;
 }
 
 // p0[i] = tv[i], p1[i] = -tv[i + N]  [src/bootstrap.c:417-421]
@@ -233,7 +233,7 @@ __global__ void clot21_lut_kernel(uint64_t *__restrict__ tv, const uint64_t *__r
   if (x >= N) return;
   const int span = N / (4 * torus_base), idx = x / span, j = idx % 4, i = idx / 4;
   tv[x] = 0;
-  tv[N + x] = j < 2 ? lut[j * torus_base + i] : (j == 2 ? sign : 0);
+  tv[N + x] = i >= torus_base ? 0 : (j < 2 ? lut[j * torus_base + i] : (j == 2 ? sign : 0));
 }
 
 // Blind rotation with unfolding u > 1 [src/bootstrap.c:124-149]: per group of u mask words, the TRGSW  xai = sum_j X^(rot_j) su_j  is

@@ -431,21 +431,44 @@ static void forget_key(Bootstrap_Key key) {
 /* Bootstrap_Key.s is an opaque token: a one-element array holding the device key handle. */
 void *mosfhet_bootstrap_key_device(Bootstrap_Key key) { return key && key->s ? (void *)key->s[0] : NULL; }
 
+/* src/bootstrap.c:23-48: 2^u torus-domain TRGSW samples per group of u key bits, su[i 2^u/u + j] = TRGSW(indicator of bit pattern j) */
+void mosfhet_gen_bootstrap_key_unfolded_flat(Torus *out, TRGSW_Key out_key, TLWE_Key in_key, int unfolding) {
+  const int l = out_key->l, N = out_key->trlwe_key->s[0]->N, key_exp = 1 << unfolding, final_exp = key_exp / unfolding;
+  const size_t row = (size_t)2 * N, sz = (size_t)2 * l * row;
+  TRGSW tmp = trgsw_alloc_new_sample(l, out_key->Bg_bit, 1, N);
+  for (int i = 0; i < in_key->n; i += unfolding)
+    for (int j = 0; j < key_exp; j++) {
+      Torus key = 1;
+      for (int u = 0, j_ = j; u < unfolding; u++, j_ >>= 1) key *= (j_ & 1) ? in_key->s[i + u] : 1 - in_key->s[i + u];
+      trgsw_monomial_sample(tmp, (int64_t)key, 0, out_key);
+      for (int q = 0; q < 2 * l; q++) trlwe_to_flat(out + ((size_t)i * final_exp + j) * sz + q * row, tmp->samples[q]);
+    }
+  free_trgsw(tmp);
+}
+
 Bootstrap_Key new_bootstrap_key(TRGSW_Key out_key, TLWE_Key in_key, int unfolding) {
-  if (unfolding != 1) {
-    fprintf(stderr, "mosfhet_amd: new_bootstrap_key: blind-rotate unfolding is not provided (unfolding = %d)\n", unfolding);
+  const int l = out_key->l, k = out_key->trlwe_key->k, N = out_key->trlwe_key->s[0]->N, n = in_key->n;
+  if (unfolding < 1 || unfolding > 8 || n % unfolding || (unfolding > 1 && k != 1)) {
+    fprintf(stderr, "mosfhet_amd: new_bootstrap_key: unfolding = %d needs 1 <= unfolding <= 8, n divisible by it (test/tests.c:34), k = 1\n", unfolding);
     abort();
   }
-  const int l = out_key->l, k = out_key->trlwe_key->k, N = out_key->trlwe_key->s[0]->N, n = in_key->n;
   Bootstrap_Key res = (Bootstrap_Key)xmalloc(sizeof(*res));
-  res->n = n; res->k = k; res->l = l; res->N = N; res->Bg_bit = out_key->Bg_bit; res->unfolding = 1;
-  res->su = NULL;
-  const size_t words = (size_t)n * (k + 1) * l * (k + 1) * N;
-  Torus *flat = (Torus *)xmalloc(sizeof(Torus) * words);
-  mosfhet_gen_bootstrap_key_flat(flat, out_key, in_key);
+  res->n = n; res->k = k; res->l = l; res->N = N; res->Bg_bit = out_key->Bg_bit; res->unfolding = unfolding;
+  res->su = NULL;   /* device resident as well (reference: host TRGSW array, src/bootstrap.c:35) */
   mosfhet_hip_bsk_t dev = NULL;
-  if (mosfhet_hip_bsk_create((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, flat, n, k, N, l, out_key->Bg_bit)) die("new_bootstrap_key");
-  free(flat);
+  if (unfolding == 1) {
+    const size_t words = (size_t)n * (k + 1) * l * (k + 1) * N;
+    Torus *flat = (Torus *)xmalloc(sizeof(Torus) * words);
+    mosfhet_gen_bootstrap_key_flat(flat, out_key, in_key);
+    if (mosfhet_hip_bsk_create((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, flat, n, k, N, l, out_key->Bg_bit)) die("new_bootstrap_key");
+    free(flat);
+  } else {
+    const size_t words = (size_t)n * ((size_t)1 << unfolding) / unfolding * 2 * l * 2 * N;
+    Torus *flat = (Torus *)xmalloc(sizeof(Torus) * words);
+    mosfhet_gen_bootstrap_key_unfolded_flat(flat, out_key, in_key, unfolding);
+    if (mosfhet_hip_bsk_unfolded_create((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, flat, n, N, l, out_key->Bg_bit, unfolding)) die("new_bootstrap_key (unfolded)");
+    free(flat);
+  }
   res->s = (TRGSW_DFT *)xmalloc(sizeof(TRGSW_DFT));
   res->s[0] = (TRGSW_DFT)dev;
   remember_key(res);
@@ -925,4 +948,267 @@ void circuit_bootstrap_3_batch(TRGSW *out, TLWE *in, int count, Bootstrap_Key ke
 
 void circuit_bootstrap_3(TRGSW out, TLWE in, Bootstrap_Key key, TRLWE_KS_Key *kska, Generic_KS_Key kskb) {
   circuit_bootstrap_3_batch(&out, &in, 1, key, kska, kskb);
+}
+
+/* ------------------------------------------------------------------ callers either side of the bootstrap (GPU compositions) */
+typedef struct { Torus *h, *d; size_t words; } Buf;
+static Buf buf_new(size_t words) {
+  Buf b;
+  b.words = words;
+  b.h = (Torus *)xmalloc(sizeof(Torus) * (words ? words : 1));
+  b.d = (Torus *)dev_alloc(sizeof(Torus) * (words ? words : 1));
+  return b;
+}
+static void buf_up(Buf *b, size_t off, size_t words) { dev_copy(b->d + off, b->h + off, sizeof(Torus) * words, HIP_H2D); }
+static void buf_down(Buf *b, size_t off, size_t words) { dev_copy(b->h + off, b->d + off, sizeof(Torus) * words, HIP_D2H); }
+static void buf_free(Buf *b) { hipFree(b->d); free(b->h); }
+static mosfhet_hip_ctx_t ectx(void) { return (mosfhet_hip_ctx_t)mosfhet_engine_ctx(); }
+static void check_rc(int rc, const char *what) { if (rc || mosfhet_hip_ctx_sync(ectx(), NULL)) die(what); }
+
+/* s[i][j][v-1] = TRLWE_out( -s_out * s_i v 2^(64-(j+1)bb) ), i <= n, s_n = -1 for the b word   [src/keyswitch.c:611-637] */
+void mosfhet_gen_priv_sk_ks_key_flat(Torus *out, TRLWE_Key out_key, TLWE_Key in_key, int t, int base_bit) {
+  const int N = out_key->s[0]->N, base = 1 << base_bit;
+  TRLWE tmp = trlwe_alloc_new_sample(1, N);
+  for (int i = 0; i <= in_key->n; i++) {
+    const Torus s_i = i < in_key->n ? in_key->s[i] : (Torus)-1;
+    for (int j = 0; j < t; j++)
+      for (int v = 1; v < base; v++) {
+        const Torus dec_key = s_i * (Torus)v * ((Torus)1 << (W - (j + 1) * base_bit));
+        trlwe_sample(tmp, NULL, out_key);
+        for (int e = 0; e < N; e++) tmp->b->coeffs[e] += ((Torus)0 - out_key->s[0]->coeffs[e]) * dec_key;
+        trlwe_to_flat(out + ((((size_t)i * t + j) * (base - 1)) + (v - 1)) * 2 * N, tmp);
+      }
+  }
+  free_trlwe(tmp);
+}
+
+Generic_KS_Key trlwe_new_priv_SK_KS_key_N2(TRLWE_Key out_key, TLWE_Key in_key, int t, int base_bit) {
+  const int N = out_key->s[0]->N, base = 1 << base_bit;
+  if (out_key->k != 1) { fprintf(stderr, "mosfhet_amd: trlwe_new_priv_SK_KS_key_N2: k = 1 only\n"); abort(); }
+  Generic_KS_Key res = (Generic_KS_Key)xmalloc(sizeof(*res));
+  res->s = NULL; res->base_bit = base_bit; res->t = t; res->n = in_key->n; res->include_b = 1;
+  Torus *flat = (Torus *)xmalloc(sizeof(Torus) * ((size_t)in_key->n + 1) * t * (base - 1) * 2 * N);
+  mosfhet_gen_priv_sk_ks_key_flat(flat, out_key, in_key, t, base_bit);
+  mosfhet_hip_ksk_t dev = NULL;
+  if (mosfhet_hip_priv_ksk_create(ectx(), &dev, flat, in_key->n, N, t, base_bit)) die("trlwe_new_priv_SK_KS_key_N2");
+  free(flat);
+  res->device = dev;
+  return res;
+}
+
+void trlwe_priv_keyswitch(TRLWE out, TLWE in, Generic_KS_Key ks) {
+  const int N = out->b->N, n = ks->n;
+  Buf b = buf_new((size_t)n + 1 + 2 * N);
+  tlwe_array_to_flat(b.h, &in, 1, n);
+  buf_up(&b, 0, (size_t)n + 1);
+  check_rc(mosfhet_hip_trlwe_priv_keyswitch_batch(ectx(), (mosfhet_hip_ksk_t)ks->device, b.d + n + 1, b.d, 1, NULL), "trlwe_priv_keyswitch");
+  buf_down(&b, (size_t)n + 1, (size_t)2 * N);
+  trlwe_from_flat(out, b.h + n + 1);
+  buf_free(&b);
+}
+
+static void circuit_bootstrap_many(TRGSW *out, TLWE *in, int count, Bootstrap_Key key, Generic_KS_Key kska, Generic_KS_Key kskb, int variant) {
+  const int n = key->n, N = key->N, l = key->l;
+  const size_t in_w = (size_t)count * (n + 1), row = (size_t)2 * N, out_w = (size_t)count * 2 * l * row;
+  Buf b = buf_new(in_w + out_w);
+  tlwe_array_to_flat(b.h, in, count, n);
+  buf_up(&b, 0, in_w);
+  check_rc(mosfhet_hip_circuit_bootstrap_batch(ectx(), (mosfhet_hip_bsk_t)key->s[0], (mosfhet_hip_ksk_t)kska->device, (mosfhet_hip_ksk_t)kskb->device, b.d + in_w,
+                                               b.d, count, variant, NULL), "circuit_bootstrap");
+  buf_down(&b, in_w, out_w);
+  for (int c = 0; c < count; c++)
+    for (int q = 0; q < 2 * l; q++) trlwe_from_flat(out[c]->samples[q], b.h + in_w + ((size_t)c * 2 * l + q) * row);
+  buf_free(&b);
+}
+
+void circuit_bootstrap(TRGSW out, TLWE in, Bootstrap_Key key, Generic_KS_Key kska, Generic_KS_Key kskb) { circuit_bootstrap_many(&out, &in, 1, key, kska, kskb, 0); }
+void circuit_bootstrap_2(TRGSW out, TLWE in, Bootstrap_Key key, Generic_KS_Key kska, Generic_KS_Key kskb) { circuit_bootstrap_many(&out, &in, 1, key, kska, kskb, 1); }
+void circuit_bootstrap_2_batch(TRGSW *out, TLWE *in, int count, Bootstrap_Key key, Generic_KS_Key kska, Generic_KS_Key kskb) {
+  circuit_bootstrap_many(out, in, count, key, kska, kskb, 1);
+}
+
+void public_mux(TRLWE out, TorusPolynomial p0, TorusPolynomial p1, TRLWE *selector, int l, int Bg_bit) {
+  const int N = out->b->N;
+  const size_t row = (size_t)2 * N;
+  Buf b = buf_new(2 * (size_t)N + l * row + row);
+  memcpy(b.h, p0->coeffs, sizeof(Torus) * N);
+  memcpy(b.h + N, p1->coeffs, sizeof(Torus) * N);
+  for (int i = 0; i < l; i++) trlwe_to_flat(b.h + 2 * N + i * row, selector[i]);
+  buf_up(&b, 0, 2 * (size_t)N + l * row);
+  check_rc(mosfhet_hip_public_mux_batch(ectx(), b.d + 2 * N + l * row, b.d, b.d + N, b.d + 2 * N, N, l, Bg_bit, 1, NULL), "public_mux");
+  buf_down(&b, 2 * (size_t)N + l * row, row);
+  trlwe_from_flat(out, b.h + 2 * N + l * row);
+  buf_free(&b);
+}
+
+static void fdfb_ks21_many(TLWE *out, TorusPolynomial tv, TLWE *in, int count, Bootstrap_Key key, Generic_KS_Key ksk, int torus_base, int variant) {
+  const int n = key->n, N = key->N;
+  const size_t in_w = (size_t)count * (n + 1), tv_w = (size_t)2 * N, out_w = (size_t)count * (N + 1);
+  if (tv->N != 2 * N) { fprintf(stderr, "mosfhet_amd: full_domain_functional_bootstrap_KS21: tv must have 2N coefficients\n"); abort(); }
+  Buf b = buf_new(in_w + tv_w + out_w);
+  tlwe_array_to_flat(b.h, in, count, n);
+  memcpy(b.h + in_w, tv->coeffs, sizeof(Torus) * tv_w);
+  buf_up(&b, 0, in_w + tv_w);
+  check_rc(mosfhet_hip_full_domain_functional_bootstrap_KS21_batch(ectx(), (mosfhet_hip_bsk_t)key->s[0], (mosfhet_hip_ksk_t)ksk->device, b.d + in_w + tv_w, b.d + in_w,
+                                                                   b.d, count, torus_base, variant, NULL), "full_domain_functional_bootstrap_KS21");
+  buf_down(&b, in_w + tv_w, out_w);
+  tlwe_array_from_flat(out, b.h + in_w + tv_w, count, N);
+  buf_free(&b);
+}
+
+void full_domain_functional_bootstrap_KS21(TLWE out, TorusPolynomial tv, TLWE in, Bootstrap_Key key, Generic_KS_Key ksk, int torus_base) {
+  fdfb_ks21_many(&out, tv, &in, 1, key, ksk, torus_base, 0);
+}
+void full_domain_functional_bootstrap_KS21_2(TLWE out, TorusPolynomial tv, TLWE in, Bootstrap_Key key, Generic_KS_Key ksk, int torus_base) {
+  fdfb_ks21_many(&out, tv, &in, 1, key, ksk, torus_base, 1);
+}
+void full_domain_functional_bootstrap_KS21_batch(TLWE *out, TorusPolynomial tv, TLWE *in, int count, Bootstrap_Key key, Generic_KS_Key ksk, int torus_base) {
+  fdfb_ks21_many(out, tv, in, count, key, ksk, torus_base, 0);
+}
+
+TRLWE_KS_Key trlwe_new_RL_key(TRLWE_Key key, int t, int base_bit) {
+  const int N = key->s[0]->N;
+  if (key->k != 1) { fprintf(stderr, "mosfhet_amd: trlwe_new_RL_key: k = 1 only\n"); abort(); }
+  Torus *s2 = (Torus *)xmalloc(sizeof(Torus) * (size_t)N), *flat = (Torus *)xmalloc(sizeof(Torus) * (size_t)t * 2 * N);
+  memset(s2, 0, sizeof(Torus) * (size_t)N);
+  negacyclic_mul_addto(s2, key->s[0]->coeffs, key->s[0]->coeffs, N);   /* s^2 (src/keyswitch.c:6) */
+  mosfhet_gen_trlwe_ks_key_flat(flat, s2, key, t, base_bit);
+  mosfhet_hip_gak_t dev = NULL;
+  if (mosfhet_hip_trlwe_ksk_create(ectx(), &dev, flat, 1, N, t, base_bit)) die("trlwe_new_RL_key");
+  free(s2);
+  free(flat);
+  return trlwe_ks_header(dev, 0, 1, t, base_bit);
+}
+
+void trlwe_tensor_prod_FFT(TRLWE out, TRLWE in1, TRLWE in2, int precision, TRLWE_KS_Key rl_key) {
+  const int N = in1->b->N;
+  const size_t row = (size_t)2 * N;
+  Buf b = buf_new(3 * row);
+  trlwe_to_flat(b.h, in1);
+  trlwe_to_flat(b.h + row, in2);
+  buf_up(&b, 0, 2 * row);
+  check_rc(mosfhet_hip_trlwe_tensor_prod_FFT_batch(ectx(), (mosfhet_hip_gak_t)rl_key->device, b.d + 2 * row, b.d, b.d + row, precision, 1, NULL), "trlwe_tensor_prod_FFT");
+  buf_down(&b, 2 * row, row);
+  trlwe_from_flat(out, b.h + 2 * row);
+  buf_free(&b);
+}
+
+void tlwe_mul(TLWE out, TLWE in1, TLWE in2, int precision, Generic_KS_Key ksk, TRLWE_KS_Key rlk) {
+  const int N = in1->n;
+  const size_t w = (size_t)N + 1;
+  Buf b = buf_new(3 * w);
+  tlwe_array_to_flat(b.h, &in1, 1, N);
+  tlwe_array_to_flat(b.h + w, &in2, 1, N);
+  buf_up(&b, 0, 2 * w);
+  check_rc(mosfhet_hip_tlwe_mul_batch(ectx(), (mosfhet_hip_ksk_t)ksk->device, (mosfhet_hip_gak_t)rlk->device, b.d + 2 * w, b.d, b.d + w, precision, 1, NULL), "tlwe_mul");
+  buf_down(&b, 2 * w, w);
+  tlwe_array_from_flat(&out, b.h + 2 * w, 1, N);
+  buf_free(&b);
+}
+
+static void fdfb_clot21_many(TLWE *out, const Torus *tv_flat, size_t tv_w, TLWE *in, int count, Bootstrap_Key key, Generic_KS_Key ksk, TRLWE_KS_Key rlk, int precision,
+                             int variant) {
+  const int n = key->n, N = key->N;
+  const size_t in_w = (size_t)count * (n + 1), out_w = (size_t)count * (N + 1);
+  Buf b = buf_new(in_w + tv_w + out_w);
+  tlwe_array_to_flat(b.h, in, count, n);
+  memcpy(b.h + in_w, tv_flat, sizeof(Torus) * tv_w);
+  buf_up(&b, 0, in_w + tv_w);
+  check_rc(mosfhet_hip_full_domain_functional_bootstrap_CLOT21_batch(ectx(), (mosfhet_hip_bsk_t)key->s[0], (mosfhet_hip_ksk_t)ksk->device, (mosfhet_hip_gak_t)rlk->device,
+                                                                     b.d + in_w + tv_w, b.d + in_w, b.d, count, precision, variant, NULL),
+           "full_domain_functional_bootstrap_CLOT21");
+  buf_down(&b, in_w + tv_w, out_w);
+  tlwe_array_from_flat(out, b.h + in_w + tv_w, count, N);
+  buf_free(&b);
+}
+
+void full_domain_functional_bootstrap_CLOT21(TLWE out, TRLWE tv[2], TLWE in, Bootstrap_Key key, Generic_KS_Key ksk, TRLWE_KS_Key rlk, int precision) {
+  const size_t row = (size_t)2 * key->N;
+  Torus *flat = (Torus *)xmalloc(sizeof(Torus) * 2 * row);
+  trlwe_to_flat(flat, tv[0]);
+  trlwe_to_flat(flat + row, tv[1]);
+  fdfb_clot21_many(&out, flat, 2 * row, &in, 1, key, ksk, rlk, precision, 0);
+  free(flat);
+}
+
+void full_domain_functional_bootstrap_CLOT21_2(TLWE out, Torus *tv, TLWE in, Bootstrap_Key key, Generic_KS_Key ksk, TRLWE_KS_Key rlk, int precision) {
+  fdfb_clot21_many(&out, tv, (size_t)1 << (precision - 1), &in, 1, key, ksk, rlk, precision, 1);
+}
+
+void full_domain_functional_bootstrap_CLOT21_2_batch(TLWE *out, Torus *tv, TLWE *in, int count, Bootstrap_Key key, Generic_KS_Key ksk, TRLWE_KS_Key rlk, int precision) {
+  fdfb_clot21_many(out, tv, (size_t)1 << (precision - 1), in, count, key, ksk, rlk, precision, 1);
+}
+
+void multivalue_bootstrap_phase1(TRLWE *out, TLWE in, Bootstrap_Key key, int torus_base) {
+  const int n = key->n, N = key->N;
+  const size_t row = (size_t)2 * N, out_w = (size_t)(torus_base + 1) * row;
+  Buf b = buf_new((size_t)n + 1 + out_w);
+  tlwe_array_to_flat(b.h, &in, 1, n);
+  buf_up(&b, 0, (size_t)n + 1);
+  check_rc(mosfhet_hip_multivalue_bootstrap_phase1_batch(ectx(), (mosfhet_hip_bsk_t)key->s[0], b.d + n + 1, b.d, 1, torus_base, NULL), "multivalue_bootstrap_phase1");
+  buf_down(&b, (size_t)n + 1, out_w);
+  for (int i = 0; i <= torus_base; i++) trlwe_from_flat(out[i], b.h + n + 1 + i * row);
+  buf_free(&b);
+}
+
+void multivalue_bootstrap_phase2(TLWE out, int *in, TRLWE *rotated_tv, int torus_base, int log_torus_base) {
+  const int N = rotated_tv[0]->b->N;
+  const size_t row = (size_t)2 * N, in_w = (size_t)(torus_base + 1) * row;
+  Buf b = buf_new(in_w + N + 1);
+  for (int i = 0; i <= torus_base; i++) trlwe_to_flat(b.h + i * row, rotated_tv[i]);
+  buf_up(&b, 0, in_w);
+  check_rc(mosfhet_hip_multivalue_bootstrap_phase2_batch(ectx(), b.d + in_w, in, b.d, N, torus_base, log_torus_base, 1, NULL), "multivalue_bootstrap_phase2");
+  buf_down(&b, in_w, (size_t)N + 1);
+  tlwe_array_from_flat(&out, b.h + in_w, 1, N);
+  buf_free(&b);
+}
+
+/* TRGSW_DFT: device-resident [2l][2][N/2] complex (reference: host struct, mosfhet.h:111-114) */
+struct _TRGSW_DFT { double *device; int l, Bg_bit, N; };
+
+TRGSW_DFT trgsw_alloc_new_DFT_sample(int l, int Bg_bit, int k, int N) {
+  if (k != 1) { fprintf(stderr, "mosfhet_amd: trgsw_alloc_new_DFT_sample: k = 1 only\n"); abort(); }
+  TRGSW_DFT res = (TRGSW_DFT)xmalloc(sizeof(*res));
+  res->l = l; res->Bg_bit = Bg_bit; res->N = N;
+  res->device = (double *)dev_alloc(sizeof(double) * (size_t)2 * l * 2 * N);
+  return res;
+}
+
+void free_trgsw_DFT(TRGSW_DFT p) {
+  if (!p) return;
+  hipFree(p->device);
+  free(p);
+}
+
+void functional_bootstrap_trgsw_phase1(TRGSW_DFT out, TLWE in, Bootstrap_Key key, int torus_base) {
+  const int n = key->n;
+  Buf b = buf_new((size_t)n + 1);
+  tlwe_array_to_flat(b.h, &in, 1, n);
+  buf_up(&b, 0, (size_t)n + 1);
+  check_rc(mosfhet_hip_functional_bootstrap_trgsw_phase1_batch(ectx(), (mosfhet_hip_bsk_t)key->s[0], out->device, b.d, 1, torus_base, NULL), "functional_bootstrap_trgsw_phase1");
+  buf_free(&b);
+}
+
+void functional_bootstrap_trgsw_phase2_key(TLWE out, TRGSW_DFT in, TRLWE tv, Bootstrap_Key key) {
+  const int N = tv->b->N;
+  const size_t row = (size_t)2 * N;
+  Buf b = buf_new(row + N + 1);
+  trlwe_to_flat(b.h, tv);
+  buf_up(&b, 0, row);
+  check_rc(mosfhet_hip_functional_bootstrap_trgsw_phase2_batch(ectx(), (mosfhet_hip_bsk_t)key->s[0], b.d + row, in->device, b.d, 1, 1, NULL), "functional_bootstrap_trgsw_phase2");
+  buf_down(&b, row, (size_t)N + 1);
+  tlwe_array_from_flat(&out, b.h + row, 1, N);
+  buf_free(&b);
+}
+
+/* the reference's signature has no key argument (src/bootstrap.c:297); the gadget comes from the TRGSW_DFT, the engine handle from
+ * any registered bootstrap key of that ring and gadget */
+void functional_bootstrap_trgsw_phase2(TLWE out, TRGSW_DFT in, TRLWE tv) {
+  for (int i = 0; i < MAX_KEYS; i++)
+    if (g_keys[i] && g_keys[i]->unfolding == 1 && g_keys[i]->N == in->N && g_keys[i]->l == in->l && g_keys[i]->Bg_bit == in->Bg_bit) {
+      functional_bootstrap_trgsw_phase2_key(out, in, tv, g_keys[i]);
+      return;
+    }
+  fprintf(stderr, "mosfhet_amd: functional_bootstrap_trgsw_phase2: no bootstrap key with this ring / gadget is alive\n");
+  abort();
 }

@@ -183,7 +183,7 @@ void orc_circuit_bootstrap(const orc_fft_plan *p, Torus *out, const Torus *in, c
     }
   } else {
     const int slot_size = N / (2 * l);
-    Torus *lut = talloc((size_t)2 * l);
+    Torus *lut = talloc((size_t)2 * l + 1);   /* + 1: trlwe_torus_packing indexes lut[2l] for the last coefficients when 2l does not divide N */
     for (int i = 0; i < l; i++) lut[l + i] = (Torus)1 << (W - (i + 1) * Bg_bit);
     orc_trlwe_torus_packing(tv, lut, 1, N, 2 * l);
     orc_functional_bootstrap_wo_extract(p, tmp, tv, in, bk_dft, n, 1, l, Bg_bit, 2 * l);

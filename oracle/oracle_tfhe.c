@@ -333,7 +333,7 @@ void orc_circuit_bootstrap_3(const orc_fft_plan *p, Torus *out, const Torus *in,
   int cnt = 0;
   (void)orc_fft_twiddles(p, &cnt);
   const int N = 2 * (cnt + 1), slot_size = N / (2 * l);
-  Torus *lut = (Torus *)calloc((size_t)2 * l, sizeof(Torus));
+  Torus *lut = (Torus *)calloc((size_t)2 * l + 1, sizeof(Torus));
   Torus *tv = (Torus *)malloc(sizeof(Torus) * (size_t)2 * N), *acc = (Torus *)malloc(sizeof(Torus) * (size_t)2 * N);
   Torus *ext = (Torus *)malloc(sizeof(Torus) * (size_t)(N + 1));
   for (int i = 0; i < l; i++) lut[l + i] = (Torus)1 << (W - (i + 1) * Bg_bit);

@@ -206,7 +206,134 @@ static void case_circuit_bootstrap(void) {
   free_bootstrap_key(cbk); free_trgsw_key(gkey); free_tlwe_key(ckey_extracted); free_trlwe_key(ckey);
 }
 
+/* ---- the wider callers: one low-noise key set (2^-44, gadget l = 4, Bg = 2^9) shared by the cases below ---- */
+enum { wl = 4, wBg = 9 };
+static TRLWE_Key wkey;
+static TLWE_Key wkey_extracted;
+static TRGSW_Key wgkey;
+static Bootstrap_Key wbk;
+static Generic_KS_Key wpack, wpriv;
+static void wide_setup(void) {
+  if (wkey) return;
+  wkey = trlwe_new_binary_key(N, k, 5.684341886080802e-14);
+  wkey_extracted = tlwe_alloc_key(N, wkey->sigma);
+  trlwe_extract_tlwe_key(wkey_extracted, wkey);
+  wgkey = trgsw_new_key(wkey, wl, wBg);
+  wbk = new_bootstrap_key(wgkey, lwe_key, 1);
+  wpack = trlwe_new_packing1_KS_key(wkey, wkey_extracted, 12, 2);
+  wpriv = trlwe_new_priv_SK_KS_key_N2(wkey, wkey_extracted, 6, 3);
+}
+
+/* test_functional_bootstrap_unfolded (test/tests.c:1486-1530): same calls, key made with unfolding = 2 and 4 */
+static void case_unfolded(void) {
+  wide_setup();
+  Torus lut[4] = {int2torus(1, 4), int2torus(5, 4), int2torus(9, 4), int2torus(13, 4)};
+  TRLWE tv = trlwe_alloc_new_sample(k, N);
+  trlwe_torus_packing(tv, lut, 4);
+  TLWE out = tlwe_alloc_sample(N);
+  for (int u = 2; u <= 4; u += 2) {
+    Bootstrap_Key ubk = new_bootstrap_key(wgkey, lwe_key, u);
+    for (int j = 0; j < 4; j++) {
+      TLWE in = tlwe_new_sample(double2torus(j / 8.), lwe_key);
+      functional_bootstrap(out, tv, in, ubk, 4);
+      WITHIN(1ULL << 58, lut[j], tlwe_phase(out, wkey_extracted), "functional_bootstrap (unfolded key)");
+      free_tlwe(in);
+    }
+    free_bootstrap_key(ubk);
+  }
+  free_tlwe(out); free_trlwe(tv);
+}
+
+/* test_FDFB_KS21 (test/tests.c:1058-1092) and test_FDFB_CLOT21_2 (:1179-1218) */
+static void case_fdfb_variants(void) {
+  wide_setup();
+  Torus in8[8];
+  for (int i = 0; i < 8; i++) in8[i] = int2torus((uint64_t)((5 * i + 3) & 15), 4);
+  TorusPolynomial poly = polynomial_new_torus_polynomial(2 * N);
+  for (int i = 0; i < 2 * N; i++) poly->coeffs[i] = in8[i / (N / 4)];
+  TRLWE_KS_Key rlk = trlwe_new_RL_key(wkey, 2, 20);
+  TLWE out = tlwe_alloc_sample(N);
+  for (int i = 0; i < 8; i++) {
+    TLWE c = tlwe_new_sample(int2torus((uint64_t)i, 3), lwe_key);
+    full_domain_functional_bootstrap_KS21(out, poly, c, wbk, wpack, 8);
+    WITHIN(1ULL << 58, in8[i], tlwe_phase(out, wkey_extracted), "full_domain_functional_bootstrap_KS21");
+    full_domain_functional_bootstrap_KS21_2(out, poly, c, wbk, wpack, 8);
+    WITHIN(1ULL << 58, in8[i], tlwe_phase(out, wkey_extracted), "full_domain_functional_bootstrap_KS21_2");
+    full_domain_functional_bootstrap_CLOT21_2(out, in8, c, wbk, wpack, rlk, 4);
+    WITHIN(1ULL << (64 - 4 - 1), in8[i], tlwe_phase(out, wkey_extracted), "full_domain_functional_bootstrap_CLOT21_2");
+    free_tlwe(c);
+  }
+  /* tlwe_mul (src/tlwe.c:322-332): 3/16 * 2/16 * 2^4 = 6/16 */
+  TLWE a = tlwe_new_sample(int2torus(3, 4), wkey_extracted), b = tlwe_new_sample(int2torus(2, 4), wkey_extracted);
+  tlwe_mul(out, a, b, 4, wpack, rlk);
+  WITHIN(1ULL << 58, int2torus(6, 4), tlwe_phase(out, wkey_extracted), "tlwe_mul");
+  free_tlwe(a); free_tlwe(b); free_tlwe(out); free_polynomial(poly); free_trlwe_ks_key(rlk);
+}
+
+/* test_multivalue_bootstrap (test/tests.c:899-929 pattern): phase 1 once per input, phase 2 once per cleartext LUT */
+static void case_multivalue_phases(void) {
+  wide_setup();
+  enum { tb = 4, log_tb = 2 };
+  TRLWE rotated[tb + 1];
+  for (int i = 0; i <= tb; i++) rotated[i] = trlwe_alloc_new_sample(k, N);
+  TLWE out = tlwe_alloc_sample(N);
+  int luts[3][tb] = {{0, 1, 2, 3}, {3, 1, 0, 2}, {2, 2, 1, 0}};
+  for (int m = 0; m < tb; m++) {
+    TLWE in = tlwe_new_sample(double2torus(m / 8.), lwe_key);
+    multivalue_bootstrap_phase1(rotated, in, wbk, tb);
+    for (int f = 0; f < 3; f++) {
+      multivalue_bootstrap_phase2(out, luts[f], rotated, tb, log_tb);
+      WITHIN(1ULL << 58, int2torus((uint64_t)luts[f][m], log_tb + 1), tlwe_phase(out, wkey_extracted), "multivalue_bootstrap_phase2");
+    }
+    free_tlwe(in);
+  }
+  for (int i = 0; i <= tb; i++) free_trlwe(rotated[i]);
+  free_tlwe(out);
+}
+
+/* circuit_bootstrap_2 with the table-lookup private key switch (src/bootstrap.c:324-344, src/keyswitch.c:639-656), public_mux with
+ * the fresh TRGSW rows as selector (src/bootstrap.c:369-389), and the TRGSW-accumulator bootstrap (:267-306) */
+static void case_circuit_2_mux_trgsw(void) {
+  wide_setup();
+  TorusPolynomial ph = polynomial_new_torus_polynomial(N);
+  TRLWE c2 = trlwe_alloc_new_sample(k, N);
+  TLWE lw = tlwe_new_sample(double2torus(0.125), wkey_extracted);
+  trlwe_priv_keyswitch(c2, lw, wpriv);
+  trlwe_phase(ph, c2, wkey);
+  for (int i = 0; i < N; i++) WITHIN(1ULL << 56, (Torus)0 - wkey->s[0]->coeffs[i] * double2torus(0.125), ph->coeffs[i], "trlwe_priv_keyswitch");
+  TRGSW sel[2] = {trgsw_alloc_new_sample(wl, wBg, k, N), trgsw_alloc_new_sample(wl, wBg, k, N)};
+  TLWE in[2] = {tlwe_new_sample(double2torus(0.25), lwe_key), tlwe_new_sample(0, lwe_key)};
+  circuit_bootstrap_2_batch(sel, in, 2, wbk, wpriv, wpack);
+  TRGSW one = trgsw_alloc_new_sample(wl, wBg, k, N);
+  circuit_bootstrap(one, in[0], wbk, wpriv, wpack);
+  TorusPolynomial p0 = polynomial_new_torus_polynomial(N), p1 = polynomial_new_torus_polynomial(N);
+  for (int i = 0; i < N; i++) { p0->coeffs[i] = int2torus((uint64_t)(i & 7), 3); p1->coeffs[i] = int2torus((uint64_t)((i >> 3) & 7), 3); }
+  for (int b = 0; b < 3; b++) {
+    TRGSW g = b < 2 ? sel[b] : one;
+    public_mux(c2, p0, p1, g->samples + wl, wl, wBg);      /* the b rows of TRGSW(m) are the gadget encryption of m */
+    trlwe_phase(ph, c2, wkey);
+    const TorusPolynomial want = (b == 1) ? p0 : p1;       /* TRGSW(1) picks p1, TRGSW(0) picks p0 */
+    for (int i = 0; i < N; i++) WITHIN(1ULL << 58, want->coeffs[i], ph->coeffs[i], "public_mux with circuit-bootstrapped selector");
+  }
+  /* full TRGSW bootstrap: LWE -> TRGSW_DFT(X^-phase), then any test vector by one external product */
+  TRGSW_DFT acc = trgsw_alloc_new_DFT_sample(wl, wBg, k, N);
+  Torus lut[4] = {int2torus(2, 4), int2torus(6, 4), int2torus(10, 4), int2torus(14, 4)};
+  TRLWE tv = trlwe_alloc_new_sample(k, N);
+  trlwe_torus_packing(tv, lut, 4);
+  TLWE out = tlwe_alloc_sample(N);
+  for (int j = 0; j < 4; j++) {
+    TLWE c = tlwe_new_sample(double2torus(j / 8.), lwe_key);
+    functional_bootstrap_trgsw_phase1(acc, c, wbk, 4);
+    functional_bootstrap_trgsw_phase2(out, acc, tv);
+    WITHIN(1ULL << 58, lut[j], tlwe_phase(out, wkey_extracted), "functional_bootstrap_trgsw");
+    free_tlwe(c);
+  }
+  free_trgsw_DFT(acc); free_trlwe(tv); free_tlwe(out); free_polynomial(p0); free_polynomial(p1); free_trgsw(one);
+  free_trgsw(sel[0]); free_trgsw(sel[1]); free_tlwe(in[0]); free_tlwe(in[1]); free_tlwe(lw); free_trlwe(c2); free_polynomial(ph);
+}
+
 int main(int argc, char **argv) {
+  setvbuf(stdout, NULL, _IOLBF, 0);
   mosfhet_seed(0x4D4F5346);
   lwe_key = tlwe_new_binary_key(n, lwe_sigma);
   rlwe_key = trlwe_new_binary_key(N, k, rlwe_sigma);
@@ -218,13 +345,19 @@ int main(int argc, char **argv) {
     {"functional_bootstrap", case_functional_bootstrap}, {"programmable_bootstrap", case_programmable_bootstrap},
     {"blind_rotate", case_blind_rotate},                 {"tlwe_keyswitch+fdfb", case_tlwe_keyswitch},
     {"multivalue", case_multivalue},                     {"bootstrap_ga", case_bootstrap_ga},
-    {"circuit_bootstrap", case_circuit_bootstrap},
+    {"circuit_bootstrap", case_circuit_bootstrap},       {"unfolded", case_unfolded},
+    {"fdfb_variants", case_fdfb_variants},               {"multivalue_phases", case_multivalue_phases},
+    {"circuit_2+mux+trgsw", case_circuit_2_mux_trgsw},
   };
   for (unsigned i = 0; i < sizeof(cases) / sizeof(cases[0]); i++) {
     if (argc > 1 && strcmp(argv[1], cases[i].name)) continue;
     const int before = failures;
     cases[i].fn();
     printf("%-24s %s\n", cases[i].name, failures == before ? "ok" : "FAILED");
+  }
+  if (wkey) {
+    free_trlwe_generic_ks_key(wpack); free_trlwe_generic_ks_key(wpriv); free_bootstrap_key(wbk); free_trgsw_key(wgkey);
+    free_tlwe_key(wkey_extracted); free_trlwe_key(wkey);
   }
   free_bootstrap_key(bk); free_trgsw_key(trgsw_key); free_trlwe_key(rlwe_key); free_tlwe_key(lwe_key); free_tlwe_key(extracted_key);
   return failures > 255 ? 255 : failures;
