@@ -15,7 +15,7 @@
  *     e.g. applications/multi-ciphertext-arith/src/lut.c:12-17);
  *   - randomness comes from a seedable generator (mosfhet_seed); the reference seeds from RDRAND and is not
  *     reproducible (src/misc.c:34-49).
- * Functions of mosfhet.h outside the programmable-bootstrap path are not provided (scope).
+ * Functions of mosfhet.h outside the bootstrap path and its callers are not provided (scope).
  */
 #ifndef MOSFHET_COMPAT_H
 #define MOSFHET_COMPAT_H
