@@ -89,17 +89,34 @@ struct Digits {
   static constexpr int kLo = lo_levels(), kHi = L - lo_levels();
   using word_t = typename std::conditional<kPacked || kSplit, uint32_t, uint64_t>::type;
 
+  // u - 2^(BG-1) for a BG-bit field u is the field with its top bit flipped, read as a signed number: the packed words keep
+  // the fields top-bit-flipped (one XOR per word) and digit() is a single signed bit-field extract.
+  static constexpr uint32_t packed_flip() {
+    uint32_t m = 0;
+    for (int lv = 0; lv < L; lv++) m |= 1u << ((L - 1 - lv) * BG + BG - 1);
+    return m;
+  }
+  static constexpr uint32_t split_hi_flip() {
+    uint32_t m = 0;
+    for (int lv = 0; lv < kHi; lv++) m |= 1u << (32 - (lv + 1) * BG + BG - 1);
+    return m;
+  }
+  static constexpr uint32_t split_ext_flip() {
+    uint32_t m = 0;
+    for (int lv = kHi; lv < L; lv++) m |= (1u << ((L - 1 - lv) * BG + BG - 1)) | (1u << (16 + (L - 1 - lv) * BG + BG - 1));
+    return m;
+  }
   static __device__ __forceinline__ void pack(word_t &w_lo, word_t &w_hi, uint32_t &ext, uint64_t dd_lo, uint64_t dd_hi) {
     if constexpr (kPacked) {
-      w_lo = (uint32_t)(dd_lo >> (64 - L * BG));
-      w_hi = (uint32_t)(dd_hi >> (64 - L * BG));
+      w_lo = (uint32_t)(dd_lo >> (64 - L * BG)) ^ packed_flip();
+      w_hi = (uint32_t)(dd_hi >> (64 - L * BG)) ^ packed_flip();
       ext = 0;
     } else if constexpr (kSplit) {
-      w_lo = (uint32_t)(dd_lo >> 32);
-      w_hi = (uint32_t)(dd_hi >> 32);
+      w_lo = (uint32_t)(dd_lo >> 32) ^ split_hi_flip();
+      w_hi = (uint32_t)(dd_hi >> 32) ^ split_hi_flip();
       // bits [64 - L*BG, 64 - kHi*BG) of each word: the kLo low-level digits, kLo*BG <= 16 bits
       constexpr uint32_t m = (1u << (kLo * BG)) - 1;
-      ext = ((uint32_t)(dd_lo >> (64 - L * BG)) & m) | (((uint32_t)(dd_hi >> (64 - L * BG)) & m) << 16);
+      ext = (((uint32_t)(dd_lo >> (64 - L * BG)) & m) | (((uint32_t)(dd_hi >> (64 - L * BG)) & m) << 16)) ^ split_ext_flip();
     } else {
       w_lo = dd_lo;
       w_hi = dd_hi;
@@ -109,13 +126,10 @@ struct Digits {
   // signed digit `lv` of the coefficient (half = 0: j, 1: j + M) as a double (exact)
   static __device__ __forceinline__ double digit(word_t w, uint32_t ext, int half, int lv, int Bg_bit) {
     if constexpr (kPacked) {
-      const uint32_t u = (w >> ((L - 1 - lv) * BG)) & ((1u << BG) - 1);
-      return (double)((int)u - (1 << (BG - 1)));
+      return (double)(int)__builtin_amdgcn_sbfe(w, (unsigned)((L - 1 - lv) * BG), (unsigned)BG);   // the builtin is typed unsigned
     } else if constexpr (kSplit) {
-      uint32_t u;
-      if (lv < kHi) u = (w >> (32 - (lv + 1) * BG)) & ((1u << BG) - 1);
-      else u = (ext >> (16 * half + (L - 1 - lv) * BG)) & ((1u << BG) - 1);
-      return (double)((int)u - (1 << (BG - 1)));
+      if (lv < kHi) return (double)(int)__builtin_amdgcn_sbfe(w, (unsigned)(32 - (lv + 1) * BG), (unsigned)BG);
+      return (double)(int)__builtin_amdgcn_sbfe(ext, (unsigned)(16 * half + (L - 1 - lv) * BG), (unsigned)BG);
     } else {
       const int bg = BG > 0 ? BG : Bg_bit;
       const uint32_t u = (uint32_t)(w >> (64 - (lv + 1) * bg)) & ((1u << bg) - 1);

@@ -313,19 +313,24 @@ struct Fft2048 {
 };
 
 // double -> Torus64, round to nearest, mod 2^64 (values reach ~2^84).  `scale` = 2^-64 / M.
-// Same arithmetic as oracle_fft.c:round_mod_2_64 (the two exact power-of-two scalings are merged);
-// semantics of the reference's AVX-512 path, fft_processor_spqlios.c:155-165.
-//   f = frac part of v*scale in [-1/2, 1/2]; g = rint(f 2^64) in [-2^63, 2^63]; split g = hf 2^32 + lo with
-//   hf = floor(g 2^-32) in [-2^31, 2^31], lo in [0, 2^32); the high word is (int32)hf, saturated at 2^31 - 1
-//   (only g = +2^63 exactly, an exact tie of probability ~2^-53, is affected; the oracle does the same).
+// Same result as oracle_fft.c:round_mod_2_64 for every input (semantics of the reference's AVX-512 path,
+// fft_processor_spqlios.c:155-165: vcvtpd2qq of the fractional part scaled by 2^64, which wraps 2^63 to -2^63):
+//   f = frac part of v*scale in [-1/2, 1/2];  out = rint(f 2^64) mod 2^64.
+// There is no 64-bit float->int conversion on the VALU, so the integer is assembled from two 32-bit halves with the
+// magic-number trick (adding 1.5 * 2^52 leaves rint(x) mod 2^32 in the low dword of the sum for |x| <= 2^31):
+//   h = rint(f 2^32), q = f 2^32 - h (exact, |q| <= 1/2), x = rint(q 2^32);  rint(f 2^64) = h 2^32 + x  because h 2^32 is an
+//   even integer (ties-to-even is preserved);  bit 32 of the second sum's mantissa is set iff x < 0 (the borrow).
 __device__ __forceinline__ uint64_t round_mod_2_64(double v, double scale) {
+  constexpr double MAGIC = 0x1.8p52;
   double f = v * scale;
   f = f - __builtin_rint(f);
-  const double g = __builtin_rint(f * 0x1p64);
-  const double hf = __builtin_floor(g * 0x1p-32);
-  const double lo = __builtin_fma(-hf, 0x1p32, g);
-  const int32_t hi = (int32_t)__builtin_fmin(hf, 2147483647.0);
-  return ((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo;
+  const double A = __builtin_fma(f, 0x1p32, MAGIC);
+  const double B = A - MAGIC;
+  const double q = __builtin_fma(f, 0x1p32, -B);
+  const double C = __builtin_fma(q, 0x1p32, MAGIC);
+  const uint64_t a = (uint64_t)__double_as_longlong(A), c = (uint64_t)__double_as_longlong(C);
+  const uint32_t hi = (uint32_t)a - ((uint32_t)(c >> 32) & 1u);
+  return ((uint64_t)hi << 32) | (uint64_t)(uint32_t)c;
 }
 
 // (double)(int64_t)x, correctly rounded (matches the C cast used by the reference and the oracle)

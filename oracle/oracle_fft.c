@@ -25,10 +25,9 @@
  *                       qr = fma(sr, dr, si * di);           qi = fma(sr, di, -(si * dr));
  *   complex MAC         or = fma(-di, bi, fma(dr, br, or));  oi = fma(di, br, fma(dr, bi, oi));
  *   rounding            w = v * 2^-log2(M); f = w * 2^-64; f -= rint(f); g = rint(f * 2^64);
- *                       hf = floor(g * 2^-32); lo = fma(-hf, 2^32, g); hi = (int32)min(hf, 2^31 - 1);
- *                       out = (u32)hi << 32 | (u32)lo                (round to nearest, as the
- *                       reference's default AVX-512 path fft_processor_spqlios.c:155-165; the clamp only
- *                       touches the exact tie g = +2^63)
+ *                       out = g mod 2^64                             (round to nearest, as the
+ *                       reference's default AVX-512 path fft_processor_spqlios.c:155-165; the kernels
+ *                       assemble the same integer from two 32-bit halves, see negacyclic_fft.h)
  * Compile with -ffp-contract=off: every fma above is explicit, nothing else may be fused.
  */
 #include "mosfhet_oracle.h"
@@ -152,11 +151,9 @@ static inline Torus round_mod_2_64(double v, double inv_m) {
   const double w = v * inv_m;
   double f = w * 0x1p-64;
   f = f - rint(f);
-  const double g = rint(f * 0x1p64);
-  const double hf = floor(g * 0x1p-32);
-  const double lo = fma(-hf, 0x1p32, g);
-  const int32_t hi = (int32_t)fmin(hf, 2147483647.0);
-  return ((Torus)(uint32_t)hi << 32) | (Torus)(uint32_t)lo;
+  const double g = rint(f * 0x1p64);                 /* in [-2^63, 2^63] */
+  if (g >= 0x1p63) return (Torus)1 << 63;            /* vcvtpd2qq wraps the exact tie +2^63 to -2^63 = 2^63 mod 2^64 */
+  return (Torus)(int64_t)g;
 }
 
 /* src/polynomial.c:359-366 -> execute_direct_torus64 (fft_processor_spqlios.c:128-165) */
