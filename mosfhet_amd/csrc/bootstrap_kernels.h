@@ -259,7 +259,7 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
   uint64_t off = 1ull << (63 - L * Bg_bit);
 #pragma unroll
   for (int i = 0; i < L; i++) off += 1ull << (63 - i * Bg_bit);
-  const double scale = 0x1p-64 / (double)M;
+  const RoundCtx scale(0x1p-64 / (double)M);
   const size_t row_sz = (size_t)2 * L * 2 * M;
 
   for (int i = 0; i < p.n; i++) {
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
 // acc <- TRGSW (.) acc (external product, result REPLACES the accumulator)
 template <class F, int L, int BG>
 __device__ __forceinline__ void ga_external_product(uint64_t (&al)[8], uint64_t (&ah)[8], uint64_t *acc1, d2 *xch, const F &fft,
-                                                    const d2 *__restrict__ bkrow, uint64_t off, int Bg_bit, double scale, int t) {
+                                                    const d2 *__restrict__ bkrow, uint64_t off, int Bg_bit, const RoundCtx &scale, int t) {
   constexpr int M = F::M, T = F::THREADS;
   using D = Digits<L, BG>;
   double o_re[2][8], o_im[2][8];
@@ -370,7 +370,7 @@ __device__ __forceinline__ void ga_external_product(uint64_t (&al)[8], uint64_t 
 // acc <- Auto_gen(acc): permute both components (out[(i gen) mod N] = +-in[i]) and key switch with `entry`
 template <class F, int L, int BG>
 __device__ __forceinline__ void ga_eval_automorphism(uint64_t (&al)[8], uint64_t (&ah)[8], uint64_t *acc1, d2 *xch, const F &fft,
-                                                     const d2 *__restrict__ entry, int gen, uint64_t off, int Bg_bit, double scale,
+                                                     const d2 *__restrict__ entry, int gen, uint64_t off, int Bg_bit, const RoundCtx &scale,
                                                      int t) {
   constexpr int N = F::N, M = F::M, T = F::THREADS;
   using D = Digits<L, BG>;
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_ga_kernel(GaParams g) {
   uint64_t off = 1ull << (63 - L * Bg_bit);
 #pragma unroll
   for (int i = 0; i < L; i++) off += 1ull << (63 - i * Bg_bit);
-  const double scale = 0x1p-64 / (double)M;
+  const RoundCtx scale(0x1p-64 / (double)M);
   const size_t row_sz = (size_t)2 * L * 2 * M, ak_sz = (size_t)L * 2 * M;
   uint64_t al[8], ah[8];
 
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(F::THREADS, 2) void trlwe_fft_keyswitch_kernel(cons
   fft.init(tw, tid);
   uint64_t off = 1ull << (63 - t * base_bit);
   for (int i = 0; i < t; i++) off += 1ull << (63 - i * base_bit);
-  const double scale = 0x1p-64 / (double)M;
+  const RoundCtx scale(0x1p-64 / (double)M);
   uint64_t res_a_lo[8], res_a_hi[8], res_b_lo[8], res_b_hi[8];
 #pragma unroll
   for (int m = 0; m < 8; m++) {
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(F::THREADS) void dft_to_torus_kernel(const d2 *__re
   for (int m = 0; m < 8; m++) { const d2 v = src[m * T + t]; re[m] = v.x; im[m] = v.y; }
   fft.inverse(re, im, xch, t);
   uint64_t *dst = out + (size_t)blockIdx.x * N;
-  const double scale = 0x1p-64 / (double)M;
+  const RoundCtx scale(0x1p-64 / (double)M);
 #pragma unroll
   for (int m = 0; m < 8; m++) {
     dst[m * T + t] = round_mod_2_64(re[m], scale);
@@ -730,7 +730,7 @@ __global__ __launch_bounds__(F::THREADS) void external_product_kernel(const d2 *
       Digits<L, 0>::pack(w_lo[m], w_hi[m], ext[m], ct[q * N + m * T + t] + off, ct[q * N + M + m * T + t] + off);
     cmux_rows<F, L, 0>(w_lo, w_hi, ext, q, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
   }
-  const double scale = 0x1p-64 / (double)M;
+  const RoundCtx scale(0x1p-64 / (double)M);
   uint64_t *dst = out + (size_t)blockIdx.x * 2 * N;
 #pragma unroll
   for (int c = 0; c < 2; c++) {

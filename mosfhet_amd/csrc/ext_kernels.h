@@ -57,7 +57,7 @@ __global__ __launch_bounds__(F::THREADS, 2) void public_mux_kernel(const uint64_
       }
     }
   }
-  const double scale = 0x1p-64 / (double)M;
+  const RoundCtx scale(0x1p-64 / (double)M);
 #pragma unroll
   for (int c = 0; c < 2; c++) {
     fft.inverse(o_re[c], o_im[c], xch, tid);
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(F::THREADS, 2) void trlwe_tensor_prod_kernel(const 
   F fft;
   fft.init(tw, tid);
   const int hp1 = 64 - (64 - precision) / 2, hp2 = 64 - (64 - precision + 1) / 2;
-  const double scale = 0x1p-64 / (double)M;
+  const RoundCtx scale(0x1p-64 / (double)M);
   auto load = [&](const uint64_t *src, int hp, double (&re)[8], double (&im)[8]) {
 #pragma unroll
     for (int m = 0; m < 8; m++) {   // torus2int(x, hp) = (x + 2^(63-hp)) >> (64-hp)   [src/misc.c:18-22]
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(F::THREADS) void pbs_unfolded_kernel(UnfoldParams p
   for (int i = 0; i < l; i++) off += 1ull << (63 - i * Bg);
   const uint32_t mask = (1u << Bg) - 1;
   const int half = 1 << (Bg - 1);
-  const double scale = 0x1p-64 / (double)M;
+  const RoundCtx scale(0x1p-64 / (double)M);
   const size_t trgsw_sz = (size_t)2 * l * 2 * N;
 #pragma unroll 1
   for (int i = 0; i < p.n; i += u) {

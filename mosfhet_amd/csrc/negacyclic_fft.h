@@ -320,14 +320,23 @@ struct Fft2048 {
 // magic-number trick (adding 1.5 * 2^52 leaves rint(x) mod 2^32 in the low dword of the sum for |x| <= 2^31):
 //   h = rint(f 2^32), q = f 2^32 - h (exact, |q| <= 1/2), x = rint(q 2^32);  rint(f 2^64) = h 2^32 + x  because h 2^32 is an
 //   even integer (ties-to-even is preserved);  bit 32 of the second sum's mantissa is set iff x < 0 (the borrow).
-__device__ __forceinline__ uint64_t round_mod_2_64(double v, double scale) {
-  constexpr double MAGIC = 0x1.8p52;
-  double f = v * scale;
+// Constant placement: v_fma_f64 (VOP3) on gfx9 takes no literal and only one scalar source, and a VOP2 v_fmac would need 1.5 * 2^52
+// copied into its accumulator in front of every use (96-128 extra moves per CMUX when left to the compiler), so 2^32 is pinned
+// in a scalar register pair and the magic number in a vector register pair, once per kernel (RoundCtx).
+struct RoundCtx {
+  double scale, magic, two32;
+  __device__ __forceinline__ explicit RoundCtx(double s) : scale(s), magic(0x1.8p52), two32(0x1p32) {
+    asm volatile("" : "+v"(magic));
+    asm volatile("" : "+s"(two32));
+  }
+};
+__device__ __forceinline__ uint64_t round_mod_2_64(double v, const RoundCtx &rc) {
+  double f = v * rc.scale;
   f = f - __builtin_rint(f);
-  const double A = __builtin_fma(f, 0x1p32, MAGIC);
-  const double B = A - MAGIC;
-  const double q = __builtin_fma(f, 0x1p32, -B);
-  const double C = __builtin_fma(q, 0x1p32, MAGIC);
+  const double A = __builtin_fma(f, rc.two32, rc.magic);
+  const double B = A - rc.magic;
+  const double q = __builtin_fma(f, rc.two32, -B);
+  const double C = __builtin_fma(q, rc.two32, rc.magic);
   const uint64_t a = (uint64_t)__double_as_longlong(A), c = (uint64_t)__double_as_longlong(C);
   const uint32_t hi = (uint32_t)a - ((uint32_t)(c >> 32) & 1u);
   return ((uint64_t)hi << 32) | (uint64_t)(uint32_t)c;

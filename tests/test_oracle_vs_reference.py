@@ -299,7 +299,7 @@ def test_circuit_bootstrap_variants(oracle, ref, wide):
                     want[0] = h
                 else:
                     want = (np.uint64(0) - s) * h
-                tol = 2.0 ** 50 if q >= l else 2.0 ** 56     # 24 / 12-bit key-switch rounding; the private switch multiplies by s
+                tol = 2.0 ** 50 if q >= l else 2.0 ** 57     # 24 / 12-bit key-switch rounding; the private switch multiplies by s
                 assert oracle.torus_dist(ph_m, want).max() < tol, (variant, q)
                 assert oracle.torus_dist(ph_t, want).max() < tol, (variant, q)
 
