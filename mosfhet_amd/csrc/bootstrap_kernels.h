@@ -280,13 +280,17 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
       cmux_digits<F, L, BG>(w_lo, w_hi, ext, al, ah, q ? acc1 : nullptr, xch, a_lo, flip, off, t);
       cmux_rows<F, L, BG>(w_lo, w_hi, ext, q, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
     }
-    fft.inverse(o_re[0], o_im[0], xch, t);
+    if constexpr (F::THREADS == 64) {
+      fft.inverse2(o_re[0], o_im[0], o_re[1], o_im[1], xch, t);
+    } else {
+      fft.inverse(o_re[0], o_im[0], xch, t);
+      fft.inverse(o_re[1], o_im[1], xch, t);
+    }
 #pragma unroll
     for (int m = 0; m < 8; m++) {
       al[m] += round_mod_2_64(o_re[0][m], scale);
       ah[m] += round_mod_2_64(o_im[0][m], scale);
     }
-    fft.inverse(o_re[1], o_im[1], xch, t);
 #pragma unroll
     for (int m = 0; m < 8; m++) {
       acc1[m * T + t] += round_mod_2_64(o_re[1][m], scale);

@@ -179,6 +179,43 @@ struct Fft1024 {
     pass_inv(re, im, wa);
     wave_lds_sync();
   }
+
+  // Two independent inverse transforms (the two components of an external product) software-pipelined through the ONE
+  // transpose buffer: DS operations of a wavefront execute in order, so Y's writes may be queued right behind X's reads of
+  // the same slots, and each transform's register pass runs while the other's transpose is in flight.
+  __device__ __forceinline__ void inverse2(double (&xr)[8], double (&xi)[8], double (&yr)[8], double (&yi)[8], d2 *xch, int lane) const {
+    d2 *pa = xch + lane, *pb = xch + 72 * (lane >> 3) + (lane & 7), *pc = xch + 9 * lane;
+    pass_inv(xr, xi, wc);
+#pragma unroll
+    for (int m = 0; m < 8; m++) pc[m] = d2{xr[m], xi[m]};
+    wave_lds_sync();
+    pass_inv(yr, yi, wc);
+#pragma unroll
+    for (int m = 0; m < 8; m++) { const d2 v = pb[9 * m]; xr[m] = v.x; xi[m] = v.y; }
+    wave_lds_sync();
+#pragma unroll
+    for (int m = 0; m < 8; m++) pc[m] = d2{yr[m], yi[m]};
+    wave_lds_sync();
+    pass_inv(xr, xi, wb);
+#pragma unroll
+    for (int m = 0; m < 8; m++) { const d2 v = pb[9 * m]; yr[m] = v.x; yi[m] = v.y; }
+    wave_lds_sync();
+#pragma unroll
+    for (int m = 0; m < 8; m++) pb[8 * m] = d2{xr[m], xi[m]};
+    wave_lds_sync();
+    pass_inv(yr, yi, wb);
+#pragma unroll
+    for (int m = 0; m < 8; m++) { const d2 v = pa[72 * m]; xr[m] = v.x; xi[m] = v.y; }
+    wave_lds_sync();
+#pragma unroll
+    for (int m = 0; m < 8; m++) pb[8 * m] = d2{yr[m], yi[m]};
+    wave_lds_sync();
+    pass_inv(xr, xi, wa);
+#pragma unroll
+    for (int m = 0; m < 8; m++) { const d2 v = pa[72 * m]; yr[m] = v.x; yi[m] = v.y; }
+    pass_inv(yr, yi, wa);
+    wave_lds_sync();
+  }
 };
 
 // ------------------------------------------------------------------------------------------------
