@@ -233,6 +233,14 @@ int mosfhet_hip_full_domain_functional_bootstrap_CLOT21_batch(mosfhet_hip_ctx_t 
 int mosfhet_hip_bsk_unfolded_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t *out, const uint64_t *h_su, int n, int N, int l, int Bg_bit,
                                     int unfolding);
 
+/* multivalue_bootstrap_UBR_phase1 / phase2 (src/bootstrap.c:151-190) with an unfolded key: d_sa = [count][n/u][2l][2][N/2] complex
+ * (the per-group TRGSW_DFT of each input); phase 2 evaluates tv_count shared test vectors per ciphertext: d_out = [count][tv_count][N+1]. */
+int mosfhet_hip_multivalue_bootstrap_UBR_phase1_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, double *d_sa, const uint64_t *d_in, int count,
+                                                      void *stream);
+int mosfhet_hip_multivalue_bootstrap_UBR_phase2_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_out, const uint64_t *d_tvs,
+                                                      int tv_count, const uint64_t *d_in, const double *d_sa, int count, int torus_base,
+                                                      void *stream);
+
 /* Timing hook for bench.py: runs `reps` launches of the programmable-bootstrap kernel on `stream`
  * bracketed by hipEvents ON THAT STREAM and returns the average kernel time in milliseconds
  * (synchronises the stream). */

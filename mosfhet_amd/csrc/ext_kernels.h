@@ -352,4 +352,128 @@ __global__ __launch_bounds__(F::THREADS) void pbs_unfolded_kernel(UnfoldParams p
     }
 }
 
+// multivalue_bootstrap_UBR_phase1 [src/bootstrap.c:151-175]: the per-group TRGSW of the unfolded rotation, transformed and written
+// out: out[b][g] = DFT( sum_j X^(rot_j) su[g 2^u + j] ), [2l][2][M] complex in slot order.  grid = (2l * 2, n / u, count): one team per
+// polynomial.
+template <class F>
+__global__ __launch_bounds__(F::THREADS) void ubr_phase1_kernel(const uint64_t *__restrict__ su, const d2 *__restrict__ tw, const uint64_t *__restrict__ in,
+                                                              d2 *__restrict__ out, int n, int l, int unfolding) {
+  constexpr int N = F::N, M = F::M, T = F::THREADS, LOG2N2 = F::LOGM + 2;
+  __shared__ __attribute__((aligned(16))) d2 xch[F::XCH_SLOTS];
+  const int t = threadIdx.x, qc = blockIdx.x, g = blockIdx.y;
+  const uint64_t *__restrict__ ct = in + (size_t)blockIdx.z * (n + 1) + (size_t)g * unfolding;
+  F fft;
+  fft.init(tw, t);
+  const int key_exp = 1 << unfolding;
+  const size_t trgsw_sz = (size_t)2 * l * 2 * N;
+  uint64_t xl[8], xh[8];
+#pragma unroll
+  for (int m = 0; m < 8; m++) { xl[m] = 0; xh[m] = 0; }
+#pragma unroll 1
+  for (int j = 0; j < key_exp; j++) {
+    uint64_t a_i = 0;
+    for (int bb = 0; bb < unfolding; bb++)
+      if ((j >> bb) & 1) a_i += ct[bb];
+    const int rot = j ? (int)modswitch<LOG2N2>(a_i) : 0;
+    const int a_lo = rot & (N - 1);
+    const bool flip = (rot & N) != 0;
+    const uint64_t *__restrict__ src = su + ((size_t)g * key_exp + j) * trgsw_sz + (size_t)qc * N;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      xl[m] += rot_coeff<N>(src, m * T + t, a_lo, flip);
+      xh[m] += rot_coeff<N>(src, M + m * T + t, a_lo, flip);
+    }
+  }
+  double kr[8], ki[8];
+#pragma unroll
+  for (int m = 0; m < 8; m++) { kr[m] = torus_to_double(xl[m]); ki[m] = torus_to_double(xh[m]); }
+  fft.forward(kr, ki, xch, t);
+  d2 *dst = out + (((size_t)blockIdx.z * gridDim.y + g) * gridDim.x + qc) * M;
+#pragma unroll
+  for (int m = 0; m < 8; m++) dst[m * T + t] = d2{kr[m], ki[m]};
+}
+
+// multivalue_bootstrap_UBR_phase2 [src/bootstrap.c:177-190]: acc = tv X^(2N - bbar); for every group acc <- sa[b][g] (.) acc.
+// One team per (ciphertext, test vector): blockIdx.x = b * tv_count + v; writes the rotated TRLWE (the caller extracts).
+template <class F>
+__global__ __launch_bounds__(F::THREADS) void ubr_phase2_kernel(const d2 *__restrict__ sa, const d2 *__restrict__ tw, const uint64_t *__restrict__ in,
+                                                              const uint64_t *__restrict__ tvs, uint64_t *__restrict__ out, int n, int l, int Bg_bit,
+                                                              int groups, int tv_count, uint64_t prec_offset) {
+  constexpr int N = F::N, M = F::M, T = F::THREADS, LOG2N2 = F::LOGM + 2;
+  __shared__ __attribute__((aligned(16))) d2 xch[F::XCH_SLOTS];
+  const int t = threadIdx.x;
+  const size_t b = blockIdx.x / tv_count, v = blockIdx.x % tv_count;
+  const uint64_t *__restrict__ ct = in + b * (size_t)(n + 1);
+  const uint64_t *__restrict__ tv = tvs + v * (size_t)(2 * N);
+  F fft;
+  fft.init(tw, t);
+  uint64_t acc[2][2][8];
+  {
+    const uint32_t bbar = modswitch<LOG2N2>(ct[n] + prec_offset);
+    const int rot = (2 * N - (int)bbar) & (2 * N - 1);
+    const int a_lo = rot & (N - 1);
+    const bool flip = (rot & N) != 0;
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        acc[c][0][m] = rot_coeff<N>(tv + c * N, m * T + t, a_lo, flip);
+        acc[c][1][m] = rot_coeff<N>(tv + c * N, M + m * T + t, a_lo, flip);
+      }
+  }
+  uint64_t off = 1ull << (63 - l * Bg_bit);
+  for (int i = 0; i < l; i++) off += 1ull << (63 - i * Bg_bit);
+  const uint32_t mask = (1u << Bg_bit) - 1;
+  const int half = 1 << (Bg_bit - 1);
+  const RoundCtx scale(0x1p-64 / (double)M);
+  const size_t key_sz = (size_t)2 * l * 2 * M;
+#pragma unroll 1
+  for (int g = 0; g < groups; g++) {
+    const d2 *__restrict__ key = sa + (b * groups + g) * key_sz;
+    double o_re[2][8], o_im[2][8];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int m = 0; m < 8; m++) { o_re[c][m] = 0.0; o_im[c][m] = 0.0; }
+#pragma unroll 1
+    for (int q = 0; q < 2 * l; q++) {
+      const int comp = q / l, shift = 64 - (q % l + 1) * Bg_bit;
+      double dr[8], di[8];
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const uint64_t lo = comp ? acc[1][0][m] : acc[0][0][m], hi = comp ? acc[1][1][m] : acc[0][1][m];
+        dr[m] = (double)((int)((uint32_t)((lo + off) >> shift) & mask) - half);
+        di[m] = (double)((int)((uint32_t)((hi + off) >> shift) & mask) - half);
+      }
+      fft.forward(dr, di, xch, t);
+      const d2 *__restrict__ row = key + (size_t)q * 2 * M;
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const d2 k0 = row[m * T + t], k1 = row[M + m * T + t];
+        o_re[0][m] = __builtin_fma(-di[m], k0.y, __builtin_fma(dr[m], k0.x, o_re[0][m]));
+        o_im[0][m] = __builtin_fma(di[m], k0.x, __builtin_fma(dr[m], k0.y, o_im[0][m]));
+        o_re[1][m] = __builtin_fma(-di[m], k1.y, __builtin_fma(dr[m], k1.x, o_re[1][m]));
+        o_im[1][m] = __builtin_fma(di[m], k1.x, __builtin_fma(dr[m], k1.y, o_im[1][m]));
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      fft.inverse(o_re[c], o_im[c], xch, t);
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        acc[c][0][m] = round_mod_2_64(o_re[c][m], scale);
+        acc[c][1][m] = round_mod_2_64(o_im[c][m], scale);
+      }
+    }
+  }
+  uint64_t *o = out + (size_t)blockIdx.x * (2 * N);
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      o[c * N + m * T + t] = acc[c][0][m];
+      o[c * N + M + m * T + t] = acc[c][1][m];
+    }
+}
+
 }  // namespace mosfhet

@@ -312,6 +312,21 @@ class Engine:
                                                                                precision, variant, self._stream()))
         return out
 
+    def multivalue_bootstrap_UBR_phase1(self, bsk, ct, unfolding, out=None):
+        count = ct.shape[0]
+        if out is None:
+            out = self.torch.empty(count, bsk.n // unfolding, 2 * bsk.l, 2, bsk.N, dtype=self.torch.float64, device=self.device)
+        _check(lib().mosfhet_hip_multivalue_bootstrap_UBR_phase1_batch(self.h, bsk.h, _ptr(out), _ptr(ct), count, self._stream()))
+        return out
+
+    def multivalue_bootstrap_UBR_phase2(self, bsk, tvs, ct, sa, torus_base, out=None):
+        count, tv_count = ct.shape[0], tvs.shape[0]
+        if out is None:
+            out = self.empty(count, tv_count, bsk.N + 1)
+        _check(lib().mosfhet_hip_multivalue_bootstrap_UBR_phase2_batch(self.h, bsk.h, _ptr(out), _ptr(tvs), tv_count, _ptr(ct), _ptr(sa), count,
+                                                                       torus_base, self._stream()))
+        return out
+
     def trlwe_eval_automorphism(self, gak, ct, gen, out=None):
         count = ct.shape[0]
         if out is None:

@@ -173,6 +173,11 @@ void orc_blind_rotate_unfolded(const orc_fft_plan *p, Torus *acc, const Torus *a
 void orc_functional_bootstrap_unfolded(const orc_fft_plan *p, Torus *out, const Torus *tv, const Torus *in, const Torus *su, int n, int l, int Bg_bit,
                     int torus_base, int unfolding, int extract);                          /* bootstrap.c:192-206 with key->unfolding > 1 */
 
+void orc_multivalue_bootstrap_UBR_phase1(const orc_fft_plan *p, double *out_dft /*[n/u][2l][2][N]*/, const Torus *in, const Torus *su, int n, int l,
+                    int Bg_bit, int unfolding);                                           /* bootstrap.c:151-175 */
+void orc_multivalue_bootstrap_UBR_phase2(const orc_fft_plan *p, Torus *out /*[N+1]*/, const Torus *tv, const Torus *in, const double *sa_dft, int n,
+                    int l, int Bg_bit, int unfolding, int torus_base);                    /* bootstrap.c:177-190 */
+
 /* ---- deterministic test-input generation (own code; the reference's RNG is RDRAND-seeded
  *      and not reproducible, src/misc.c:34-49) ---- */
 uint64_t orc_rng_next(orc_rng *r);                       /* splitmix64 */

@@ -513,6 +513,21 @@ def functional_bootstrap_unfolded(tv, c, su, l, Bg_bit, torus_base, unfolding, e
     return out
 
 
+def multivalue_bootstrap_UBR_phase1(c, su, l, Bg_bit, unfolding):
+    N = su.shape[-1]
+    n = c.size - 1
+    out = np.empty((n // unfolding, 2 * l, 2, N), dtype=np.float64)
+    lib().orc_multivalue_bootstrap_UBR_phase1(plan(N).h, _d(out), _u(c), _u(su), n, l, Bg_bit, unfolding)
+    return out
+
+
+def multivalue_bootstrap_UBR_phase2(tv, c, sa_dft, l, Bg_bit, unfolding, torus_base):
+    N = tv.shape[-1]
+    out = np.empty(N + 1, dtype=np.uint64)
+    lib().orc_multivalue_bootstrap_UBR_phase2(plan(N).h, _u(out), _u(tv), _u(c), _d(sa_dft), C.c_int(c.size - 1), l, Bg_bit, unfolding, torus_base)
+    return out
+
+
 # ---------------- deterministic inputs ----------------
 def gen_binary_key(rng, n):
     s = np.empty(n, dtype=np.uint64)

@@ -365,3 +365,46 @@ void orc_functional_bootstrap_unfolded(const orc_fft_plan *p, Torus *out, const 
   else memcpy(out, acc, sizeof(Torus) * (size_t)2 * N);
   free(acc);
 }
+
+/* src/bootstrap.c:151-175  multivalue_bootstrap_UBR_phase1: the per-group TRGSW of blind_rotate_unfolded, transformed, one per group
+ * (out_dft: [n / u][2l][2][N] doubles).  Depends on the input's mask only, so one phase 1 serves any number of test vectors. */
+void orc_multivalue_bootstrap_UBR_phase1(const orc_fft_plan *p, double *out_dft, const Torus *in, const Torus *su, int n, int l, int Bg_bit, int unfolding) {
+  const int N = plan_N(p);
+  int log_N2 = 0;
+  while ((1 << log_N2) < 2 * N) log_N2++;
+  (void)Bg_bit;
+  const int key_exp = 1 << unfolding, final_exp = key_exp / unfolding;
+  const size_t sz = (size_t)2 * l * 2 * N;
+  Torus *xai = talloc(sz);
+  for (int i = 0, g = 0; i < n; i += unfolding, g++) {
+    memcpy(xai, su + (size_t)i * final_exp * sz, sizeof(Torus) * sz);
+    for (int j = 1; j < key_exp; j++) {
+      Torus a_i = 0;
+      for (int u = 0, j_ = j; u < unfolding; u++, j_ >>= 1)
+        if (j_ & 1) a_i += in[i + u];
+      const int rot = (int)orc_torus2int(a_i, log_N2);
+      const Torus *src = su + ((size_t)i * final_exp + j) * sz;
+      for (int q = 0; q < 2 * l * 2; q++) orc_poly_mul_by_xai_addto(xai + (size_t)q * N, src + (size_t)q * N, N, rot);
+    }
+    orc_trgsw_to_dft(p, out_dft + (size_t)g * sz, xai, 1, l);
+  }
+  free(xai);
+}
+
+/* src/bootstrap.c:177-190  multivalue_bootstrap_UBR_phase2: rotate tv by the body, chain of external products, extract */
+void orc_multivalue_bootstrap_UBR_phase2(const orc_fft_plan *p, Torus *out, const Torus *tv, const Torus *in, const double *sa_dft, int n, int l,
+                                         int Bg_bit, int unfolding, int torus_base) {
+  const int N = plan_N(p);
+  int log_N2 = 0;
+  while ((1 << log_N2) < 2 * N) log_N2++;
+  const size_t sz = (size_t)2 * l * 2 * N;
+  Torus *acc = talloc((size_t)2 * N), *tmp = talloc((size_t)2 * N);
+  const int rot = 2 * N - (int)orc_torus2int(in[n] + orc_double2torus(1. / (4 * torus_base)), log_N2);
+  for (int c = 0; c < 2; c++) orc_poly_mul_by_xai(acc + (size_t)c * N, tv + (size_t)c * N, N, rot);
+  for (int g = 0; g < n / unfolding; g++) {
+    orc_external_product(p, tmp, acc, sa_dft + (size_t)g * sz, 1, l, Bg_bit);
+    memcpy(acc, tmp, sizeof(Torus) * (size_t)2 * N);
+  }
+  orc_trlwe_extract_tlwe(out, acc, 1, N, 0);
+  free(acc); free(tmp);
+}

@@ -623,6 +623,26 @@ void *ref_bk_unfolded_new(const Torus *su_flat, int n, int N, int l, int Bg_bit,
   return res;
 }
 
+/* multivalue_bootstrap_UBR_phase1 + phase2 (src/bootstrap.c:151-190) with an unfolded key: one phase 1, then phase 2 per test vector */
+void ref_multivalue_bootstrap_UBR(Torus *out /*[n_tv][N+1]*/, const Torus *tvs /*[n_tv][2][N]*/, int n_tv, const Torus *in, void *bkh, int torus_base) {
+  Bootstrap_Key bk = (Bootstrap_Key)bkh;
+  const int groups = bk->n / bk->unfolding;
+  TRGSW_DFT *sa = (TRGSW_DFT *)safe_malloc(sizeof(TRGSW_DFT) * groups);
+  for (int g = 0; g < groups; g++) sa[g] = trgsw_alloc_new_DFT_sample(bk->l, bk->Bg_bit, 1, bk->N);
+  TLWE c = tlwe_from_flat(in, bk->n), o = tlwe_alloc_sample(bk->N);
+  multivalue_bootstrap_UBR_phase1(sa, c, bk);
+  for (int i = 0; i < n_tv; i++) {
+    TRLWE t = trlwe_from_flat(tvs + (size_t)i * 2 * bk->N, 1, bk->N);
+    multivalue_bootstrap_UBR_phase2(o, t, c, sa, bk, torus_base);
+    tlwe_to_flat(out + (size_t)i * (bk->N + 1), o);
+    free_trlwe(t);
+  }
+  for (int g = 0; g < groups; g++) free_trgsw(sa[g]);
+  free(sa);
+  free_tlwe(c);
+  free_tlwe(o);
+}
+
 /* ---------- CPU baseline: time `reps` reference programmable bootstraps on the calling thread.
  * Re-entrant across threads once ref_init(N) has run on the main thread (FFT processors are
  * __thread, src/polynomial.c:338-349). Returns elapsed seconds. ---------- */

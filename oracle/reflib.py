@@ -313,6 +313,12 @@ class Ref:
         self.l.ref_bk_unfolded_new.restype = C.c_void_p
         return C.c_void_p(self.l.ref_bk_unfolded_new(_u(su), count * unfolding >> unfolding, N, l, Bg_bit, unfolding))
 
+    def multivalue_bootstrap_UBR(self, tvs, c, bkh, torus_base):
+        n_tv, _, N = tvs.shape
+        out = np.empty((n_tv, N + 1), dtype=np.uint64)
+        self.l.ref_multivalue_bootstrap_UBR(_u(out), _u(tvs), n_tv, _u(c), bkh, torus_base)
+        return out
+
     def bench_programmable_bootstrap(self, tv, c, h, precision, reps):
         """Seconds for `reps` programmable_bootstrap calls on the calling thread (GIL released)."""
         return self.l.ref_bench_programmable_bootstrap(_u(tv), _u(c), h, precision, reps)

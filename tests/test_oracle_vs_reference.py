@@ -377,4 +377,16 @@ def test_functional_bootstrap_unfolded(oracle, ref, unfolding):
         assert oracle.torus_dist(oracle.tlwe_phase(mine, s), lut[m]) < 2.0 ** 58
         assert oracle.torus_dist(oracle.tlwe_phase(theirs, s), lut[m]) < 2.0 ** 58
         assert oracle.torus_dist(oracle.tlwe_phase(mine, s), oracle.tlwe_phase(theirs, s)) < 2.0 ** 50
+    # multivalue_bootstrap_UBR_phase1 / phase2 (src/bootstrap.c:151-190): one phase 1, several test vectors; in the oracle the
+    # pair computes exactly what the unfolded bootstrap computes
+    luts = oracle.u64(rng.words(8)).reshape(2, 4)
+    tvs = np.stack([oracle.trlwe_torus_packing(x, 1, N) for x in luts])
+    c = oracle.tlwe_sample(rng, oracle.double2torus(3 / 8.0), lwe_s, 2.0 ** -20)
+    sa = oracle.multivalue_bootstrap_UBR_phase1(c, su, l, Bg, unfolding)
+    theirs = ref.multivalue_bootstrap_UBR(tvs, c, h, 4)
+    for i in range(2):
+        mine = oracle.multivalue_bootstrap_UBR_phase2(tvs[i], c, sa, l, Bg, unfolding, 4)
+        assert (mine == oracle.functional_bootstrap_unfolded(tvs[i], c, su, l, Bg, 4, unfolding)).all()
+        assert oracle.torus_dist(oracle.tlwe_phase(mine, s), luts[i][3]) < 2.0 ** 58
+        assert oracle.torus_dist(oracle.tlwe_phase(mine, s), oracle.tlwe_phase(theirs[i], s)) < 2.0 ** 50
     ref.bk_free(h)
