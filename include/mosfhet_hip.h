@@ -241,6 +241,11 @@ int mosfhet_hip_multivalue_bootstrap_UBR_phase2_batch(mosfhet_hip_ctx_t ctx, mos
                                                       int tv_count, const uint64_t *d_in, const double *d_sa, int count, int torus_base,
                                                       void *stream);
 
+/* trlwe_mv_extract_tlwe (mode 0: d_out = [count][amount][N+1]), _scaling (1), _scaling_addto (2), _scaling_subto (3: d_out = [count][N+1])
+ * (src/trlwe.c:580-622); `amount` is the reference's amount / scale argument. */
+int mosfhet_hip_trlwe_mv_extract_batch(mosfhet_hip_ctx_t ctx, uint64_t *d_out, const uint64_t *d_in /*[count][2][N]*/, int N, int mode, int amount,
+                                       int count, void *stream);
+
 /* Timing hook for bench.py: runs `reps` launches of the programmable-bootstrap kernel on `stream`
  * bracketed by hipEvents ON THAT STREAM and returns the average kernel time in milliseconds
  * (synchronises the stream). */

@@ -352,6 +352,34 @@ __global__ __launch_bounds__(F::THREADS) void pbs_unfolded_kernel(UnfoldParams p
     }
 }
 
+// trlwe_mv_extract_tlwe / _scaling / _scaling_addto / _scaling_subto [src/trlwe.c:580-622].  mode 0: `amount` outputs per ciphertext,
+// out[b][i] = +-extract(in[b], idx_i) (grid.y = amount); modes 1-3: one output, out (=, +=, -=) sum_i sign_i extract(in[b], idx_i).
+// grid = (N / 256, mode 0 ? amount : 1, count)
+__global__ void mv_extract_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, int N, int mode, int amount) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= N) return;
+  const uint64_t *c = in + (size_t)blockIdx.z * 2 * N;
+  auto ext = [&](int idx) { return x <= idx ? c[idx - x] : (uint64_t)0 - c[N + idx - x]; };
+  if (mode == 0) {
+    const int i = blockIdx.y;
+    uint64_t *o = out + ((size_t)blockIdx.z * amount + i) * (N + 1);
+    const bool neg = i >= amount / 2;
+    const int idx = neg ? N - 1 - (i - amount / 2) : i;
+    o[x] = neg ? (uint64_t)0 - ext(idx) : ext(idx);
+    if (x == 0) o[N] = neg ? (uint64_t)0 - c[N + idx] : c[N + idx];
+    return;
+  }
+  uint64_t *o = out + (size_t)blockIdx.z * (N + 1);
+  uint64_t acc = 0, acc_b = 0;
+  const int first_sub = mode == 1 ? amount / 2 + 1 : amount / 2;
+  for (int i = first_sub; i < amount; i++) { const int idx = N - 1 - (i - amount / 2); acc -= ext(idx); if (x == 0) acc_b -= c[N + idx]; }
+  for (int i = 0; i < amount / 2; i++) { acc += ext(i); if (x == 0) acc_b += c[N + i]; }
+  if (mode == 1) { acc += ext(amount / 2); if (x == 0) acc_b += c[N + amount / 2]; }
+  if (mode == 1) { o[x] = acc; if (x == 0) o[N] = acc_b; }
+  else if (mode == 2) { o[x] += acc; if (x == 0) o[N] += acc_b; }
+  else { o[x] -= acc; if (x == 0) o[N] -= acc_b; }
+}
+
 // multivalue_bootstrap_UBR_phase1 [src/bootstrap.c:151-175]: the per-group TRGSW of the unfolded rotation, transformed and written
 // out: out[b][g] = DFT( sum_j X^(rot_j) su[g 2^u + j] ), [2l][2][M] complex in slot order.  grid = (2l * 2, n / u, count): one team per
 // polynomial.

@@ -327,6 +327,13 @@ class Engine:
                                                                        torus_base, self._stream()))
         return out
 
+    def trlwe_mv_extract(self, ct, mode, amount, out=None):
+        count, _, N = ct.shape
+        if out is None:
+            out = self.empty(count, amount, N + 1) if mode == 0 else self.empty(count, N + 1)
+        _check(lib().mosfhet_hip_trlwe_mv_extract_batch(self.h, _ptr(out), _ptr(ct), N, mode, amount, count, self._stream()))
+        return out
+
     def trlwe_eval_automorphism(self, gak, ct, gen, out=None):
         count = ct.shape[0]
         if out is None:

@@ -178,6 +178,9 @@ void orc_multivalue_bootstrap_UBR_phase1(const orc_fft_plan *p, double *out_dft 
 void orc_multivalue_bootstrap_UBR_phase2(const orc_fft_plan *p, Torus *out /*[N+1]*/, const Torus *tv, const Torus *in, const double *sa_dft, int n,
                     int l, int Bg_bit, int unfolding, int torus_base);                    /* bootstrap.c:177-190 */
 
+void orc_trlwe_mv_extract(Torus *out, const Torus *in /*[2][N]*/, int N, int mode /*0 mv_extract, 1 scaling, 2 scaling_addto, 3 scaling_subto*/,
+                    int amount);                                                          /* trlwe.c:580-622 */
+
 /* ---- deterministic test-input generation (own code; the reference's RNG is RDRAND-seeded
  *      and not reproducible, src/misc.c:34-49) ---- */
 uint64_t orc_rng_next(orc_rng *r);                       /* splitmix64 */

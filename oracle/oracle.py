@@ -528,6 +528,13 @@ def multivalue_bootstrap_UBR_phase2(tv, c, sa_dft, l, Bg_bit, unfolding, torus_b
     return out
 
 
+def trlwe_mv_extract(c, mode, amount, acc=None):
+    N = c.shape[1]
+    out = np.zeros((amount if mode == 0 else 1, N + 1), dtype=np.uint64) if acc is None else acc.copy().reshape(1, N + 1)
+    lib().orc_trlwe_mv_extract(_u(out), _u(c), N, mode, amount)
+    return out if mode == 0 else out[0]
+
+
 # ---------------- deterministic inputs ----------------
 def gen_binary_key(rng, n):
     s = np.empty(n, dtype=np.uint64)

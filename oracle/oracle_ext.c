@@ -408,3 +408,24 @@ void orc_multivalue_bootstrap_UBR_phase2(const orc_fft_plan *p, Torus *out, cons
   orc_trlwe_extract_tlwe(out, acc, 1, N, 0);
   free(acc); free(tmp);
 }
+
+/* src/trlwe.c:580-622  the multi-value extraction helpers.  mode 0: trlwe_mv_extract_tlwe (`amount` outputs), 1: _scaling (=),
+ * 2: _scaling_addto (+=), 3: _scaling_subto (-=).  `out` holds `amount` TLWEs in mode 0, one otherwise (read in modes 2, 3). */
+void orc_trlwe_mv_extract(Torus *out, const Torus *in, int N, int mode, int amount) {
+  const size_t w = (size_t)N + 1;
+  if (mode == 0) {
+    for (int i = 0; i < amount / 2; i++) orc_trlwe_extract_tlwe(out + i * w, in, 1, N, i);
+    for (int i = amount / 2; i < amount; i++) {
+      orc_trlwe_extract_tlwe(out + i * w, in, 1, N, N - 1 - (i - amount / 2));
+      for (size_t c = 0; c < w; c++) out[i * w + c] = (Torus)0 - out[i * w + c];
+    }
+  } else if (mode == 1) {
+    orc_trlwe_extract_tlwe(out, in, 1, N, amount / 2);
+    for (int i = amount / 2 + 1; i < amount; i++) extract_acc(out, in, N, N - 1 - (i - amount / 2), -1);
+    for (int i = 0; i < amount / 2; i++) extract_acc(out, in, N, i, +1);
+  } else {
+    const int s = mode == 2 ? +1 : -1;
+    for (int i = amount / 2; i < amount; i++) extract_acc(out, in, N, N - 1 - (i - amount / 2), -s);
+    for (int i = 0; i < amount / 2; i++) extract_acc(out, in, N, i, s);
+  }
+}

@@ -643,6 +643,25 @@ void ref_multivalue_bootstrap_UBR(Torus *out /*[n_tv][N+1]*/, const Torus *tvs /
   free_tlwe(o);
 }
 
+/* trlwe_mv_extract_tlwe / _scaling / _scaling_addto / _scaling_subto (src/trlwe.c:580-622); modes as in the oracle */
+void ref_trlwe_mv_extract(Torus *out, const Torus *in, int N, int mode, int amount) {
+  TRLWE c = trlwe_from_flat(in, 1, N);
+  if (mode == 0) {
+    TLWE *o = tlwe_alloc_sample_array(amount, N);
+    trlwe_mv_extract_tlwe(o, c, amount);
+    for (int i = 0; i < amount; i++) tlwe_to_flat(out + (size_t)i * (N + 1), o[i]);
+    free_tlwe_array(o, amount);
+  } else {
+    TLWE o = tlwe_from_flat(out, N);
+    if (mode == 1) trlwe_mv_extract_tlwe_scaling(o, c, amount);
+    else if (mode == 2) trlwe_mv_extract_tlwe_scaling_addto(o, c, amount);
+    else trlwe_mv_extract_tlwe_scaling_subto(o, c, amount);
+    tlwe_to_flat(out, o);
+    free_tlwe(o);
+  }
+  free_trlwe(c);
+}
+
 /* ---------- CPU baseline: time `reps` reference programmable bootstraps on the calling thread.
  * Re-entrant across threads once ref_init(N) has run on the main thread (FFT processors are
  * __thread, src/polynomial.c:338-349). Returns elapsed seconds. ---------- */

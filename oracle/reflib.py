@@ -319,6 +319,12 @@ class Ref:
         self.l.ref_multivalue_bootstrap_UBR(_u(out), _u(tvs), n_tv, _u(c), bkh, torus_base)
         return out
 
+    def trlwe_mv_extract(self, c, mode, amount, acc=None):
+        N = c.shape[1]
+        out = np.zeros((amount if mode == 0 else 1, N + 1), dtype=np.uint64) if acc is None else acc.copy().reshape(1, N + 1)
+        self.l.ref_trlwe_mv_extract(_u(out), _u(c), N, mode, amount)
+        return out if mode == 0 else out[0]
+
     def bench_programmable_bootstrap(self, tv, c, h, precision, reps):
         """Seconds for `reps` programmable_bootstrap calls on the calling thread (GIL released)."""
         return self.l.ref_bench_programmable_bootstrap(_u(tv), _u(c), h, precision, reps)

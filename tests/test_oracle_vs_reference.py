@@ -271,8 +271,11 @@ def test_multivalue_phases(oracle, ref, wide):
             assert (out == ref.multivalue_bootstrap_phase2(lut_in, theirs, tb, log_tb)).all()
     acc = oracle.u64(rng.words(N + 1))
     c2 = oracle.u64(rng.words(2 * N)).reshape(2, N)
-    for scale in (1, 2, 4, 8):
-        assert oracle.trlwe_mv_extract_tlwe_scaling_addto(acc, c2, scale).shape == (N + 1,)
+    for scale in (1, 2, 4, 8):     # the extraction helpers (src/trlwe.c:580-622): integer, bit-exact
+        assert (oracle.trlwe_mv_extract_tlwe_scaling_addto(acc, c2, scale) == ref.trlwe_mv_extract(c2, 2, scale, acc=acc)).all()
+        for mode in (0, 1, 2, 3):
+            a = None if mode < 2 else acc
+            assert (oracle.trlwe_mv_extract(c2, mode, scale, acc=a) == ref.trlwe_mv_extract(c2, mode, scale, acc=a)).all(), (mode, scale)
 
 
 def test_circuit_bootstrap_variants(oracle, ref, wide):
