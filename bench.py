@@ -199,7 +199,7 @@ def main():
                                                           "no collective on the data path" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "pbs_kernel_1024<2>", "kernel_ms": kernel_ms,
+                         "kernel": "mosfhet::pbs_kernel<mosfhet::Fft1024, 2, 8>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
             "cpu_baseline": cpu,
             "max_phase_error_log2": float(np.log2(err + 1)),
