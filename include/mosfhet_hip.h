@@ -246,6 +246,14 @@ int mosfhet_hip_multivalue_bootstrap_UBR_phase2_batch(mosfhet_hip_ctx_t ctx, mos
 int mosfhet_hip_trlwe_mv_extract_batch(mosfhet_hip_ctx_t ctx, uint64_t *d_out, const uint64_t *d_in /*[count][2][N]*/, int N, int mode, int amount,
                                        int count, void *stream);
 
+/* On-device generation of a table-lookup TRLWE key (the 6 GB packing key of config 4 in milliseconds): kind 0 = packing key
+ * (trlwe_new_packing1_KS_key, src/keyswitch.c:368-390), kind 1 = private key (trlwe_new_priv_SK_KS_key_N2, :611-637); rows are fresh
+ * TRLWE encryptions under the binary key h_s_out[N] (exact a * s, Gaussian noise sigma, counter-based generator seeded by `seed`).
+ * ksk_export_rows copies rows [first_row, first_row + count) back for inspection. */
+int mosfhet_hip_trlwe_table_ksk_generate(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t *out, int kind, const uint64_t *h_s_out, int N,
+                                         const uint64_t *h_s_in, int n, int t, int base_bit, double sigma, uint64_t seed);
+int mosfhet_hip_ksk_export_rows(mosfhet_hip_ksk_t ksk, size_t first_row, size_t count, uint64_t *h_out);
+
 /* Timing hook for bench.py: runs `reps` launches of the programmable-bootstrap kernel on `stream`
  * bracketed by hipEvents ON THAT STREAM and returns the average kernel time in milliseconds
  * (synchronises the stream). */

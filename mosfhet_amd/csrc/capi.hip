@@ -15,6 +15,7 @@
 #include "bootstrap_kernels.h"
 #include "keyswitch_kernels.h"
 #include "ext_kernels.h"
+#include "keygen_kernels.h"
 
 using namespace mosfhet;
 

@@ -891,18 +891,23 @@ static void trlwe_ks_run(int mode, TRLWE out, TRLWE in, TRLWE_KS_Key key) {
 void trlwe_keyswitch(TRLWE out, TRLWE in, TRLWE_KS_Key ks_key) { trlwe_ks_run(0, out, in, ks_key); }
 void trlwe_priv_keyswitch_2(TRLWE out, TRLWE in, TRLWE_KS_Key *ks_key) { trlwe_ks_run(1, out, in, ks_key[0]); }
 
-Generic_KS_Key trlwe_new_packing1_KS_key(TRLWE_Key out_key, TLWE_Key in_key, int t, int base_bit) {
-  const int N = out_key->s[0]->N, base = 1 << base_bit;
-  if (out_key->k != 1) { fprintf(stderr, "mosfhet_amd: trlwe_new_packing1_KS_key: k = 1 only\n"); abort(); }
+/* The rows are generated ON THE DEVICE (mosfhet_hip_trlwe_table_ksk_generate: exact a * s, Gaussian noise, counter-based generator
+ * seeded from the host generator): the 6 GB packing key of test_circuit_bootstrap (test/tests.c:974) takes milliseconds. */
+static Generic_KS_Key table_key_new(int kind, TRLWE_Key out_key, TLWE_Key in_key, int t, int base_bit, const char *who) {
+  const int N = out_key->s[0]->N;
+  if (out_key->k != 1) { fprintf(stderr, "mosfhet_amd: %s: k = 1 only\n", who); abort(); }
   Generic_KS_Key res = (Generic_KS_Key)xmalloc(sizeof(*res));
-  res->s = NULL; res->base_bit = base_bit; res->t = t; res->n = in_key->n; res->include_b = 0;
-  Torus *flat = (Torus *)xmalloc(sizeof(Torus) * (size_t)in_key->n * t * (base - 1) * 2 * N);
-  mosfhet_gen_packing1_ks_key_flat(flat, out_key, in_key, t, base_bit);
+  res->s = NULL; res->base_bit = base_bit; res->t = t; res->n = in_key->n; res->include_b = kind;
   mosfhet_hip_ksk_t dev = NULL;
-  if (mosfhet_hip_packing1_ksk_create((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, flat, in_key->n, N, t, base_bit)) die("trlwe_new_packing1_KS_key");
-  free(flat);
+  if (mosfhet_hip_trlwe_table_ksk_generate((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, kind, out_key->s[0]->coeffs, N, in_key->s, in_key->n, t, base_bit,
+                                           out_key->sigma, rnd64()))
+    die(who);
   res->device = dev;
   return res;
+}
+
+Generic_KS_Key trlwe_new_packing1_KS_key(TRLWE_Key out_key, TLWE_Key in_key, int t, int base_bit) {
+  return table_key_new(0, out_key, in_key, t, base_bit, "trlwe_new_packing1_KS_key");
 }
 
 void free_trlwe_generic_ks_key(Generic_KS_Key key) {
@@ -983,17 +988,7 @@ void mosfhet_gen_priv_sk_ks_key_flat(Torus *out, TRLWE_Key out_key, TLWE_Key in_
 }
 
 Generic_KS_Key trlwe_new_priv_SK_KS_key_N2(TRLWE_Key out_key, TLWE_Key in_key, int t, int base_bit) {
-  const int N = out_key->s[0]->N, base = 1 << base_bit;
-  if (out_key->k != 1) { fprintf(stderr, "mosfhet_amd: trlwe_new_priv_SK_KS_key_N2: k = 1 only\n"); abort(); }
-  Generic_KS_Key res = (Generic_KS_Key)xmalloc(sizeof(*res));
-  res->s = NULL; res->base_bit = base_bit; res->t = t; res->n = in_key->n; res->include_b = 1;
-  Torus *flat = (Torus *)xmalloc(sizeof(Torus) * ((size_t)in_key->n + 1) * t * (base - 1) * 2 * N);
-  mosfhet_gen_priv_sk_ks_key_flat(flat, out_key, in_key, t, base_bit);
-  mosfhet_hip_ksk_t dev = NULL;
-  if (mosfhet_hip_priv_ksk_create(ectx(), &dev, flat, in_key->n, N, t, base_bit)) die("trlwe_new_priv_SK_KS_key_N2");
-  free(flat);
-  res->device = dev;
-  return res;
+  return table_key_new(1, out_key, in_key, t, base_bit, "trlwe_new_priv_SK_KS_key_N2");
 }
 
 void trlwe_priv_keyswitch(TRLWE out, TLWE in, Generic_KS_Key ks) {

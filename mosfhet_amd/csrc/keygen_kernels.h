@@ -1,0 +1,68 @@
+// keygen_kernels.h -- on-device generation of the multi-gigabyte table-lookup TRLWE key-switch keys: the
+// packing key of trlwe_new_packing1_KS_key (src/keyswitch.c:368-390) and the private key of trlwe_new_priv_SK_KS_key_N2
+// (src/keyswitch.c:611-637).  Every row is a fresh TRLWE encryption under the binary key s_out:
+//     a uniform,  b = a * s_out + e + message,  e ~ N(0, sigma) on the torus  (src/trlwe.c:296-316)
+// with a counter-based generator (splitmix64 of (seed, row, coefficient)) instead of the reference's AES / SHAKE streams
+// (src/misc.c:34-91): statistically the same objects, reproducible from the seed, and a 6 GB key takes milliseconds instead of
+// minutes of host time.  The product a * s_out is exact (integer adds over the set bits of the key).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mosfhet {
+
+__device__ __forceinline__ uint64_t keygen_mix(uint64_t seed, uint64_t row, uint64_t idx, uint64_t stream) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (row * 0x100000001B3ull + idx * 4 + stream + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// kind 0 (packing): rows (i < n, j < t, v in 1..2^bb-1), message = s_in[i] v 2^(64-(j+1)bb) on X^0
+// kind 1 (private): rows (i <= n, ...), message polynomial = -s_out * (s_i v 2^(64-(j+1)bb)), s_n = -1
+// One workgroup of 256 threads per row; the mask lives in LDS while the key's set bits are walked.
+__global__ __launch_bounds__(256) void trlwe_table_keygen_kernel(uint64_t *__restrict__ rows, const uint64_t *__restrict__ s_out,
+                                                               const uint64_t *__restrict__ s_in, int n, int N, int t, int base_bit, double sigma,
+                                                               uint64_t seed, int kind, size_t first_row) {
+  extern __shared__ uint64_t sh[];   // a[N], then the indices of the set key bits (uint16) packed behind it
+  uint64_t *a = sh;
+  uint16_t *ones = reinterpret_cast<uint16_t *>(sh + N);
+  __shared__ int n_ones;
+  const int tid = threadIdx.x;
+  const size_t r = first_row + blockIdx.x;
+  const int cands = (1 << base_bit) - 1;
+  const int v = (int)(r % cands) + 1, j = (int)((r / cands) % t), i = (int)(r / ((size_t)cands * t));
+  uint64_t *dst = rows + r * 2 * (size_t)N;
+  if (tid == 0) {
+    int c = 0;
+    for (int x = 0; x < N; x++)
+      if (s_out[x] & 1) ones[c++] = (uint16_t)x;
+    n_ones = c;
+  }
+  for (int x = tid; x < N; x += 256) {
+    const uint64_t ax = keygen_mix(seed, r, x, 0);
+    a[x] = ax;
+    dst[x] = ax;
+  }
+  __syncthreads();
+  const uint64_t s_i = i < n ? s_in[i] : ~0ull;
+  const uint64_t dec = s_i * (uint64_t)v * (1ull << (64 - (j + 1) * base_bit));
+  const int cnt = n_ones;
+  for (int x = tid; x < N; x += 256) {
+    uint64_t acc = 0;
+    for (int q = 0; q < cnt; q++) {       // (a * s)[x] = sum over set bits p of +-a[x - p]  (negacyclic wrap)
+      const int p = ones[q], src = x - p;
+      const uint64_t w = a[src & (N - 1)];
+      acc += src < 0 ? (uint64_t)0 - w : w;
+    }
+    // Box-Muller on two uniforms (src/misc.c:87-91), double2torus of sigma * z (src/misc.c:13-15)
+    const double u1 = ((double)(keygen_mix(seed, r, x, 1) >> 11) + 0.5) * 0x1p-53, u2 = ((double)(keygen_mix(seed, r, x, 2) >> 11) + 0.5) * 0x1p-53;
+    const double z = cos(6.283185307179586 * u1) * sqrt(-2.0 * log(u2)) * sigma;
+    acc += (uint64_t)(int64_t)(18446744073709551616.0 * z);
+    if (kind == 0) { if (x == 0) acc += dec; }
+    else acc += ((uint64_t)0 - s_out[x]) * dec;
+    dst[N + x] = acc;
+  }
+}
+
+}  // namespace mosfhet

@@ -334,6 +334,20 @@ class Engine:
         _check(lib().mosfhet_hip_trlwe_mv_extract_batch(self.h, _ptr(out), _ptr(ct), N, mode, amount, count, self._stream()))
         return out
 
+    def generate_table_key(self, kind, s_out, s_in, t, base_bit, sigma, seed):
+        """On-device packing (kind 0) / private (kind 1) key-switch key; returns a KeySwitchKey."""
+        s_out = np.ascontiguousarray(s_out, dtype=np.uint64)
+        s_in = np.ascontiguousarray(s_in, dtype=np.uint64)
+        h = C.c_void_p()
+        _check(lib().mosfhet_hip_trlwe_table_ksk_generate(self.h, C.byref(h), kind, s_out.ctypes.data_as(C.c_void_p), s_out.size,
+                                                          s_in.ctypes.data_as(C.c_void_p), s_in.size, t, base_bit, C.c_double(sigma), C.c_uint64(seed)))
+        return KeySwitchKey(self, h, s_in.size + kind, 2 * s_out.size - 1, t, base_bit)
+
+    def export_key_rows(self, ksk, first_row, count):
+        out = np.empty((count, ksk.n_out + 1), dtype=np.uint64)
+        _check(lib().mosfhet_hip_ksk_export_rows(ksk.h, C.c_size_t(first_row), C.c_size_t(count), out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def trlwe_eval_automorphism(self, gak, ct, gen, out=None):
         count = ct.shape[0]
         if out is None:
