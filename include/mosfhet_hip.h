@@ -254,6 +254,11 @@ int mosfhet_hip_trlwe_table_ksk_generate(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_
                                          const uint64_t *h_s_in, int n, int t, int base_bit, double sigma, uint64_t seed);
 int mosfhet_hip_ksk_export_rows(mosfhet_hip_ksk_t ksk, size_t first_row, size_t count, uint64_t *h_out);
 
+/* Kernel selection for the N = 1024 bootstraps: batches of at most `max_batch` ciphertexts run the latency-oriented kernel (one workgroup
+ * of 2l wavefronts per ciphertext, ~1/3 of the latency), larger ones the throughput kernel (one wavefront per ciphertext).  Results are
+ * bit-identical.  Default 512 (or env MOSFHET_HIP_TEAM_MAX); 0 disables the latency kernel. */
+int mosfhet_hip_set_team_max_batch(int max_batch);
+
 /* Timing hook for bench.py: runs `reps` launches of the programmable-bootstrap kernel on `stream`
  * bracketed by hipEvents ON THAT STREAM and returns the average kernel time in milliseconds
  * (synchronises the stream). */

@@ -324,6 +324,108 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Latency-oriented variant for SMALL batches (fewer ciphertexts than the chip has CUs x 8): one workgroup of 2L wavefronts per
+// ciphertext, wavefront w owns TRGSW row w of every CMUX (its digits, its forward transform), then wavefronts 0 and 1 run the
+// multiply-accumulate over all rows -- in row order, the same fma chain as pbs_kernel and the oracle, so results are bit-identical --
+// and the inverse transform of one output component each.  Per CMUX the critical path is 1 forward + 1 inverse transform instead of
+// 2L + 2: a single bootstrap takes ~1/3 of the time, at ~1/3 of the throughput kernel's per-CU rate (capi.hip picks by batch size).
+// Accumulator (both components) in LDS; per-wavefront transpose buffers; the transformed digits are handed over through LDS.
+// N = 1024 only (Fft1024: wave-level transposes, workgroup barriers only at the two hand-overs).
+// ------------------------------------------------------------------------------------------------------------
+template <int L, int BG>
+__global__ __launch_bounds__(64 * 2 * L) void pbs_team_kernel(PbsParams p) {
+  using F = Fft1024;
+  constexpr int N = F::N, M = F::M, T = F::THREADS, LOG2N2 = F::LOGM + 2, R = 2 * L, TEAM = T * R;
+  __shared__ __attribute__((aligned(16))) d2 xch[R][F::XCH_SLOTS];     // transposes; after the forward transform: D_w (slots m T + t)
+  __shared__ __attribute__((aligned(16))) d2 xinv[2][F::XCH_SLOTS];    // transposes of the two inverse transforms
+  __shared__ __attribute__((aligned(16))) uint64_t acc[2][N];
+  const int tid = threadIdx.x, w = tid >> 6, t = tid & 63;
+  const size_t b = blockIdx.x;
+  const uint64_t *__restrict__ ct = p.in + b * (size_t)(p.n + 1);
+  const int Bg_bit = BG > 0 ? BG : p.Bg_bit;
+  F fft;
+  fft.init(p.tw, t);
+  if (p.skip_init) {
+    const uint64_t *src = p.out + b * (size_t)(2 * N);
+    for (int x = tid; x < 2 * N; x += TEAM) acc[x >> 10][x & (N - 1)] = src[x];
+  } else {
+    const uint64_t *__restrict__ tv = p.tv + b * (size_t)p.tv_stride;
+    const uint32_t bbar = modswitch<LOG2N2>(pbs_pre(ct[p.n], p, LOG2N2) + p.prec_offset);
+    const int rot = (2 * N - (int)bbar) & (2 * N - 1);
+    const int a_lo = rot & (N - 1);
+    const bool flip = (rot & N) != 0;
+    for (int x = tid; x < 2 * N; x += TEAM) acc[x >> 10][x & (N - 1)] = rot_coeff<N>(tv + (x >> 10) * N, x & (N - 1), a_lo, flip);
+  }
+  __syncthreads();
+  uint64_t off = 1ull << (63 - L * Bg_bit);
+#pragma unroll
+  for (int i = 0; i < L; i++) off += 1ull << (63 - i * Bg_bit);
+  const RoundCtx scale(0x1p-64 / (double)M);
+  const size_t row_sz = (size_t)2 * L * 2 * M;
+  const int q = w / L, shift = 64 - (w % L + 1) * Bg_bit;   // this wavefront's row: component q, level w % L
+  const uint32_t mask = (1u << Bg_bit) - 1;
+  const int half = 1 << (Bg_bit - 1);
+  for (int i = 0; i < p.n; i++) {
+    const int abar = (int)modswitch<LOG2N2>(pbs_pre(ct[i], p, LOG2N2));
+    if (!abar) continue;   // src/bootstrap.c:114 (uniform over the workgroup)
+    const d2 *__restrict__ bkrow = p.bk + (size_t)i * row_sz;
+    const int a_lo = abar & (N - 1);
+    const bool flip = (abar & N) != 0;
+    // wavefronts 0 and 1 fetch their component of all R key rows now, under the digit extraction and the forward transform
+    d2 kk[R][8];
+    if (w < 2) {
+#pragma unroll
+      for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int m = 0; m < 8; m++) kk[r][m] = bkrow[(size_t)r * (2 * M) + (size_t)w * M + m * T + t];
+    }
+    double re[8], im[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int j = m * T + t;
+      const uint64_t d_lo = rot_coeff<N>(acc[q], j, a_lo, flip) - acc[q][j] + off;
+      const uint64_t d_hi = rot_coeff<N>(acc[q], j + M, a_lo, flip) - acc[q][j + M] + off;
+      re[m] = (double)((int)((uint32_t)(d_lo >> shift) & mask) - half);
+      im[m] = (double)((int)((uint32_t)(d_hi >> shift) & mask) - half);
+    }
+    fft.forward(re, im, xch[w], t);
+#pragma unroll
+    for (int m = 0; m < 8; m++) xch[w][m * T + t] = d2{re[m], im[m]};
+    __syncthreads();
+    if (w < 2) {   // output component c = w: fma chain over the rows in order, inverse, round, accumulate
+      double o_re[8], o_im[8];
+#pragma unroll
+      for (int m = 0; m < 8; m++) { o_re[m] = 0.0; o_im[m] = 0.0; }
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          const d2 d = xch[r][m * T + t], k = kk[r][m];
+          o_re[m] = __builtin_fma(-d.y, k.y, __builtin_fma(d.x, k.x, o_re[m]));
+          o_im[m] = __builtin_fma(d.y, k.x, __builtin_fma(d.x, k.y, o_im[m]));
+        }
+      }
+      fft.inverse(o_re, o_im, xinv[w], t);
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        acc[w][m * T + t] += round_mod_2_64(o_re[m], scale);
+        acc[w][M + m * T + t] += round_mod_2_64(o_im[m], scale);
+      }
+    }
+    __syncthreads();
+  }
+  if (p.extract) {
+    // src/trlwe.c:540-552 at idx = 0
+    uint64_t *dst = p.out + b * (size_t)(N + 1);
+    for (int j = tid; j < N; j += TEAM) dst[j] = (j == 0) ? acc[0][0] : (0 - acc[0][N - j]);
+    if (tid == 0) dst[N] = acc[1][0];
+  } else {
+    uint64_t *dst = p.out + b * (size_t)(2 * N);
+    for (int x = tid; x < 2 * N; x += TEAM) dst[x] = acc[x >> 10][x & (N - 1)];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Galois-automorphism bootstrap [src/bootstrap_ga.c:39-76] and its building blocks:
 //   trlwe_keyswitch          [src/keyswitch.c:162-193]  out = (0, b) - IDFT(sum_j DFT(digit_j(a)) (.) KS[j])
 //   trlwe_eval_automorphism  [src/trlwe.c:775-781, src/polynomial.c:442-450]  X -> X^gen on both components, then

@@ -256,6 +256,21 @@ static int launch_pbs_f(int l, int Bg_bit, const PbsParams &p, int count, hipStr
   return MOSFHET_HIP_OK;
 }
 
+// Batches up to this size take pbs_team_kernel (N = 1024): below ~1.5 workgroups per CU the one-wavefront-per-ciphertext kernel leaves
+// most of the chip idle and a bootstrap's latency is what counts.  MOSFHET_HIP_TEAM_MAX overrides (0 disables).
+static int g_team_max = -1;
+static int team_max_batch() {
+  if (g_team_max < 0) {
+    const char *e = getenv("MOSFHET_HIP_TEAM_MAX");
+    g_team_max = e ? atoi(e) : 512;
+  }
+  return g_team_max;
+}
+extern "C" int mosfhet_hip_set_team_max_batch(int max_batch) {
+  g_team_max = max_batch < 0 ? 0 : max_batch;
+  return MOSFHET_HIP_OK;
+}
+
 static int bootstrap_unfolded(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_out, const uint64_t *d_tv, int tv_count,
                               const uint64_t *d_in, int count, int pre, int torus_base, int extract, int skip_init, void *stream, int rows);
 
@@ -287,6 +302,21 @@ static int bootstrap_common(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hip_
   p.extract = extract;
   p.skip_init = skip_init;
   p.rows = rows;
+  // small batches: the latency-oriented team kernel (one workgroup of 2l wavefronts per ciphertext), N = 1024
+  if (bsk->N == 1024 && rows == 1 && count <= team_max_batch() && bsk->l <= 4) {
+    hipStream_t s = pick(ctx, stream);
+    const int l = bsk->l, Bg = bsk->Bg_bit;
+#define TEAM_LAUNCH(LL, BB) hipLaunchKernelGGL((pbs_team_kernel<LL, BB>), dim3((unsigned)count), dim3(64 * 2 * LL), 0, s, p)
+    if (l == 2 && Bg == 8) TEAM_LAUNCH(2, 8);
+    else if (l == 4 && Bg == 9) TEAM_LAUNCH(4, 9);
+    else if (l == 1) TEAM_LAUNCH(1, 0);
+    else if (l == 2) TEAM_LAUNCH(2, 0);
+    else if (l == 3) TEAM_LAUNCH(3, 0);
+    else TEAM_LAUNCH(4, 0);
+#undef TEAM_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return MOSFHET_HIP_OK;
+  }
   return bsk->N == 1024 ? launch_pbs_f<Fft1024>(bsk->l, bsk->Bg_bit, p, count, pick(ctx, stream))
                         : launch_pbs_f<Fft2048>(bsk->l, bsk->Bg_bit, p, count, pick(ctx, stream));
 }

@@ -484,6 +484,11 @@ class Engine:
         self.torch.cuda.current_stream(self.device).synchronize()
 
 
+def set_team_max_batch(max_batch):
+    """Batches up to this size use the latency-oriented bootstrap kernel at N = 1024 (0 disables it)."""
+    _check(lib().mosfhet_hip_set_team_max_batch(int(max_batch)))
+
+
 def twiddles(N):
     out = np.empty(2 * (N // 2 - 1), dtype=np.float64)
     _check(lib().mosfhet_hip_twiddles(N, out.ctypes.data_as(C.c_void_p)))
