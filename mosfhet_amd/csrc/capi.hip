@@ -277,7 +277,9 @@ static int bootstrap_unfolded(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hi
 static int bootstrap_common(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_out,
                             const uint64_t *d_tv, int tv_count, const uint64_t *d_in, int count, int pre, int kappa,
                             int theta, int torus_base, int extract, int skip_init, void *stream, int rows = 1) {
-  if (!ctx || !bsk || !d_out || !d_in || count < 0) return fail(MOSFHET_HIP_EINVAL, "%s: bad argument", who);
+  if (!ctx || !bsk || count < 0) return fail(MOSFHET_HIP_EINVAL, "%s: bad argument", who);
+  if (count == 0) return MOSFHET_HIP_OK;   // an empty batch is a no-op (its buffers may be null)
+  if (!d_out || !d_in) return fail(MOSFHET_HIP_EINVAL, "%s: null buffer", who);
   if (!skip_init && rows == 1 && (!d_tv || (tv_count != 1 && tv_count != count)))
     return fail(MOSFHET_HIP_EINVAL, "%s: tv_count must be 1 or count (got %d, count %d)", who, tv_count, count);
   if (!skip_init && torus_base < 1) return fail(MOSFHET_HIP_EINVAL, "%s: torus_base %d", who, torus_base);
@@ -439,8 +441,9 @@ extern "C" int mosfhet_hip_ksk_destroy(mosfhet_hip_ksk_t ksk) {
 
 extern "C" int mosfhet_hip_tlwe_keyswitch_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t ksk, uint64_t *d_out, const uint64_t *d_in,
                                                 int count, void *stream) {
-  if (!ctx || !ksk || !d_out || !d_in || count < 0) return fail(MOSFHET_HIP_EINVAL, "tlwe_keyswitch: bad argument");
+  if (!ctx || !ksk || count < 0) return fail(MOSFHET_HIP_EINVAL, "tlwe_keyswitch: bad argument");
   if (count == 0) return MOSFHET_HIP_OK;
+  if (!d_out || !d_in) return fail(MOSFHET_HIP_EINVAL, "tlwe_keyswitch: null buffer");
   HIP_TRY(hipSetDevice(ctx->device));
   if (ksk->b_word != ksk->n_out) return fail(MOSFHET_HIP_EINVAL, "tlwe_keyswitch: this key is a packing (LWE -> TRLWE) key");
   HIP_TRY(launch_tlwe_keyswitch(ksk->d_ksk, d_out, (size_t)ksk->row, d_in, (size_t)ksk->n_in + 1, count, ksk->n_in, ksk->row, ksk->b_word, ksk->t,
