@@ -1,10 +1,10 @@
-"""Latency of small bootstrap batches at SET_1, throughput kernel vs latency (team) kernel: tools/gpu_latency.py"""
+"""Latency of small bootstrap batches, throughput kernel vs latency (team) kernel: tools/gpu_latency.py [set1|lvl2]"""
 import sys, time, numpy as np
 sys.path.insert(0, '.')
 import torch
 import mosfhet_amd as ma
 from mosfhet_amd import host, engine
-P = dict(ma.PARAMS_SET1)
+P = dict(ma.PARAMS_LVL2 if len(sys.argv) > 1 and sys.argv[1] == 'lvl2' else ma.PARAMS_SET1)
 host.seed(5)
 lk = host.LweKey(P['n'], P['lwe_sigma']); rk = host.RlweKey(P['N'], 1, P['rlwe_sigma'])
 eng = ma.Engine(0)
