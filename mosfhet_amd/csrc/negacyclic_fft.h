@@ -228,7 +228,7 @@ struct Fft1024 {
 // Three LDS transposes per transform, each through its own padded layout (tools/lds_layout_search.py: conflict
 // free for ds_write_b128 and ds_read_b128 in both directions, every access = thread base + immediate):
 //     A<->B: slot = j                      B<->C: slot = j + 2 (j >> 4)         C<->D: slot = j + (j >> 3)
-// The two wavefronts hand data to each other, so every transpose is bracketed by workgroup barriers.
+// Only the A<->B exchange crosses the two wavefronts (workgroup barriers); B<->C and C<->D are wave-local (wave-level ordering).
 // Slot order of the DFT domain = layout D: device index m * 128 + thread.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void team_sync() { __syncthreads(); }
@@ -285,21 +285,24 @@ struct Fft2048 {
     }
     pass_fwd(re, im, wb);
     team_sync();
+    // From here on the wavefront index is j[9] in every layout (B: t = 16 j[9:7] + j[3:0], C: t = 2 j[9:4] + j[0], D: t = j[9:3]) and
+    // both slot maps send j < 512 to slots < 576 and j >= 512 to slots >= 576: the B<->C and C<->D exchanges stay inside a wavefront
+    // and its own half of the buffer, so wave-level ordering is enough (3 workgroup barriers per transform instead of 6).
     {
       d2 *w = xch + base_b2(t), *r = xch + base_c2(t);
 #pragma unroll
       for (int m = 0; m < 8; m++) w[18 * m] = d2{re[m], im[m]};
-      team_sync();
+      wave_lds_sync();
 #pragma unroll
       for (int m = 0; m < 8; m++) { const d2 v = r[2 * m]; re[m] = v.x; im[m] = v.y; }
     }
     pass_fwd(re, im, wc);
-    team_sync();
+    wave_lds_sync();
     {
       d2 *w = xch + base_c3(t), *r = xch + base_d3(t);
 #pragma unroll
       for (int m = 0; m < 8; m++) w[off_c3(m)] = d2{re[m], im[m]};
-      team_sync();
+      wave_lds_sync();
 #pragma unroll
       for (int m = 0; m < 8; m++) { const d2 v = r[m]; re[m] = v.x; im[m] = v.y; }
     }
@@ -316,21 +319,21 @@ struct Fft2048 {
   // inverse: input in layout D, output in layout A, UNSCALED
   __device__ __forceinline__ void inverse(double (&re)[8], double (&im)[8], d2 *xch, int t) const {
     pass_d_inv(re, im);
-    {
+    {  // D -> C and C -> B stay inside a wavefront (see forward_head): wave-level ordering
       d2 *w = xch + base_d3(t), *r = xch + base_c3(t);
 #pragma unroll
       for (int m = 0; m < 8; m++) w[m] = d2{re[m], im[m]};
-      team_sync();
+      wave_lds_sync();
 #pragma unroll
       for (int m = 0; m < 8; m++) { const d2 v = r[off_c3(m)]; re[m] = v.x; im[m] = v.y; }
     }
     pass_inv(re, im, wc);
-    team_sync();
+    wave_lds_sync();
     {
       d2 *w = xch + base_c2(t), *r = xch + base_b2(t);
 #pragma unroll
       for (int m = 0; m < 8; m++) w[2 * m] = d2{re[m], im[m]};
-      team_sync();
+      wave_lds_sync();
 #pragma unroll
       for (int m = 0; m < 8; m++) { const d2 v = r[18 * m]; re[m] = v.x; im[m] = v.y; }
     }
