@@ -259,6 +259,13 @@ int mosfhet_hip_ksk_export_rows(mosfhet_hip_ksk_t ksk, size_t first_row, size_t 
  * bit-identical.  Default 512 (or env MOSFHET_HIP_TEAM_MAX); 0 disables the latency kernel. */
 int mosfhet_hip_set_team_max_batch(int max_batch);
 
+/* The canonical caller pattern in one call (applications/multi-ciphertext-arith/src/integer.c:94-95): tlwe_keyswitch kN -> n, then
+ * functional_bootstrap (extract = 1: d_out [count][kN+1]) or functional_bootstrap_wo_extract (extract = 0: d_out [count][k+1][N]);
+ * same stream, no host synchronisation in between. */
+int mosfhet_hip_keyswitch_functional_bootstrap_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t ksk, mosfhet_hip_bsk_t bsk, uint64_t *d_out,
+                                                     const uint64_t *d_tv, int tv_count, const uint64_t *d_in /*[count][kN+1]*/, int count,
+                                                     int torus_base, int extract, void *stream);
+
 /* Timing hook for bench.py: runs `reps` launches of the programmable-bootstrap kernel on `stream`
  * bracketed by hipEvents ON THAT STREAM and returns the average kernel time in milliseconds
  * (synchronises the stream). */

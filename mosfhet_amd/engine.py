@@ -348,6 +348,15 @@ class Engine:
         _check(lib().mosfhet_hip_ksk_export_rows(ksk.h, C.c_size_t(first_row), C.c_size_t(count), out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def keyswitch_functional_bootstrap(self, ksk, bsk, tv, ct, torus_base, extract=True, out=None):
+        """tlwe_keyswitch N -> n followed by functional_bootstrap[_wo_extract] in one call."""
+        count = ct.shape[0]
+        if out is None:
+            out = self.empty(count, bsk.N + 1) if extract else self.empty(count, 2, bsk.N)
+        _check(lib().mosfhet_hip_keyswitch_functional_bootstrap_batch(self.h, ksk.h, bsk.h, _ptr(out), _ptr(tv), self._tv(tv, bsk, count), _ptr(ct), count,
+                                                                      torus_base, int(extract), self._stream()))
+        return out
+
     def trlwe_eval_automorphism(self, gak, ct, gen, out=None):
         count = ct.shape[0]
         if out is None:
