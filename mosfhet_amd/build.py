@@ -26,18 +26,48 @@ def _hipcc():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
+STAMP = LIB + ".srchash"   # content hash of the sources the library was built from (travels with the .so)
+
+
+def _source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(HIP_SOURCES + HOST_C_SOURCES + DEPS):
+        path = os.path.join(CSRC, f)
+        if os.path.exists(path):
+            h.update(f.encode())
+            with open(path, "rb") as fh:
+                h.update(fh.read())
+    h.update(os.environ.get("MOSFHET_HIPCC_EXTRA", "").encode())
+    return h.hexdigest()
+
+
 def _stale():
-    if not os.path.exists(LIB):
+    """Stale = the sources' CONTENT differs from what the library was built from (mtimes do not survive the copy to a GPU box,
+    and a rebuild there by every rank at once would race)."""
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    files = HIP_SOURCES + HOST_C_SOURCES + DEPS
-    return any(os.path.exists(os.path.join(CSRC, f)) and os.path.getmtime(os.path.join(CSRC, f)) > t for f in files)
+    with open(STAMP) as fh:
+        return fh.read().strip() != _source_hash()
 
 
 def build(force=False, verbose=False):
     """Compile csrc/*.hip (device + C ABI) and csrc/host/*.c (MOSFHET-compatible host layer) into one .so."""
     if not force and not _stale():
         return LIB
+    import fcntl
+    lock = open(LIB + ".lock", "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)   # one builder at a time (torch.distributed.run starts one process per GPU)
+    try:
+        if not force and not _stale():
+            return LIB
+        return _build_locked(verbose)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(verbose):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     objs = []
@@ -53,15 +83,19 @@ def build(force=False, verbose=False):
         objs.append(obj)
     for src in HIP_SOURCES:
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        cmd = [_hipcc()] + HIPCC_FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [_hipcc()] + HIPCC_FLAGS + os.environ.get("MOSFHET_HIPCC_EXTRA", "").split() + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lm"]
+    tmp = LIB + ".tmp.%d" % os.getpid()
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs + ["-lm"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    os.replace(tmp, LIB)
+    with open(STAMP, "w") as fh:
+        fh.write(_source_hash() + "\n")
     return LIB
 
 
