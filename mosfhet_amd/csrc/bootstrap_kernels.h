@@ -183,7 +183,9 @@ __device__ __forceinline__ void cmux_rows(const typename Digits<L, BG>::word_t (
                                           const F &fft, const d2 *__restrict__ bkrow, int Bg_bit, int t) {
   constexpr int M = F::M, T = F::THREADS;
   using D = Digits<L, BG>;
-#pragma unroll 1
+  // two levels are unrolled (the next row's digit conversion and first pass overlap the MAC tail; no scratch at l = 2), more stay rolled
+  constexpr int kUnroll = L <= 2 ? L : 1;
+#pragma unroll kUnroll
   for (int lv = 0; lv < L; lv++) {
     const d2 *__restrict__ row = bkrow + (size_t)(p * L + lv) * (2 * M);
     double re[8], im[8];
