@@ -21,8 +21,12 @@
  *   return value     0 on success, a negative MOSFHET_HIP_E* code otherwise; mosfhet_hip_last_error()
  *                    returns a thread-local message.  The legacy void API of mosfhet_compat.h aborts on
  *                    error, like the reference's assert/exit behaviour (src/misc.c:104-128).
- *   supported        k = 1; N = 1024 (more ring degrees are added per round);
- *                    any l, Bg_bit with l*Bg_bit < 64; any n.
+ *   supported        k = 1; N = 1024 and N = 2048 (the reference's SET_3, N = 4096, is not built); l <= 4 with
+ *                    l*Bg_bit < 64 (compile-time specialisations for 2x8, 4x9, 1x23); any n.
+ *   threading        a context and its key handles may be used from several host threads, but calls that share a
+ *                    KEY HANDLE must be serialised by the caller (compositions keep their temporaries in the handle);
+ *                    independent handles / streams are independent.  (The reference is re-entrant through
+ *                    thread-local scratch, src/polynomial.c:269-352.)
  * DFT-domain data (bootstrap key) is device-resident in the engine's own slot order and never leaves it,
  * as in the reference where the element order is private to the FFT back-end (src/polynomial.c:336-357).
  */
