@@ -21,8 +21,8 @@
  *   return value     0 on success, a negative MOSFHET_HIP_E* code otherwise; mosfhet_hip_last_error()
  *                    returns a thread-local message.  The legacy void API of mosfhet_compat.h aborts on
  *                    error, like the reference's assert/exit behaviour (src/misc.c:104-128).
- *   supported        k = 1; N = 1024 and N = 2048 (the reference's SET_3, N = 4096, is not built); l <= 4 with
- *                    l*Bg_bit < 64 (compile-time specialisations for 2x8, 4x9, 1x23); any n.
+ *   supported        k = 1; N = 1024, 2048, 4096 (all ring degrees of the reference's parameter sets, test/tests.c:37-62);
+ *                    l <= 4 with l*Bg_bit < 64 (compile-time specialisations for 2x8, 4x9, 1x23); any n.
  *   threading        a context and its key handles may be used from several host threads, but calls that share a
  *                    KEY HANDLE must be serialised by the caller (compositions keep their temporaries in the handle);
  *                    independent handles / streams are independent.  (The reference is re-entrant through

@@ -8,5 +8,5 @@ There is NO CPU fallback: importing works without a GPU (so the build can be che
 call raises when the native library or the device is missing.
 """
 from .engine import (Engine, BootstrapKey, KeySwitchKey, MosfhetHipError, lib, lib_path, to_device, to_numpy,  # noqa: F401
-                     PARAMS_SET1, PARAMS_LVL2)
+                     PARAMS_SET1, PARAMS_LVL2, PARAMS_SET2, PARAMS_SET3)
 from . import host  # noqa: F401

@@ -38,7 +38,7 @@ static int fail(int code, const char *fmt, ...) {
 
 struct mosfhet_hip_ctx {
   int device;
-  d2 *tw1024, *tw2048;  // device twiddle tables
+  d2 *tw1024, *tw2048, *tw4096;  // device twiddle tables
   uint64_t *scratch[3] = {nullptr, nullptr, nullptr};  // temporaries of compositions without a bootstrap key (tlwe_mul, tensor product)
   size_t scratch_words[3] = {0, 0, 0};
 };
@@ -125,10 +125,10 @@ extern "C" int mosfhet_hip_ctx_create(mosfhet_hip_ctx_t *out, int device) {
   HIP_TRY(hipSetDevice(device));
   mosfhet_hip_ctx *c = new mosfhet_hip_ctx();
   c->device = device;
-  for (int N : {1024, 2048}) {
+  for (int N : {1024, 2048, 4096}) {
     std::vector<double> tw;
     make_twiddles(N, tw);
-    d2 *&dst = (N == 1024) ? c->tw1024 : c->tw2048;
+    d2 *&dst = (N == 1024) ? c->tw1024 : (N == 2048 ? c->tw2048 : c->tw4096);
     HIP_TRY(hipMalloc((void **)&dst, tw.size() * sizeof(double)));
     HIP_TRY(hipMemcpy(dst, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice));
   }
@@ -142,6 +142,7 @@ extern "C" int mosfhet_hip_ctx_destroy(mosfhet_hip_ctx_t ctx) {
   hipDeviceSynchronize();
   hipFree(ctx->tw1024);
   hipFree(ctx->tw2048);
+  hipFree(ctx->tw4096);
   for (int i = 0; i < 3; i++)
     if (ctx->scratch[i]) hipFree(ctx->scratch[i]);
   delete ctx;
@@ -152,6 +153,15 @@ extern "C" int mosfhet_hip_ctx_destroy(mosfhet_hip_ctx_t ctx) {
 // its default stream -- never a private stream, so work stays ordered with the caller's copies.
 static hipStream_t pick(mosfhet_hip_ctx_t, void *stream) { return (hipStream_t)stream; }
 
+// Ring dispatch: BODY runs with `F` = the transform type of ring degree n_ (Fft1024 / Fft2048 / Fft4096) and `TW` = its twiddle table.
+static bool ring_ok(int N) { return N == 1024 || N == 2048 || N == 4096; }
+#define RING_DISPATCH(ctx_, n_, ...)                                                                   \
+  do {                                                                                                 \
+    if ((n_) == 1024) { using F = Fft1024; const d2 *TW = (ctx_)->tw1024; (void)TW; __VA_ARGS__; }     \
+    else if ((n_) == 2048) { using F = Fft2048; const d2 *TW = (ctx_)->tw2048; (void)TW; __VA_ARGS__; } \
+    else { using F = Fft4096; const d2 *TW = (ctx_)->tw4096; (void)TW; __VA_ARGS__; }                  \
+  } while (0)
+
 extern "C" int mosfhet_hip_ctx_sync(mosfhet_hip_ctx_t ctx, void *stream) {
   if (!ctx) return fail(MOSFHET_HIP_EINVAL, "ctx_sync: null ctx");
   HIP_TRY(hipSetDevice(ctx->device));
@@ -161,7 +171,7 @@ extern "C" int mosfhet_hip_ctx_sync(mosfhet_hip_ctx_t ctx, void *stream) {
 
 static int check_params(const char *who, int k, int N, int l, int Bg_bit) {
   if (k != 1) return fail(MOSFHET_HIP_EINVAL, "%s: only k = 1 is supported (got %d)", who, k);
-  if (N != 1024 && N != 2048) return fail(MOSFHET_HIP_EINVAL, "%s: ring degree N = %d not supported (1024, 2048)", who, N);
+  if (!ring_ok(N)) return fail(MOSFHET_HIP_EINVAL, "%s: ring degree N = %d not supported (1024, 2048, 4096)", who, N);
   if (l < 1 || Bg_bit < 1 || l * Bg_bit >= 64) return fail(MOSFHET_HIP_EINVAL, "%s: bad gadget l=%d Bg_bit=%d", who, l, Bg_bit);
   if (l != 1 && l != 2 && l != 3 && l != 4) return fail(MOSFHET_HIP_EINVAL, "%s: l = %d not instantiated (1..4)", who, l);
   return MOSFHET_HIP_OK;
@@ -179,8 +189,7 @@ extern "C" int mosfhet_hip_bsk_create_from_device(mosfhet_hip_ctx_t ctx, mosfhet
   const size_t polys = (size_t)n * (k + 1) * l * (k + 1);
   b->bytes = polys * N * sizeof(double);
   HIP_TRY(hipMalloc((void **)&b->d_bk, b->bytes));
-  if (N == 1024) hipLaunchKernelGGL(torus_to_dft_kernel<Fft1024>, dim3((unsigned)polys), dim3(64), 0, pick(ctx, stream), d_bk, b->d_bk, ctx->tw1024);
-  else hipLaunchKernelGGL(torus_to_dft_kernel<Fft2048>, dim3((unsigned)polys), dim3(128), 0, pick(ctx, stream), d_bk, b->d_bk, ctx->tw2048);
+  RING_DISPATCH(ctx, N, hipLaunchKernelGGL(torus_to_dft_kernel<F>, dim3((unsigned)polys), dim3(F::THREADS), 0, pick(ctx, stream), d_bk, b->d_bk, TW));
   HIP_TRY(hipGetLastError());
   *out = b;
   return MOSFHET_HIP_OK;
@@ -289,7 +298,7 @@ static int bootstrap_common(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hip_
   if (bsk->unfolding > 1) return bootstrap_unfolded(who, ctx, bsk, d_out, d_tv, tv_count, d_in, count, pre, torus_base, extract, skip_init, stream, rows);
   PbsParams p;
   p.bk = bsk->d_bk;
-  p.tw = bsk->N == 1024 ? ctx->tw1024 : ctx->tw2048;
+  p.tw = bsk->N == 1024 ? ctx->tw1024 : (bsk->N == 2048 ? ctx->tw2048 : ctx->tw4096);
   p.in = d_in;
   p.tv = d_tv;
   p.out = d_out;
@@ -319,8 +328,9 @@ static int bootstrap_common(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hip_
     HIP_TRY(hipGetLastError());
     return MOSFHET_HIP_OK;
   }
-  return bsk->N == 1024 ? launch_pbs_f<Fft1024>(bsk->l, bsk->Bg_bit, p, count, pick(ctx, stream))
-                        : launch_pbs_f<Fft2048>(bsk->l, bsk->Bg_bit, p, count, pick(ctx, stream));
+  int rc_pbs = MOSFHET_HIP_OK;
+  RING_DISPATCH(ctx, bsk->N, rc_pbs = launch_pbs_f<F>(bsk->l, bsk->Bg_bit, p, count, pick(ctx, stream)));
+  return rc_pbs;
 }
 
 extern "C" int mosfhet_hip_programmable_bootstrap_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_out,
@@ -357,21 +367,12 @@ extern "C" int mosfhet_hip_external_product_batch(mosfhet_hip_ctx_t ctx, mosfhet
   HIP_TRY(hipSetDevice(ctx->device));
   const d2 *row = bsk->d_bk + (size_t)key_index * (2 * bsk->l * 2 * (bsk->N / 2));
   hipStream_t s = pick(ctx, stream);
-#define EP_LAUNCH(F, T, TW, LL) hipLaunchKernelGGL((external_product_kernel<F, LL>), dim3(count), dim3(T), 0, s, row, TW, d_in, d_out, bsk->Bg_bit)
-  if (bsk->N == 1024) {
-    switch (bsk->l) {
-      case 1: EP_LAUNCH(Fft1024, 64, ctx->tw1024, 1); break;
-      case 2: EP_LAUNCH(Fft1024, 64, ctx->tw1024, 2); break;
-      case 3: EP_LAUNCH(Fft1024, 64, ctx->tw1024, 3); break;
-      default: EP_LAUNCH(Fft1024, 64, ctx->tw1024, 4); break;
-    }
-  } else {
-    switch (bsk->l) {
-      case 1: EP_LAUNCH(Fft2048, 128, ctx->tw2048, 1); break;
-      case 2: EP_LAUNCH(Fft2048, 128, ctx->tw2048, 2); break;
-      case 3: EP_LAUNCH(Fft2048, 128, ctx->tw2048, 3); break;
-      default: EP_LAUNCH(Fft2048, 128, ctx->tw2048, 4); break;
-    }
+#define EP_LAUNCH(LL) RING_DISPATCH(ctx, bsk->N, hipLaunchKernelGGL((external_product_kernel<F, LL>), dim3(count), dim3(F::THREADS), 0, s, row, TW, d_in, d_out, bsk->Bg_bit))
+  switch (bsk->l) {
+    case 1: EP_LAUNCH(1); break;
+    case 2: EP_LAUNCH(2); break;
+    case 3: EP_LAUNCH(3); break;
+    default: EP_LAUNCH(4); break;
   }
 #undef EP_LAUNCH
   HIP_TRY(hipGetLastError());
@@ -381,22 +382,20 @@ extern "C" int mosfhet_hip_external_product_batch(mosfhet_hip_ctx_t ctx, mosfhet
 // ---- polynomial-level entry points ----
 extern "C" int mosfhet_hip_torus_to_dft_batch(mosfhet_hip_ctx_t ctx, double *d_out, const uint64_t *d_in, int N, int count, void *stream) {
   if (!ctx || !d_out || !d_in || count < 0) return fail(MOSFHET_HIP_EINVAL, "torus_to_dft: bad argument");
-  if (N != 1024 && N != 2048) return fail(MOSFHET_HIP_EINVAL, "torus_to_dft: N = %d not supported (1024, 2048)", N);
+  if (!ring_ok(N)) return fail(MOSFHET_HIP_EINVAL, "torus_to_dft: N = %d not supported (1024, 2048, 4096)", N);
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
-  if (N == 1024) hipLaunchKernelGGL(torus_to_dft_kernel<Fft1024>, dim3(count), dim3(64), 0, pick(ctx, stream), d_in, (d2 *)d_out, ctx->tw1024);
-  else hipLaunchKernelGGL(torus_to_dft_kernel<Fft2048>, dim3(count), dim3(128), 0, pick(ctx, stream), d_in, (d2 *)d_out, ctx->tw2048);
+  RING_DISPATCH(ctx, N, hipLaunchKernelGGL(torus_to_dft_kernel<F>, dim3(count), dim3(F::THREADS), 0, pick(ctx, stream), d_in, (d2 *)d_out, TW));
   HIP_TRY(hipGetLastError());
   return MOSFHET_HIP_OK;
 }
 
 extern "C" int mosfhet_hip_dft_to_torus_batch(mosfhet_hip_ctx_t ctx, uint64_t *d_out, const double *d_in, int N, int count, void *stream) {
   if (!ctx || !d_out || !d_in || count < 0) return fail(MOSFHET_HIP_EINVAL, "dft_to_torus: bad argument");
-  if (N != 1024 && N != 2048) return fail(MOSFHET_HIP_EINVAL, "dft_to_torus: N = %d not supported (1024, 2048)", N);
+  if (!ring_ok(N)) return fail(MOSFHET_HIP_EINVAL, "dft_to_torus: N = %d not supported (1024, 2048, 4096)", N);
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
-  if (N == 1024) hipLaunchKernelGGL(dft_to_torus_kernel<Fft1024>, dim3(count), dim3(64), 0, pick(ctx, stream), (const d2 *)d_in, d_out, ctx->tw1024);
-  else hipLaunchKernelGGL(dft_to_torus_kernel<Fft2048>, dim3(count), dim3(128), 0, pick(ctx, stream), (const d2 *)d_in, d_out, ctx->tw2048);
+  RING_DISPATCH(ctx, N, hipLaunchKernelGGL(dft_to_torus_kernel<F>, dim3(count), dim3(F::THREADS), 0, pick(ctx, stream), (const d2 *)d_in, d_out, TW));
   HIP_TRY(hipGetLastError());
   return MOSFHET_HIP_OK;
 }
@@ -533,7 +532,7 @@ extern "C" int mosfhet_hip_multivalue_bootstrap_CLOT21_batch(mosfhet_hip_ctx_t c
 extern "C" int mosfhet_hip_trlwe_ksk_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_gak_t *out, const uint64_t *h_rows, int entries, int N, int t,
                                             int base_bit) {
   if (!ctx || !out || !h_rows || entries < 1) return fail(MOSFHET_HIP_EINVAL, "trlwe_ksk_create: bad argument");
-  if (N != 1024 && N != 2048) return fail(MOSFHET_HIP_EINVAL, "trlwe_ksk_create: N = %d not supported (1024, 2048)", N);
+  if (!ring_ok(N)) return fail(MOSFHET_HIP_EINVAL, "trlwe_ksk_create: N = %d not supported (1024, 2048, 4096)", N);
   if (t < 1 || base_bit < 1 || t * base_bit >= 64) return fail(MOSFHET_HIP_EINVAL, "trlwe_ksk_create: bad t = %d base_bit = %d", t, base_bit);
   HIP_TRY(hipSetDevice(ctx->device));
   mosfhet_hip_gak *g = new mosfhet_hip_gak();
@@ -544,8 +543,7 @@ extern "C" int mosfhet_hip_trlwe_ksk_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_g
   HIP_TRY(hipMalloc((void **)&d_tmp, g->bytes));
   HIP_TRY(hipMalloc((void **)&g->d_ak, g->bytes));
   HIP_TRY(hipMemcpy(d_tmp, h_rows, g->bytes, hipMemcpyHostToDevice));
-  if (N == 1024) hipLaunchKernelGGL(torus_to_dft_kernel<Fft1024>, dim3((unsigned)polys), dim3(64), 0, nullptr, d_tmp, g->d_ak, ctx->tw1024);
-  else hipLaunchKernelGGL(torus_to_dft_kernel<Fft2048>, dim3((unsigned)polys), dim3(128), 0, nullptr, d_tmp, g->d_ak, ctx->tw2048);
+  RING_DISPATCH(ctx, N, hipLaunchKernelGGL(torus_to_dft_kernel<F>, dim3((unsigned)polys), dim3(F::THREADS), 0, nullptr, d_tmp, g->d_ak, TW));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(nullptr));
   hipFree(d_tmp);
@@ -591,15 +589,16 @@ extern "C" int mosfhet_hip_trlwe_eval_automorphism_batch(mosfhet_hip_ctx_t ctx, 
   HIP_TRY(hipSetDevice(ctx->device));
   GaParams g;
   memset(&g, 0, sizeof(g));
-  g.p.tw = gak->N == 1024 ? ctx->tw1024 : ctx->tw2048;
+  g.p.tw = gak->N == 1024 ? ctx->tw1024 : (gak->N == 2048 ? ctx->tw2048 : ctx->tw4096);
   g.p.in = d_in;
   g.p.out = d_out;
   g.p.Bg_bit = gak->base_bit;
   g.ak = gak->d_ak;
   g.mode = 1;
   g.gen = gen;
-  return gak->N == 1024 ? launch_ga_f<Fft1024>(gak->t, gak->base_bit, g, count, pick(ctx, stream))
-                        : launch_ga_f<Fft2048>(gak->t, gak->base_bit, g, count, pick(ctx, stream));
+  int rc_ga = MOSFHET_HIP_OK;
+  RING_DISPATCH(ctx, gak->N, rc_ga = launch_ga_f<F>(gak->t, gak->base_bit, g, count, pick(ctx, stream)));
+  return rc_ga;
 }
 
 extern "C" int mosfhet_hip_functional_bootstrap_ga_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, mosfhet_hip_gak_t gak,
@@ -616,7 +615,7 @@ extern "C" int mosfhet_hip_functional_bootstrap_ga_batch(mosfhet_hip_ctx_t ctx, 
   GaParams g;
   memset(&g, 0, sizeof(g));
   g.p.bk = bsk->d_bk;
-  g.p.tw = bsk->N == 1024 ? ctx->tw1024 : ctx->tw2048;
+  g.p.tw = bsk->N == 1024 ? ctx->tw1024 : (bsk->N == 2048 ? ctx->tw2048 : ctx->tw4096);
   g.p.in = d_in;
   g.p.tv = d_tv;
   g.p.out = d_out;
@@ -627,19 +626,16 @@ extern "C" int mosfhet_hip_functional_bootstrap_ga_batch(mosfhet_hip_ctx_t ctx, 
   g.p.extract = extract ? 1 : 0;
   g.ak = gak->d_ak;
   g.mode = 0;
-  return bsk->N == 1024 ? launch_ga_f<Fft1024>(bsk->l, bsk->Bg_bit, g, count, pick(ctx, stream))
-                        : launch_ga_f<Fft2048>(bsk->l, bsk->Bg_bit, g, count, pick(ctx, stream));
+  int rc_ga = MOSFHET_HIP_OK;
+  RING_DISPATCH(ctx, bsk->N, rc_ga = launch_ga_f<F>(bsk->l, bsk->Bg_bit, g, count, pick(ctx, stream)));
+  return rc_ga;
 }
 
 // ---- FFT TRLWE key switches with run-time parameters, packing key switch, circuit bootstrap ----
 static int launch_fft_ks(mosfhet_hip_ctx_t ctx, mosfhet_hip_gak_t tks, const d2 *ks0, const d2 *ks1, uint64_t *d_out, size_t out_stride,
                          const uint64_t *d_in, size_t in_stride, int count, int mode, hipStream_t s) {
-  if (tks->N == 1024)
-    hipLaunchKernelGGL(trlwe_fft_keyswitch_kernel<Fft1024>, dim3(count), dim3(64), 0, s, ks0, ks1, ctx->tw1024, d_in, in_stride, d_out, out_stride,
-                       tks->t, tks->base_bit, mode);
-  else
-    hipLaunchKernelGGL(trlwe_fft_keyswitch_kernel<Fft2048>, dim3(count), dim3(128), 0, s, ks0, ks1, ctx->tw2048, d_in, in_stride, d_out, out_stride,
-                       tks->t, tks->base_bit, mode);
+  RING_DISPATCH(ctx, tks->N, hipLaunchKernelGGL(trlwe_fft_keyswitch_kernel<F>, dim3(count), dim3(F::THREADS), 0, s, ks0, ks1, TW, d_in, in_stride, d_out,
+                                                out_stride, tks->t, tks->base_bit, mode));
   HIP_TRY(hipGetLastError());
   return MOSFHET_HIP_OK;
 }

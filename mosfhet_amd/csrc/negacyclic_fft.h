@@ -352,6 +352,138 @@ struct Fft2048 {
   }
 };
 
+// ------------------------------------------------------------------------------------------------
+// N = 4096 (M = 2048; the reference's SET_3, test/tests.c:48): four wavefronts (256 threads) x 8 points.
+// Index j has 11 bits; passes of 3, 3, 3 and 2 radix-2 levels:
+//     pass A: register = j[10:8], thread = j[7:0]                         levels 0-2, twiddles in SGPRs
+//     pass B: register = j[7:5],  thread = (j[10:8], j[4:0])              levels 3-5
+//     pass C: register = j[4:2],  thread = (j[10:5], j[1:0])              levels 6-8
+//     pass D: register = j[2:0],  thread = j[10:3]                        levels 9-10 (the last two stages of a pass)
+// Slot maps (tools/lds_layout_search.py, conflict free for ds_write_b128 / ds_read_b128 in both directions, every access =
+// thread base + immediate):   A<->B: slot = j      B<->C: slot = j + 4 (j >> 5)      C<->D: slot = j + (j >> 3)     (2304 slots)
+// In layouts B, C, D the wavefront index is (j[10], j[9]) and both padded maps send each block of 512 indices to its own 576
+// slots, so B<->C and C<->D stay inside a wavefront (wave-level ordering); only A<->B crosses wavefronts.
+// Slot order of the DFT domain = layout D: device index m * 256 + thread.
+// ------------------------------------------------------------------------------------------------
+struct Fft4096 {
+  static constexpr int N = 4096, M = 2048, LOGM = 11, THREADS = 256, P = 8;
+  static constexpr int XCH_SLOTS = 2304;
+  static __device__ __forceinline__ void sync() { team_sync(); }
+  PassTw wa, wb, wc, wd;  // wd: only w1 (level 9, node 2t) and w2a / w2b (level 10, nodes 4t, 4t + 2) are used
+
+  __device__ __forceinline__ void init(const d2 *__restrict__ tw, int t) {
+    wa = load_pass_tw(tw, 0, 0);
+    wb = load_pass_tw(tw, 3, t >> 5);
+    wc = load_pass_tw(tw, 6, t >> 2);
+    const d2 a = tw[(1 << 9) - 1 + 2 * t], b = tw[(1 << 10) - 1 + 4 * t], c = tw[(1 << 10) - 1 + 4 * t + 2];
+    wd.w0r = 0.0; wd.w0i = 0.0;
+    wd.w1r = a.x; wd.w1i = a.y; wd.w2ar = b.x; wd.w2ai = b.y; wd.w2br = c.x; wd.w2bi = c.y;
+  }
+
+  static __device__ __forceinline__ int base_a(int t) { return t; }                                  // + 256 m   (slot = j)
+  static __device__ __forceinline__ int base_b1(int t) { return 256 * (t >> 5) + (t & 31); }         // + 32 m    (slot = j)
+  static __device__ __forceinline__ int base_b2(int t) { return 288 * (t >> 5) + (t & 31); }         // + 36 m    (j + 4 (j>>5))
+  static __device__ __forceinline__ int base_c(int t) { return 36 * (t >> 2) + (t & 3); }            // + 4 m (j + 4 (j>>5));  + off_c3(m) (j + (j>>3))
+  static __device__ __forceinline__ int base_d3(int t) { return 9 * t; }                             // + m       (j + (j>>3))
+  static __device__ __forceinline__ constexpr int off_c3(int m) { return 4 * m + (m >> 1); }
+
+  // the last two stages of a three-level pass (register pairs (m, m+2), then (m, m+1))
+  __device__ __forceinline__ void pass_d_fwd(double (&re)[8], double (&im)[8]) const {
+    bf_fwd(re[0], im[0], re[2], im[2], wd.w1r, wd.w1i);
+    bf_fwd(re[1], im[1], re[3], im[3], wd.w1r, wd.w1i);
+    bf_fwd_i(re[4], im[4], re[6], im[6], wd.w1r, wd.w1i);
+    bf_fwd_i(re[5], im[5], re[7], im[7], wd.w1r, wd.w1i);
+    bf_fwd(re[0], im[0], re[1], im[1], wd.w2ar, wd.w2ai);
+    bf_fwd_i(re[2], im[2], re[3], im[3], wd.w2ar, wd.w2ai);
+    bf_fwd(re[4], im[4], re[5], im[5], wd.w2br, wd.w2bi);
+    bf_fwd_i(re[6], im[6], re[7], im[7], wd.w2br, wd.w2bi);
+  }
+  __device__ __forceinline__ void pass_d_inv(double (&re)[8], double (&im)[8]) const {
+    bf_inv(re[0], im[0], re[1], im[1], wd.w2ar, wd.w2ai);
+    bf_inv_i(re[2], im[2], re[3], im[3], wd.w2ar, wd.w2ai);
+    bf_inv(re[4], im[4], re[5], im[5], wd.w2br, wd.w2bi);
+    bf_inv_i(re[6], im[6], re[7], im[7], wd.w2br, wd.w2bi);
+    bf_inv(re[0], im[0], re[2], im[2], wd.w1r, wd.w1i);
+    bf_inv(re[1], im[1], re[3], im[3], wd.w1r, wd.w1i);
+    bf_inv_i(re[4], im[4], re[6], im[6], wd.w1r, wd.w1i);
+    bf_inv_i(re[5], im[5], re[7], im[7], wd.w1r, wd.w1i);
+  }
+
+  __device__ __forceinline__ void forward_head(double (&re)[8], double (&im)[8], d2 *xch, int t) const {
+    pass_fwd(re, im, wa);
+    {
+      d2 *w = xch + base_a(t), *r = xch + base_b1(t);
+#pragma unroll
+      for (int m = 0; m < 8; m++) w[256 * m] = d2{re[m], im[m]};
+      team_sync();
+#pragma unroll
+      for (int m = 0; m < 8; m++) { const d2 v = r[32 * m]; re[m] = v.x; im[m] = v.y; }
+    }
+    pass_fwd(re, im, wb);
+    team_sync();
+    {
+      d2 *w = xch + base_b2(t), *r = xch + base_c(t);
+#pragma unroll
+      for (int m = 0; m < 8; m++) w[36 * m] = d2{re[m], im[m]};
+      wave_lds_sync();
+#pragma unroll
+      for (int m = 0; m < 8; m++) { const d2 v = r[4 * m]; re[m] = v.x; im[m] = v.y; }
+    }
+    pass_fwd(re, im, wc);
+    wave_lds_sync();
+    {
+      d2 *w = xch + base_c(t), *r = xch + base_d3(t);
+#pragma unroll
+      for (int m = 0; m < 8; m++) w[off_c3(m)] = d2{re[m], im[m]};
+      wave_lds_sync();
+#pragma unroll
+      for (int m = 0; m < 8; m++) { const d2 v = r[m]; re[m] = v.x; im[m] = v.y; }
+    }
+  }
+  __device__ __forceinline__ void forward_tail(double (&re)[8], double (&im)[8]) const {
+    pass_d_fwd(re, im);
+    team_sync();
+  }
+  __device__ __forceinline__ void forward(double (&re)[8], double (&im)[8], d2 *xch, int t) const {
+    forward_head(re, im, xch, t);
+    forward_tail(re, im);
+  }
+  // inverse: input in layout D, output in layout A, UNSCALED
+  __device__ __forceinline__ void inverse(double (&re)[8], double (&im)[8], d2 *xch, int t) const {
+    pass_d_inv(re, im);
+    {
+      d2 *w = xch + base_d3(t), *r = xch + base_c(t);
+#pragma unroll
+      for (int m = 0; m < 8; m++) w[m] = d2{re[m], im[m]};
+      wave_lds_sync();
+#pragma unroll
+      for (int m = 0; m < 8; m++) { const d2 v = r[off_c3(m)]; re[m] = v.x; im[m] = v.y; }
+    }
+    pass_inv(re, im, wc);
+    wave_lds_sync();
+    {
+      d2 *w = xch + base_c(t), *r = xch + base_b2(t);
+#pragma unroll
+      for (int m = 0; m < 8; m++) w[4 * m] = d2{re[m], im[m]};
+      wave_lds_sync();
+#pragma unroll
+      for (int m = 0; m < 8; m++) { const d2 v = r[36 * m]; re[m] = v.x; im[m] = v.y; }
+    }
+    pass_inv(re, im, wb);
+    team_sync();
+    {
+      d2 *w = xch + base_b1(t), *r = xch + base_a(t);
+#pragma unroll
+      for (int m = 0; m < 8; m++) w[32 * m] = d2{re[m], im[m]};
+      team_sync();
+#pragma unroll
+      for (int m = 0; m < 8; m++) { const d2 v = r[256 * m]; re[m] = v.x; im[m] = v.y; }
+    }
+    pass_inv(re, im, wa);
+    team_sync();
+  }
+};
+
 // double -> Torus64, round to nearest, mod 2^64 (values reach ~2^84).  `scale` = 2^-64 / M.
 // Same result as oracle_fft.c:round_mod_2_64 for every input (semantics of the reference's AVX-512 path,
 // fft_processor_spqlios.c:155-165: vcvtpd2qq of the fractional part scaled by 2^64, which wraps 2^63 to -2^63):

@@ -16,6 +16,11 @@ PARAMS_SET1 = dict(n=585, N=1024, k=1, l=2, Bg_bit=8, t=5, base_bit=2,
                    lwe_sigma=9.141776004202573e-5, rlwe_sigma=2.989040792967434e-8)
 PARAMS_LVL2 = dict(n=632, N=2048, k=1, l=4, Bg_bit=9, t=8, base_bit=4,
                    lwe_sigma=2.0 ** -15, rlwe_sigma=2.0 ** -44)
+# the reference's SET_2 (its default, test/tests.c:43-45) and SET_3 (:47-49), eprint 2022/704 table 4
+PARAMS_SET2 = dict(n=744, N=2048, k=1, l=1, Bg_bit=23, t=5, base_bit=3,
+                   lwe_sigma=7.747831515176779e-6, rlwe_sigma=2.2148688116005568e-16)
+PARAMS_SET3 = dict(n=807, N=4096, k=1, l=1, Bg_bit=22, t=5, base_bit=3,
+                   lwe_sigma=1.0562341599676662e-6, rlwe_sigma=2.168404344971009e-19)
 
 
 class MosfhetHipError(RuntimeError):
@@ -506,7 +511,7 @@ def twiddles(N):
 
 def slot_order_to_oracle(dft, N):
     """Engine slot order (index m*T + thread, T = N/16 threads of 8 registers) -> oracle order (index thread*8 + m)."""
-    assert N in (1024, 2048)
+    assert N in (1024, 2048, 4096)
     M, T = N // 2, N // 16
     j = np.arange(M)
     dev = (j & 7) * T + (j >> 3)

@@ -1,4 +1,4 @@
-"""Quick GPU perf + correctness probe of the PBS kernel (run through gpurun): tools/gpu_perf.py [B] [set1|lvl2]"""
+"""Quick GPU perf + correctness probe of the PBS kernel (run through gpurun): tools/gpu_perf.py [B] [set1|lvl2|set2|set3]"""
 import sys, time, numpy as np
 sys.path.insert(0, '.')
 import torch
@@ -6,7 +6,7 @@ import mosfhet_amd as ma
 from mosfhet_amd import host
 from oracle import oracle as O
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-P = dict(ma.PARAMS_LVL2 if (len(sys.argv) > 2 and sys.argv[2] == "lvl2") else ma.PARAMS_SET1)
+P = dict({"set1": ma.PARAMS_SET1, "lvl2": ma.PARAMS_LVL2, "set2": ma.PARAMS_SET2, "set3": ma.PARAMS_SET3}[sys.argv[2] if len(sys.argv) > 2 else "set1"])
 host.seed(0x4D4F5346)
 lk = host.LweKey(P['n'], P['lwe_sigma']); rk = host.RlweKey(P['N'], 1, P['rlwe_sigma'])
 bk = host.gen_bootstrap_key(rk, lk, P['l'], P['Bg_bit'])
