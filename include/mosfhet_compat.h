@@ -75,6 +75,15 @@ void tlwe_sample(TLWE out, Torus m, TLWE_Key key);                /* :106-115 */
 TLWE tlwe_new_sample(Torus m, TLWE_Key key);                      /* :122-133 */
 Torus tlwe_phase(TLWE c, TLWE_Key key);                           /* :135-141 */
 void tlwe_copy(TLWE out, TLWE in);                                /* :117-120 */
+TLWE tlwe_new_noiseless_trivial_sample(Torus m, int n);           /* :26-30 */
+void tlwe_add(TLWE out, TLWE in1, TLWE in2);                      /* :143-149  (host; the glue between bootstraps in callers) */
+void tlwe_addto(TLWE out, TLWE in);                               /* :171-173 */
+void tlwe_sub(TLWE out, TLWE in1, TLWE in2);                      /* :175-180 */
+void tlwe_subto(TLWE out, TLWE in);
+void tlwe_negate(TLWE out, TLWE in);                              /* :182-187 */
+void tlwe_scale(TLWE out, TLWE in1, Torus in2);                   /* :151-156 */
+void tlwe_scale_addto(TLWE out, TLWE in1, Torus in2);
+void tlwe_scale_subto(TLWE out, TLWE in1, Torus in2);             /* :163-169 */
 TLWE_KS_Key tlwe_new_KS_key(TLWE_Key out_key, TLWE_Key in_key, int t, int base_bit);   /* :193-212 */
 void free_tlwe_ks_key(TLWE_KS_Key key);                           /* :232-245 */
 void tlwe_keyswitch(TLWE out, TLWE in, TLWE_KS_Key ks_key);       /* :289-303  -> GPU */
@@ -90,8 +99,21 @@ TRLWE trlwe_new_noiseless_trivial_sample(TorusPolynomial m, int k, int N);
 void trlwe_sample(TRLWE out, TorusPolynomial m, TRLWE_Key key);   /* :296-316 */
 void trlwe_phase(TorusPolynomial out, TRLWE in, TRLWE_Key key);   /* :324-331 (exact product here) */
 void trlwe_torus_packing(TRLWE out, Torus *in, int size);         /* :662-667 */
+void trlwe_add(TRLWE out, TRLWE in1, TRLWE in2);                  /* :394-411  (host) */
+void trlwe_addto(TRLWE out, TRLWE in);                            /* :437-439 */
+void trlwe_sub(TRLWE out, TRLWE in1, TRLWE in2);
+void trlwe_subto(TRLWE out, TRLWE in);
+void trlwe_negate(TRLWE out, TRLWE in);
+void trlwe_copy(TRLWE out, TRLWE in);
+void trlwe_mul_by_xai(TRLWE out, TRLWE in, int a);                /* :441-447 with polynomial.c:184-199; out != in */
 void trlwe_extract_tlwe_key(TLWE_Key out, TRLWE_Key in);          /* :531-538 */
 void trlwe_extract_tlwe(TLWE out, TRLWE in, int idx);             /* :540-552 (host) */
+void trlwe_extract_tlwe_addto(TLWE out, TRLWE in, int idx);       /* :554-565 (host) */
+void trlwe_extract_tlwe_subto(TLWE out, TRLWE in, int idx);       /* :567-578 (host) */
+void trlwe_mv_extract_tlwe(TLWE *out, TRLWE in, int amount);      /* :580-589 (host; batches: mosfhet_hip_trlwe_mv_extract_batch) */
+void trlwe_mv_extract_tlwe_scaling(TLWE out, TRLWE in, int scale);        /* :591-601 */
+void trlwe_mv_extract_tlwe_scaling_addto(TLWE out, TRLWE in, int scale);  /* :603-611 */
+void trlwe_mv_extract_tlwe_scaling_subto(TLWE out, TRLWE in, int scale);  /* :613-622 */
 
 /* ---- TRGSW (src/trgsw.c) ---- */
 TRGSW_Key trgsw_new_key(TRLWE_Key trlwe_key, int l, int Bg_bit);  /* :20-27 */

@@ -222,6 +222,37 @@ void tlwe_copy(TLWE out, TLWE in) {
   out->b = in->b;
 }
 
+TLWE tlwe_new_noiseless_trivial_sample(Torus m, int n) {
+  TLWE c = tlwe_alloc_sample(n);
+  tlwe_noiseless_trivial_sample(c, m);
+  return c;
+}
+#define TLWE_BINOP(name, expr_a, expr_b)                                  \
+  void name(TLWE out, TLWE in1, TLWE in2) {                               \
+    for (int i = 0; i < in1->n; i++) out->a[i] = expr_a;                  \
+    out->b = expr_b;                                                      \
+  }
+TLWE_BINOP(tlwe_add, in1->a[i] + in2->a[i], in1->b + in2->b)
+TLWE_BINOP(tlwe_sub, in1->a[i] - in2->a[i], in1->b - in2->b)
+void tlwe_addto(TLWE out, TLWE in) { tlwe_add(out, out, in); }
+void tlwe_subto(TLWE out, TLWE in) { tlwe_sub(out, out, in); }
+void tlwe_negate(TLWE out, TLWE in) {
+  for (int i = 0; i < in->n; i++) out->a[i] = (Torus)0 - in->a[i];
+  out->b = (Torus)0 - in->b;
+}
+void tlwe_scale(TLWE out, TLWE in1, Torus in2) {
+  for (int i = 0; i < in1->n; i++) out->a[i] = in1->a[i] * in2;
+  out->b = in1->b * in2;
+}
+void tlwe_scale_addto(TLWE out, TLWE in1, Torus in2) {
+  for (int i = 0; i < in1->n; i++) out->a[i] += in1->a[i] * in2;
+  out->b += in1->b * in2;
+}
+void tlwe_scale_subto(TLWE out, TLWE in1, Torus in2) {
+  for (int i = 0; i < in1->n; i++) out->a[i] -= in1->a[i] * in2;
+  out->b -= in1->b * in2;
+}
+
 /* ------------------------------------------------------------------ TRLWE */
 TRLWE_Key trlwe_alloc_key(int N, int k, double sigma) {
   TRLWE_Key key = (TRLWE_Key)xmalloc(sizeof(*key));
@@ -295,6 +326,44 @@ void trlwe_phase(TorusPolynomial out, TRLWE in, TRLWE_Key key) {
   for (int j = 0; j < N; j++) out->coeffs[j] = in->b->coeffs[j] - out->coeffs[j];
 }
 
+static void poly_op(TorusPolynomial out, TorusPolynomial a, TorusPolynomial b, int sign) {
+  for (int j = 0; j < out->N; j++) out->coeffs[j] = sign > 0 ? a->coeffs[j] + b->coeffs[j] : a->coeffs[j] - b->coeffs[j];
+}
+void trlwe_add(TRLWE out, TRLWE in1, TRLWE in2) {
+  for (int p = 0; p < out->k; p++) poly_op(out->a[p], in1->a[p], in2->a[p], +1);
+  poly_op(out->b, in1->b, in2->b, +1);
+}
+void trlwe_sub(TRLWE out, TRLWE in1, TRLWE in2) {
+  for (int p = 0; p < out->k; p++) poly_op(out->a[p], in1->a[p], in2->a[p], -1);
+  poly_op(out->b, in1->b, in2->b, -1);
+}
+void trlwe_addto(TRLWE out, TRLWE in) { trlwe_add(out, out, in); }
+void trlwe_subto(TRLWE out, TRLWE in) { trlwe_sub(out, out, in); }
+void trlwe_negate(TRLWE out, TRLWE in) {
+  for (int p = 0; p <= out->k; p++) {
+    TorusPolynomial o = p < out->k ? out->a[p] : out->b, i = p < in->k ? in->a[p] : in->b;
+    for (int j = 0; j < o->N; j++) o->coeffs[j] = (Torus)0 - i->coeffs[j];
+  }
+}
+void trlwe_copy(TRLWE out, TRLWE in) {
+  for (int p = 0; p < out->k; p++) memcpy(out->a[p]->coeffs, in->a[p]->coeffs, sizeof(Torus) * (size_t)in->b->N);
+  memcpy(out->b->coeffs, in->b->coeffs, sizeof(Torus) * (size_t)in->b->N);
+}
+/* out = in * X^a, a in [0, 2N)  (src/polynomial.c:184-199) */
+void trlwe_mul_by_xai(TRLWE out, TRLWE in, int a) {
+  const int N = in->b->N;
+  a &= 2 * N - 1;
+  for (int p = 0; p <= out->k; p++) {
+    const Torus *src = (p < in->k ? in->a[p] : in->b)->coeffs;
+    Torus *dst = (p < out->k ? out->a[p] : out->b)->coeffs;
+    for (int j = 0; j < N; j++) {
+      int s = j - a, neg = 0;
+      while (s < 0) { s += N; neg ^= 1; }
+      dst[j] = neg ? (Torus)0 - src[s] : src[s];
+    }
+  }
+}
+
 void trlwe_torus_packing(TRLWE out, Torus *in, int size) {
   const int N = out->b->N;
   trlwe_noiseless_trivial_sample(out, NULL);
@@ -314,6 +383,43 @@ void trlwe_extract_tlwe(TLWE out, TRLWE in, int idx) {
     for (int j = idx + 1; j < N; j++) out->a[p * N + j] = (Torus)0 - ap[N + idx - j];
   }
   out->b = in->b->coeffs[idx];
+}
+
+static void extract_acc(TLWE out, TRLWE in, int idx, int sign) {
+  const int N = in->b->N;
+  for (int p = 0; p < in->k; p++) {
+    const Torus *c = in->a[p]->coeffs;
+    Torus *o = out->a + (size_t)p * N;
+    for (int j = 0; j <= idx; j++) o[j] += sign > 0 ? c[idx - j] : (Torus)0 - c[idx - j];
+    for (int j = idx + 1; j < N; j++) o[j] += sign > 0 ? (Torus)0 - c[N + idx - j] : c[N + idx - j];
+  }
+  out->b += sign > 0 ? in->b->coeffs[idx] : (Torus)0 - in->b->coeffs[idx];
+}
+void trlwe_extract_tlwe_addto(TLWE out, TRLWE in, int idx) { extract_acc(out, in, idx, +1); }
+void trlwe_extract_tlwe_subto(TLWE out, TRLWE in, int idx) { extract_acc(out, in, idx, -1); }
+void trlwe_mv_extract_tlwe(TLWE *out, TRLWE in, int amount) {
+  const int N = in->b->N;
+  for (int i = 0; i < amount / 2; i++) trlwe_extract_tlwe(out[i], in, i);
+  for (int i = amount / 2; i < amount; i++) {
+    trlwe_extract_tlwe(out[i], in, N - 1 - (i - amount / 2));
+    tlwe_negate(out[i], out[i]);
+  }
+}
+void trlwe_mv_extract_tlwe_scaling(TLWE out, TRLWE in, int scale) {
+  const int N = in->b->N, amount = scale;
+  trlwe_extract_tlwe(out, in, amount / 2);
+  for (int i = amount / 2 + 1; i < amount; i++) extract_acc(out, in, N - 1 - (i - amount / 2), -1);
+  for (int i = 0; i < amount / 2; i++) extract_acc(out, in, i, +1);
+}
+void trlwe_mv_extract_tlwe_scaling_addto(TLWE out, TRLWE in, int scale) {
+  const int N = in->b->N, amount = scale;
+  for (int i = amount / 2; i < amount; i++) extract_acc(out, in, N - 1 - (i - amount / 2), -1);
+  for (int i = 0; i < amount / 2; i++) extract_acc(out, in, i, +1);
+}
+void trlwe_mv_extract_tlwe_scaling_subto(TLWE out, TRLWE in, int scale) {
+  const int N = in->b->N, amount = scale;
+  for (int i = amount / 2; i < amount; i++) extract_acc(out, in, N - 1 - (i - amount / 2), +1);
+  for (int i = 0; i < amount / 2; i++) extract_acc(out, in, i, -1);
 }
 
 /* ------------------------------------------------------------------ TRGSW */

@@ -332,6 +332,44 @@ static void case_circuit_2_mux_trgsw(void) {
   free_trgsw(sel[0]); free_trgsw(sel[1]); free_tlwe(in[0]); free_tlwe(in[1]); free_tlwe(lw); free_trlwe(c2); free_polynomial(ph);
 }
 
+/* The radix-integer addition of the reference's application layer (applications/multi-ciphertext-arith/src/integer.c:78-107,
+ * ufhe_sl_add_integer): digits v / (2 torus_base) under the extracted key; per digit: add, key switch N -> n, bootstrap with the
+ * constant ADDSUB test vector (ufhe.c:57-60), reduce the digit with trlwe_mv_extract_tlwe_scaling_subto and propagate the carry with
+ * _scaling_addto -- exactly the call sequence of the reference, through the compat API. */
+static void case_radix_integer_add(void) {
+  wide_setup();
+  enum { tb = 4, digits = 3 };
+  TLWE_KS_Key ksk = tlwe_new_KS_key(lwe_key, wkey_extracted, 8, 2);
+  TRLWE addsub = trlwe_alloc_new_sample(k, N), tmp2 = trlwe_alloc_new_sample(k, N);
+  Torus c = double2torus(-1. / (4 * tb));
+  trlwe_torus_packing(addsub, &c, 1);
+  TLWE tmp = tlwe_alloc_sample(n);
+  const int av[digits] = {3, 2, 0}, bv[digits] = {2, 1, 0};        /* 0b1011 + 0b0110 = 0b10001 */
+  const int want[digits] = {1, 0, 1};
+  TLWE a[digits], b[digits], cd[digits];
+  for (int i = 0; i < digits; i++) {
+    a[i] = tlwe_new_sample(double2torus((double)av[i] / (2 * tb)), wkey_extracted);
+    b[i] = tlwe_new_sample(double2torus((double)bv[i] / (2 * tb)), wkey_extracted);
+    cd[i] = tlwe_new_noiseless_trivial_sample(0, N);
+  }
+  for (int i = 0; i < digits; i++) {
+    tlwe_addto(cd[i], a[i]);
+    tlwe_addto(cd[i], b[i]);
+    tlwe_keyswitch(tmp, cd[i], ksk);
+    functional_bootstrap_wo_extract(tmp2, addsub, tmp, wbk, tb);
+    trlwe_mv_extract_tlwe_scaling_subto(cd[i], tmp2, tb);
+    cd[i]->b -= double2torus(1. / 4);
+    if (i != digits - 1) {
+      tlwe_noiseless_trivial_sample(cd[i + 1], double2torus(1. / (tb * 4)));
+      trlwe_mv_extract_tlwe_scaling_addto(cd[i + 1], tmp2, 1);
+    }
+  }
+  for (int i = 0; i < digits; i++)
+    WITHIN(1ULL << 58, double2torus((double)want[i] / (2 * tb)), tlwe_phase(cd[i], wkey_extracted), "radix-integer addition digit");
+  for (int i = 0; i < digits; i++) { free_tlwe(a[i]); free_tlwe(b[i]); free_tlwe(cd[i]); }
+  free_tlwe(tmp); free_trlwe(addsub); free_trlwe(tmp2); free_tlwe_ks_key(ksk);
+}
+
 int main(int argc, char **argv) {
   setvbuf(stdout, NULL, _IOLBF, 0);
   mosfhet_seed(0x4D4F5346);
@@ -347,7 +385,7 @@ int main(int argc, char **argv) {
     {"multivalue", case_multivalue},                     {"bootstrap_ga", case_bootstrap_ga},
     {"circuit_bootstrap", case_circuit_bootstrap},       {"unfolded", case_unfolded},
     {"fdfb_variants", case_fdfb_variants},               {"multivalue_phases", case_multivalue_phases},
-    {"circuit_2+mux+trgsw", case_circuit_2_mux_trgsw},
+    {"circuit_2+mux+trgsw", case_circuit_2_mux_trgsw},   {"radix_integer_add", case_radix_integer_add},
   };
   for (unsigned i = 0; i < sizeof(cases) / sizeof(cases[0]); i++) {
     if (argc > 1 && strcmp(argv[1], cases[i].name)) continue;
