@@ -270,6 +270,12 @@ int mosfhet_hip_keyswitch_functional_bootstrap_batch(mosfhet_hip_ctx_t ctx, mosf
                                                      const uint64_t *d_tv, int tv_count, const uint64_t *d_in /*[count][kN+1]*/, int count,
                                                      int torus_base, int extract, void *stream);
 
+/* CMUX over a batch with one shared selector = entry `key_index` of a key handle (e.g. circuit-bootstrap outputs turned into a handle by
+ * mosfhet_hip_bsk_create_from_device): d_out[b] = d_in0[b] + key (.) (d_in1[b] - d_in0[b]); d_out may alias d_in0.  The leveled caller of
+ * the path (applications/leveled_lut/vertical_packing.c:24-52: CMUX tree, then blind_rotate with the selectors as key). */
+int mosfhet_hip_cmux_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, int key_index, uint64_t *d_out /*[count][2][N]*/, const uint64_t *d_in0,
+                           const uint64_t *d_in1, int count, void *stream);
+
 /* Timing hook for bench.py: runs `reps` launches of the programmable-bootstrap kernel on `stream`
  * bracketed by hipEvents ON THAT STREAM and returns the average kernel time in milliseconds
  * (synchronises the stream). */

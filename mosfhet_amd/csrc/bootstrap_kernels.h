@@ -811,13 +811,16 @@ __global__ __launch_bounds__(F::THREADS) void dft_to_torus_kernel(const d2 *__re
 template <class F, int L>
 __global__ __launch_bounds__(F::THREADS) void external_product_kernel(const d2 *__restrict__ bkrow, const d2 *__restrict__ tw,
                                                                     const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
-                                                                    int Bg_bit, size_t key_stride = 0, size_t in_stride = 2 * F::N) {
+                                                                    int Bg_bit, size_t key_stride = 0, size_t in_stride = 2 * F::N,
+                                                                    const uint64_t *__restrict__ in0 = nullptr) {
   // key_stride (in d2): 0 = one TRGSW for the whole batch, else TRGSW b starts at bkrow + b * key_stride (per-ciphertext
-  // selectors, functional_bootstrap_trgsw_phase2); in_stride (words): 0 = one shared TRLWE input
+  // selectors, functional_bootstrap_trgsw_phase2); in_stride (words): 0 = one shared TRLWE input.
+  // in0 != nullptr: CMUX (applications/leveled_lut/vertical_packing.c:24-33): out[b] = in0[b] + TRGSW (.) (in[b] - in0[b])
   constexpr int N = F::N, M = F::M, T = F::THREADS;
   __shared__ __attribute__((aligned(16))) d2 xch[F::XCH_SLOTS];
   const int t = threadIdx.x;
   const uint64_t *ct = in + (size_t)blockIdx.x * in_stride;
+  const uint64_t *c0 = in0 ? in0 + (size_t)blockIdx.x * 2 * N : nullptr;
   bkrow += (size_t)blockIdx.x * key_stride;
   F fft;
   fft.init(tw, t);
@@ -834,8 +837,10 @@ __global__ __launch_bounds__(F::THREADS) void external_product_kernel(const d2 *
     typename Digits<L, 0>::word_t w_lo[8], w_hi[8];
     uint32_t ext[8];
 #pragma unroll
-    for (int m = 0; m < 8; m++)
-      Digits<L, 0>::pack(w_lo[m], w_hi[m], ext[m], ct[q * N + m * T + t] + off, ct[q * N + M + m * T + t] + off);
+    for (int m = 0; m < 8; m++) {
+      const uint64_t s_lo = c0 ? c0[q * N + m * T + t] : 0, s_hi = c0 ? c0[q * N + M + m * T + t] : 0;
+      Digits<L, 0>::pack(w_lo[m], w_hi[m], ext[m], ct[q * N + m * T + t] - s_lo + off, ct[q * N + M + m * T + t] - s_hi + off);
+    }
     cmux_rows<F, L, 0>(w_lo, w_hi, ext, q, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
   }
   const RoundCtx scale(0x1p-64 / (double)M);
@@ -844,9 +849,10 @@ __global__ __launch_bounds__(F::THREADS) void external_product_kernel(const d2 *
   for (int c = 0; c < 2; c++) {
     fft.inverse(o_re[c], o_im[c], xch, t);
 #pragma unroll
-    for (int m = 0; m < 8; m++) {
-      dst[c * N + m * T + t] = round_mod_2_64(o_re[c][m], scale);
-      dst[c * N + m * T + t + M] = round_mod_2_64(o_im[c][m], scale);
+    for (int m = 0; m < 8; m++) {   // (out may alias in0: each lane reads its words of in0 before it writes them)
+      const uint64_t s_lo = c0 ? c0[c * N + m * T + t] : 0, s_hi = c0 ? c0[c * N + m * T + t + M] : 0;
+      dst[c * N + m * T + t] = round_mod_2_64(o_re[c][m], scale) + s_lo;
+      dst[c * N + m * T + t + M] = round_mod_2_64(o_im[c][m], scale) + s_hi;
     }
   }
 }

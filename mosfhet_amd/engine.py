@@ -362,6 +362,14 @@ class Engine:
                                                                       torus_base, int(extract), self._stream()))
         return out
 
+    def cmux(self, bsk, key_index, in0, in1, out=None):
+        """out[b] = in0[b] + key[key_index] (.) (in1[b] - in0[b]); out may be in0."""
+        count = in0.shape[0]
+        if out is None:
+            out = self.empty(count, 2, bsk.N)
+        _check(lib().mosfhet_hip_cmux_batch(self.h, bsk.h, int(key_index), _ptr(out), _ptr(in0), _ptr(in1), count, self._stream()))
+        return out
+
     def trlwe_eval_automorphism(self, gak, ct, gen, out=None):
         count = ct.shape[0]
         if out is None:
