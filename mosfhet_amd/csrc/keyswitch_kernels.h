@@ -17,6 +17,7 @@
 //     and the result words are coalesced.
 // Table traffic per launch: (ciphertexts / (64 NW)) * table size, served from L2 / Infinity Cache.
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -198,7 +199,11 @@ inline hipError_t launch_tlwe_keyswitch(const uint64_t *ksk, uint64_t *out, size
   const size_t Bp = ((size_t)count + TILE - 1) / TILE * TILE;
   // split the mask words over blockIdx.z until the grid fills the chip (each workgroup walks its i-range serially)
   const int slices = (row + W - 1) / W, ct_blocks = (int)(Bp / TILE);
-  int split = (1536 + slices * ct_blocks - 1) / (slices * ct_blocks);
+  // ~4 x the resident capacity (6 workgroups per CU): the workgroups are not equally long (tile padding, split remainders) and the
+  // kernel is latency-bound (LDS ~42 %, VALU ~50 %, HBM ~34 % busy, profiles/r01d_ks_summary.txt), so a finer grid balances better:
+  // packing switch 7.4 -> 6.3 ms, lvl2 LWE switch 6.1 -> 5.1 ms per batch.  MOSFHET_KS_TARGET_WGS overrides (tuning).
+  static const int target_wgs = getenv("MOSFHET_KS_TARGET_WGS") ? atoi(getenv("MOSFHET_KS_TARGET_WGS")) : 6144;
+  int split = (target_wgs + slices * ct_blocks - 1) / (slices * ct_blocks);
   if (split > 16) split = 16;
   if (split > n_in / 8) split = n_in / 8;
   if (split < 1) split = 1;

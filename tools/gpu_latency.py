@@ -1,6 +1,6 @@
 """Latency of small bootstrap batches, throughput kernel vs latency (team) kernel: tools/gpu_latency.py [set1|lvl2]"""
 import sys, time, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import mosfhet_amd as ma
 from mosfhet_amd import host, engine

@@ -1,6 +1,6 @@
 """Quick GPU perf + correctness probe of the PBS kernel (run through gpurun): tools/gpu_perf.py [B] [set1|lvl2|set2|set3]"""
 import sys, time, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import mosfhet_amd as ma
 from mosfhet_amd import host

@@ -1,7 +1,7 @@
 """GPU perf probe of circuit_bootstrap_3 at config 4 (N=2048 l=4 Bg=2^9, packing key t=6 bb=4, private KS t=20 bb=2),
 random key material (timing only): tools/gpu_perf_cb.py [B]"""
 import sys, time, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import mosfhet_amd as ma
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024

@@ -1,6 +1,6 @@
 """GPU perf probe of functional_bootstrap_ga: tools/gpu_perf_ga.py [B]"""
 import sys, time, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import mosfhet_amd as ma
 from mosfhet_amd import host
