@@ -227,7 +227,12 @@ inline hipError_t launch_tlwe_keyswitch(const uint64_t *ksk, uint64_t *out, size
   hipLaunchKernelGGL(transpose_u64_kernel, dim3((in_words + 31) / 32, (count + 31) / 32), dim3(32, 8), 0, s, in, ws.inT, count, in_words,
                      in_stride, Bp, 1, (size_t)0);
   const int cands = (1 << base_bit) - 1;
-  int JB = KS_LDS_BYTES / ((cands + 1) * (W + 2) * 8);          // per LDS buffer
+  // LDS per buffer: with >= 7 candidates per digit one digit position per stage (4.3 KiB) keeps more workgroups resident and measured
+  // fastest (packing switch 6.3 -> 5.8 ms, lvl2 LWE switch 5.1 -> 4.7 ms); small digit sets (base_bit 2) prefer all of an input
+  // word's positions in one stage.  MOSFHET_KS_LDS_BYTES overrides (tuning).
+  static const int lds_env = getenv("MOSFHET_KS_LDS_BYTES") ? atoi(getenv("MOSFHET_KS_LDS_BYTES")) : 0;
+  const int lds_budget = lds_env ? lds_env : (cands >= 7 ? 4352 : KS_LDS_BYTES);
+  int JB = lds_budget / ((cands + 1) * (W + 2) * 8);          // per LDS buffer
   const int pf_cap = KS_PF_MAX * (TILE / W) / cands;             // rows a stage can prefetch through registers
   if (JB > pf_cap) JB = pf_cap;
   if (JB < 1) JB = 1;
