@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64 * NW) void tlwe_keyswitch_kernel(const uint64_t 
       buf_sel ^= 1;
 #pragma unroll
       for (int k = 0; k < PF; k++)
-        if (in_row && sv0 + k * SV_STEP < jb * cands) buf[slot[k]] = pf[k];
+        if (in_row && sv0 + k * SV_STEP < jb * cands) buf[slot[k]] = 0 - pf[k];   // rows are staged NEGATED: the inner op is a 64-bit add
       __syncthreads();  // stage data visible; the other buffer is free (its readers passed the previous barrier)
       // next stage: (i, j0 + JB) or (i + 1, 0)
       {
@@ -146,8 +146,8 @@ __global__ __launch_bounds__(64 * NW) void tlwe_keyswitch_kernel(const uint64_t 
 #pragma unroll
         for (int w = 0; w < W; w += 2) {
           const ul2 x = r[w / 2];
-          acc[w] -= x.x;
-          acc[w + 1] -= x.y;
+          acc[w] += x.x;       // one v_lshl_add_u64 instead of a borrow pair (out -= row of src/tlwe.c:297, src/keyswitch.c:472)
+          acc[w + 1] += x.y;
         }
       }
     }
