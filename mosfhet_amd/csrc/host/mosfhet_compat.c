@@ -499,6 +499,20 @@ static void *dev_alloc(size_t bytes) {
   return p;
 }
 
+/* Device staging buffer of the single-call wrappers: every wrapper is synchronous (it waits for its result before returning), so one
+ * growable buffer per host thread is reused instead of a hipMalloc / hipFree pair per call (those cost more than the copies). */
+static __thread void *g_stage = NULL;
+static __thread size_t g_stage_bytes = 0;
+static void *stage_alloc(size_t bytes) {
+  if (bytes > g_stage_bytes) {
+    if (g_stage) hipFree(g_stage);
+    g_stage_bytes = bytes < 65536 ? 65536 : bytes + bytes / 2;
+    g_stage = dev_alloc(g_stage_bytes);
+  }
+  return g_stage;
+}
+static void stage_free(void *p) { (void)p; }
+
 static void dev_copy(void *dst, const void *src, size_t bytes, int kind) {
   if (bytes && hipMemcpy(dst, src, bytes, kind)) {
     fprintf(stderr, "mosfhet_amd: hipMemcpy failed\n");
@@ -602,7 +616,7 @@ static void bootstrap_many(int mode, TLWE *out, TRLWE out_trlwe, TRLWE tv, TLWE 
   Torus *h = (Torus *)xmalloc(sizeof(Torus) * (in_w + tv_w + out_w));
   tlwe_array_to_flat(h, in, count, n);
   trlwe_to_flat(h + in_w, tv);
-  Torus *d = (Torus *)dev_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
+  Torus *d = (Torus *)stage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
   dev_copy(d, h, sizeof(Torus) * (in_w + tv_w), HIP_H2D);
   int rc;
   if (mode == MODE_PROGRAMMABLE)
@@ -615,7 +629,7 @@ static void bootstrap_many(int mode, TLWE *out, TRLWE out_trlwe, TRLWE tv, TLWE 
   dev_copy(h + in_w + tv_w, d + in_w + tv_w, sizeof(Torus) * out_w, HIP_D2H);
   if (mode == MODE_WO_EXTRACT) trlwe_from_flat(out_trlwe, h + in_w + tv_w);
   else tlwe_array_from_flat(out, h + in_w + tv_w, count, k * N);
-  hipFree(d);
+  stage_free(d);
   free(h);
 }
 
@@ -654,7 +668,7 @@ void full_domain_functional_bootstrap_batch(TLWE *out, TRLWE tv, TLWE *in, int c
   Torus *h = (Torus *)xmalloc(sizeof(Torus) * (in_w + tv_w + out_w));
   tlwe_array_to_flat(h, in, count, n);
   trlwe_to_flat(h + in_w, tv);
-  Torus *d = (Torus *)dev_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
+  Torus *d = (Torus *)stage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
   dev_copy(d, h, sizeof(Torus) * (in_w + tv_w), HIP_H2D);
   if (mosfhet_hip_full_domain_functional_bootstrap_batch(ctx, (mosfhet_hip_bsk_t)mosfhet_bootstrap_key_device(key),
                                                          (mosfhet_hip_ksk_t)ksk->device, d + in_w + tv_w, d + in_w, 1, d, count, precision, NULL) ||
@@ -662,7 +676,7 @@ void full_domain_functional_bootstrap_batch(TLWE *out, TRLWE tv, TLWE *in, int c
     die("full_domain_functional_bootstrap");
   dev_copy(h + in_w + tv_w, d + in_w + tv_w, sizeof(Torus) * out_w, HIP_D2H);
   tlwe_array_from_flat(out, h + in_w + tv_w, count, k * N);
-  hipFree(d);
+  stage_free(d);
   free(h);
 }
 
@@ -677,7 +691,7 @@ void multivalue_bootstrap_CLOT21(TLWE *out, TRLWE tv, TLWE in, Bootstrap_Key key
   Torus *h = (Torus *)xmalloc(sizeof(Torus) * (in_w + tv_w + out_w));
   tlwe_array_to_flat(h, &in, 1, n);
   trlwe_to_flat(h + in_w, tv);
-  Torus *d = (Torus *)dev_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
+  Torus *d = (Torus *)stage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
   dev_copy(d, h, sizeof(Torus) * (in_w + tv_w), HIP_H2D);
   if (mosfhet_hip_multivalue_bootstrap_CLOT21_batch(ctx, (mosfhet_hip_bsk_t)mosfhet_bootstrap_key_device(key), d + in_w + tv_w, d + in_w, 1, d,
                                                     1, torus_base, n_luts, NULL) ||
@@ -685,7 +699,7 @@ void multivalue_bootstrap_CLOT21(TLWE *out, TRLWE tv, TLWE in, Bootstrap_Key key
     die("multivalue_bootstrap_CLOT21");
   dev_copy(h + in_w + tv_w, d + in_w + tv_w, sizeof(Torus) * out_w, HIP_D2H);
   tlwe_array_from_flat(out, h + in_w + tv_w, n_luts, k * N);
-  hipFree(d);
+  stage_free(d);
   free(h);
 }
 
@@ -705,14 +719,14 @@ void blind_rotate(TRLWE tv, Torus *a, TRGSW_DFT *s, int size) {
   trlwe_to_flat(h, tv);
   memcpy(h + acc_w, a, sizeof(Torus) * (size_t)n);
   h[acc_w + n] = 0;
-  Torus *d = (Torus *)dev_alloc(sizeof(Torus) * (acc_w + n + 1));
+  Torus *d = (Torus *)stage_alloc(sizeof(Torus) * (acc_w + n + 1));
   dev_copy(d, h, sizeof(Torus) * (acc_w + n + 1), HIP_H2D);
   if (mosfhet_hip_blind_rotate_batch(ctx, (mosfhet_hip_bsk_t)mosfhet_bootstrap_key_device(key), d, d + acc_w, 1, NULL) ||
       mosfhet_hip_ctx_sync(ctx, NULL))
     die("blind_rotate");
   dev_copy(h, d, sizeof(Torus) * acc_w, HIP_D2H);
   trlwe_from_flat(tv, h);
-  hipFree(d);
+  stage_free(d);
   free(h);
 }
 
@@ -795,7 +809,7 @@ static void bootstrap_ga_many(TLWE *out, TRLWE out_trlwe, TRLWE tv, TLWE *in, in
   Torus *h = (Torus *)xmalloc(sizeof(Torus) * (in_w + tv_w + out_w));
   tlwe_array_to_flat(h, in, count, n);
   trlwe_to_flat(h + in_w, tv);
-  Torus *d = (Torus *)dev_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
+  Torus *d = (Torus *)stage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
   dev_copy(d, h, sizeof(Torus) * (in_w + tv_w), HIP_H2D);
   if (mosfhet_hip_functional_bootstrap_ga_batch(ctx, (mosfhet_hip_bsk_t)key->s[0], (mosfhet_hip_gak_t)key->ak[0], d + in_w + tv_w, d + in_w, 1, d,
                                                 count, torus_base, extract, NULL) ||
@@ -804,7 +818,7 @@ static void bootstrap_ga_many(TLWE *out, TRLWE out_trlwe, TRLWE tv, TLWE *in, in
   dev_copy(h + in_w + tv_w, d + in_w + tv_w, sizeof(Torus) * out_w, HIP_D2H);
   if (extract) tlwe_array_from_flat(out, h + in_w + tv_w, count, N);
   else trlwe_from_flat(out_trlwe, h + in_w + tv_w);
-  hipFree(d);
+  stage_free(d);
   free(h);
 }
 
@@ -885,13 +899,13 @@ void tlwe_keyswitch_batch(TLWE *out, TLWE *in, int count, TLWE_KS_Key ks) {
   const size_t in_w = (size_t)count * (n_in + 1), out_w = (size_t)count * (n_out + 1);
   Torus *h = (Torus *)xmalloc(sizeof(Torus) * (in_w + out_w));
   tlwe_array_to_flat(h, in, count, n_in);
-  Torus *d = (Torus *)dev_alloc(sizeof(Torus) * (in_w + out_w));
+  Torus *d = (Torus *)stage_alloc(sizeof(Torus) * (in_w + out_w));
   dev_copy(d, h, sizeof(Torus) * in_w, HIP_H2D);
   if (mosfhet_hip_tlwe_keyswitch_batch(ctx, (mosfhet_hip_ksk_t)ks->device, d + in_w, d, count, NULL) || mosfhet_hip_ctx_sync(ctx, NULL))
     die("tlwe_keyswitch");
   dev_copy(h + in_w, d + in_w, sizeof(Torus) * out_w, HIP_D2H);
   tlwe_array_from_flat(out, h + in_w, count, n_out);
-  hipFree(d);
+  stage_free(d);
   free(h);
 }
 
@@ -983,14 +997,14 @@ static void trlwe_ks_run(int mode, TRLWE out, TRLWE in, TRLWE_KS_Key key) {
   const size_t w = (size_t)2 * N;
   Torus *h = (Torus *)xmalloc(sizeof(Torus) * w);
   trlwe_to_flat(h, in);
-  Torus *d = (Torus *)dev_alloc(sizeof(Torus) * 2 * w);
+  Torus *d = (Torus *)stage_alloc(sizeof(Torus) * 2 * w);
   dev_copy(d, h, sizeof(Torus) * w, HIP_H2D);
   int rc = mode ? mosfhet_hip_trlwe_priv_keyswitch_2_batch(ctx, (mosfhet_hip_gak_t)key->device, d + w, d, 1, NULL)
                 : mosfhet_hip_trlwe_keyswitch_batch(ctx, (mosfhet_hip_gak_t)key->device, key->entry, d + w, d, 1, NULL);
   if (rc || mosfhet_hip_ctx_sync(ctx, NULL)) die(mode ? "trlwe_priv_keyswitch_2" : "trlwe_keyswitch");
   dev_copy(h, d + w, sizeof(Torus) * w, HIP_D2H);
   trlwe_from_flat(out, h);
-  hipFree(d);
+  stage_free(d);
   free(h);
 }
 
@@ -1028,13 +1042,13 @@ void trlwe_packing1_keyswitch(TRLWE out, TLWE in, Generic_KS_Key ks) {
   const size_t in_w = (size_t)n + 1, out_w = (size_t)2 * N;
   Torus *h = (Torus *)xmalloc(sizeof(Torus) * (in_w + out_w));
   tlwe_array_to_flat(h, &in, 1, n);
-  Torus *d = (Torus *)dev_alloc(sizeof(Torus) * (in_w + out_w));
+  Torus *d = (Torus *)stage_alloc(sizeof(Torus) * (in_w + out_w));
   dev_copy(d, h, sizeof(Torus) * in_w, HIP_H2D);
   if (mosfhet_hip_trlwe_packing1_keyswitch_batch(ctx, (mosfhet_hip_ksk_t)ks->device, d + in_w, d, 1, NULL) || mosfhet_hip_ctx_sync(ctx, NULL))
     die("trlwe_packing1_keyswitch");
   dev_copy(h + in_w, d + in_w, sizeof(Torus) * out_w, HIP_D2H);
   trlwe_from_flat(out, h + in_w);
-  hipFree(d);
+  stage_free(d);
   free(h);
 }
 
@@ -1044,7 +1058,7 @@ void circuit_bootstrap_3_batch(TRGSW *out, TLWE *in, int count, Bootstrap_Key ke
   const size_t in_w = (size_t)count * (n + 1), row = (size_t)2 * N, out_w = (size_t)count * 2 * l * row;
   Torus *h = (Torus *)xmalloc(sizeof(Torus) * (in_w + out_w));
   tlwe_array_to_flat(h, in, count, n);
-  Torus *d = (Torus *)dev_alloc(sizeof(Torus) * (in_w + out_w));
+  Torus *d = (Torus *)stage_alloc(sizeof(Torus) * (in_w + out_w));
   dev_copy(d, h, sizeof(Torus) * in_w, HIP_H2D);
   if (mosfhet_hip_circuit_bootstrap_3_batch(ctx, (mosfhet_hip_bsk_t)key->s[0], (mosfhet_hip_gak_t)kska[0]->device, (mosfhet_hip_ksk_t)kskb->device,
                                             d + in_w, d, count, NULL) ||
@@ -1053,7 +1067,7 @@ void circuit_bootstrap_3_batch(TRGSW *out, TLWE *in, int count, Bootstrap_Key ke
   dev_copy(h + in_w, d + in_w, sizeof(Torus) * out_w, HIP_D2H);
   for (int b = 0; b < count; b++)
     for (int q = 0; q < 2 * l; q++) trlwe_from_flat(out[b]->samples[q], h + in_w + ((size_t)b * 2 * l + q) * row);
-  hipFree(d);
+  stage_free(d);
   free(h);
 }
 
@@ -1067,12 +1081,12 @@ static Buf buf_new(size_t words) {
   Buf b;
   b.words = words;
   b.h = (Torus *)xmalloc(sizeof(Torus) * (words ? words : 1));
-  b.d = (Torus *)dev_alloc(sizeof(Torus) * (words ? words : 1));
+  b.d = (Torus *)stage_alloc(sizeof(Torus) * (words ? words : 1));
   return b;
 }
 static void buf_up(Buf *b, size_t off, size_t words) { dev_copy(b->d + off, b->h + off, sizeof(Torus) * words, HIP_H2D); }
 static void buf_down(Buf *b, size_t off, size_t words) { dev_copy(b->h + off, b->d + off, sizeof(Torus) * words, HIP_D2H); }
-static void buf_free(Buf *b) { hipFree(b->d); free(b->h); }
+static void buf_free(Buf *b) { stage_free(b->d); free(b->h); }
 static mosfhet_hip_ctx_t ectx(void) { return (mosfhet_hip_ctx_t)mosfhet_engine_ctx(); }
 static void check_rc(int rc, const char *what) { if (rc || mosfhet_hip_ctx_sync(ectx(), NULL)) die(what); }
 

@@ -1,0 +1,21 @@
+/* single-call latency through the compat API: gcc -O2 -Iinclude tools/compat_latency.c -Lmosfhet_amd -lmosfhet_hip -Wl,-rpath,$PWD/mosfhet_amd */
+#include <stdio.h>
+#include <time.h>
+#include "mosfhet_compat.h"
+static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
+int main(void) {
+  mosfhet_seed(1);
+  TLWE_Key lk = tlwe_new_binary_key(585, 9.1418e-5);
+  TRLWE_Key rk = trlwe_new_binary_key(1024, 1, 2.989e-8);
+  TRGSW_Key gk = trgsw_new_key(rk, 2, 8);
+  Bootstrap_Key bk = new_bootstrap_key(gk, lk, 1);
+  Torus lut[4] = {int2torus(1, 4), int2torus(5, 4), int2torus(9, 4), int2torus(13, 4)};
+  TRLWE tv = trlwe_alloc_new_sample(1, 1024);
+  trlwe_torus_packing(tv, lut, 4);
+  TLWE in = tlwe_new_sample(double2torus(1. / 8), lk), out = tlwe_alloc_sample(1024);
+  programmable_bootstrap(out, tv, in, bk, 3, 0, 0);
+  const double t0 = now();
+  for (int i = 0; i < 50; i++) programmable_bootstrap(out, tv, in, bk, 3, 0, 0);
+  printf("programmable_bootstrap(out, tv, in, bk, 3, 0, 0): %.3f ms per call (single sample, host structs in and out)\n", (now() - t0) / 50);
+  return 0;
+}
