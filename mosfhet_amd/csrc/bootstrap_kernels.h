@@ -44,6 +44,7 @@ struct PbsParams {
   uint64_t prec_offset;              // double2torus(1 / (4 torus_base))
   int extract;                       // 1: write TLWE (sample extract at 0); 0: write the rotated TRLWE
   int skip_init;                     // 1: blind_rotate only -- acc is loaded from `out` as is
+  int count = 0;                     // host-side launch hint only (capi.hip: launch_pbs), not read by the kernels
   int rows = 1;                      // > 1: TRGSW accumulator (blind_rotate_trgsw, src/bootstrap.c:267-282): groups of `rows` consecutive
                                      // blocks share input ciphertext b / rows and start from test vector b % rows of one shared set
 };

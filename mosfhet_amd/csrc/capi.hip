@@ -244,8 +244,37 @@ extern "C" int mosfhet_hip_bsk_export_dft(mosfhet_hip_bsk_t bsk, double *h_out) 
 }
 
 // ---- bootstrap launches ----
+// One launch per residency round when the key does not fit the L2s (N >= 2048).  All teams walk the key rows in the same order and
+// share each row through their XCD's L2 while they stay close together; in one big launch the teams of later rounds start as earlier
+// ones finish, the phases smear out and the sharing collapses (4096 bootstraps at lvl2 in one launch: L2 hit rate 52 %, 318 GB of
+// fabric reads; one round alone: 96 %, 7 GB).  Kernel boundaries re-align the teams: 79 -> 74 ms.  A round = CUs x resident teams
+// per CU (LDS-limited: 4 at N = 2048, 2 at N = 4096).  MOSFHET_HIP_ROUND_CHUNK overrides (0 = single launch).
+static int round_chunk(int threads) {
+  static int cus = 0, env = -2;
+  if (env == -2) { const char *e = getenv("MOSFHET_HIP_ROUND_CHUNK"); env = e ? atoi(e) : -1; }
+  if (env >= 0) return env;
+  if (!cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  }
+  return threads == 128 ? 4 * cus : 0;   // N = 4096 (2 teams per CU) measured slower in rounds (tail idling): single launch
+}
+
 template <class F, int L, int BG>
 static void launch_pbs(const PbsParams &p, int count, hipStream_t s) {
+  const int chunk = F::THREADS > 64 && p.rows == 1 && p.count < 0 ? round_chunk(F::THREADS) : 0;   // p.count < 0: key larger than the L2s
+  if (chunk > 0 && count > chunk) {
+    const size_t out_row = p.extract ? (size_t)F::N + 1 : (size_t)2 * F::N;
+    for (int lo = 0; lo < count; lo += chunk) {
+      PbsParams q = p;
+      q.in = p.in + (size_t)lo * (p.n + 1);
+      q.out = p.out + (size_t)lo * out_row;
+      q.tv = p.tv ? p.tv + (size_t)lo * p.tv_stride : p.tv;
+      const int c = count - lo < chunk ? count - lo : chunk;
+      hipLaunchKernelGGL((pbs_kernel<F, L, BG>), dim3((unsigned)c), dim3(F::THREADS), 0, s, q);
+    }
+    return;
+  }
   hipLaunchKernelGGL((pbs_kernel<F, L, BG>), dim3((unsigned)count), dim3(F::THREADS), 0, s, p);
 }
 
@@ -312,6 +341,7 @@ static int bootstrap_common(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hip_
   p.prec_offset = skip_init ? 0 : (uint64_t)((int64_t)(18446744073709551616.0 * (1. / (4 * (double)torus_base))));
   p.extract = extract;
   p.skip_init = skip_init;
+  p.count = bsk->bytes > ((size_t)96 << 20) ? -1 : 0;   // launch hint: split into residency rounds (launch_pbs)
   p.rows = rows;
   // small batches: the latency-oriented team kernel (one workgroup of 2l wavefronts per ciphertext), N = 1024
   if (bsk->N == 1024 && rows == 1 && count <= team_max_batch() && bsk->l <= 4) {
