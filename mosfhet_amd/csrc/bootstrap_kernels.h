@@ -283,12 +283,7 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
       cmux_digits<F, L, BG>(w_lo, w_hi, ext, al, ah, q ? acc1 : nullptr, xch, a_lo, flip, off, t);
       cmux_rows<F, L, BG>(w_lo, w_hi, ext, q, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
     }
-    if constexpr (F::THREADS == 64) {
-      fft.inverse2(o_re[0], o_im[0], o_re[1], o_im[1], xch, t);
-    } else {
-      fft.inverse(o_re[0], o_im[0], xch, t);
-      fft.inverse(o_re[1], o_im[1], xch, t);
-    }
+    fft.inverse2(o_re[0], o_im[0], o_re[1], o_im[1], xch, t);
 #pragma unroll
     for (int m = 0; m < 8; m++) {
       al[m] += round_mod_2_64(o_re[0][m], scale);
@@ -461,12 +456,7 @@ __device__ __forceinline__ void ga_external_product(uint64_t (&al)[8], uint64_t 
     }
     cmux_rows<F, L, BG>(w_lo, w_hi, ext, q, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
   }
-  if constexpr (F::THREADS == 64) {
-    fft.inverse2(o_re[0], o_im[0], o_re[1], o_im[1], xch, t);
-  } else {
-    fft.inverse(o_re[0], o_im[0], xch, t);
-    fft.inverse(o_re[1], o_im[1], xch, t);
-  }
+  fft.inverse2(o_re[0], o_im[0], o_re[1], o_im[1], xch, t);
 #pragma unroll
   for (int m = 0; m < 8; m++) {
     al[m] = round_mod_2_64(o_re[0][m], scale);
@@ -523,12 +513,7 @@ __device__ __forceinline__ void ga_eval_automorphism(uint64_t (&al)[8], uint64_t
 #pragma unroll
     for (int m = 0; m < 8; m++) { o_re[c][m] = 0.0; o_im[c][m] = 0.0; }
   cmux_rows<F, L, BG>(w_lo, w_hi, ext, 0, o_re, o_im, xch, fft, entry, Bg_bit, t);
-  if constexpr (F::THREADS == 64) {
-    fft.inverse2(o_re[0], o_im[0], o_re[1], o_im[1], xch, t);
-  } else {
-    fft.inverse(o_re[0], o_im[0], xch, t);
-    fft.inverse(o_re[1], o_im[1], xch, t);
-  }
+  fft.inverse2(o_re[0], o_im[0], o_re[1], o_im[1], xch, t);
 #pragma unroll
   for (int m = 0; m < 8; m++) {
     al[m] = 0 - round_mod_2_64(o_re[0][m], scale);

@@ -350,6 +350,57 @@ struct Fft2048 {
     pass_inv(re, im, wa);
     team_sync();
   }
+
+  // two inverse transforms pipelined through the one buffer (cf. Fft1024::inverse2): wave-local exchanges rely on in-order DS
+  // execution, the cross-wavefront B -> A exchange keeps its workgroup barriers (5 in all instead of 6) and every register pass
+  // runs while the other transform's exchange is in flight.
+  __device__ __forceinline__ void inverse2(double (&xr)[8], double (&xi)[8], double (&yr)[8], double (&yi)[8], d2 *xch, int t) const {
+    d2 *pd = xch + base_d3(t), *pc3 = xch + base_c3(t), *pc2 = xch + base_c2(t), *pb2 = xch + base_b2(t), *pb1 = xch + base_b1(t), *pa = xch + base_a(t);
+    pass_d_inv(xr, xi);
+#pragma unroll
+    for (int m = 0; m < 8; m++) pd[m] = d2{xr[m], xi[m]};
+    wave_lds_sync();
+    pass_d_inv(yr, yi);
+#pragma unroll
+    for (int m = 0; m < 8; m++) { const d2 v = pc3[off_c3(m)]; xr[m] = v.x; xi[m] = v.y; }
+    wave_lds_sync();
+#pragma unroll
+    for (int m = 0; m < 8; m++) pd[m] = d2{yr[m], yi[m]};
+    wave_lds_sync();
+    pass_inv(xr, xi, wc);
+#pragma unroll
+    for (int m = 0; m < 8; m++) { const d2 v = pc3[off_c3(m)]; yr[m] = v.x; yi[m] = v.y; }
+    wave_lds_sync();
+#pragma unroll
+    for (int m = 0; m < 8; m++) pc2[2 * m] = d2{xr[m], xi[m]};
+    wave_lds_sync();
+    pass_inv(yr, yi, wc);
+#pragma unroll
+    for (int m = 0; m < 8; m++) { const d2 v = pb2[18 * m]; xr[m] = v.x; xi[m] = v.y; }
+    wave_lds_sync();
+#pragma unroll
+    for (int m = 0; m < 8; m++) pc2[2 * m] = d2{yr[m], yi[m]};
+    wave_lds_sync();
+    pass_inv(xr, xi, wb);
+#pragma unroll
+    for (int m = 0; m < 8; m++) { const d2 v = pb2[18 * m]; yr[m] = v.x; yi[m] = v.y; }
+    team_sync();
+#pragma unroll
+    for (int m = 0; m < 8; m++) pb1[16 * m] = d2{xr[m], xi[m]};
+    team_sync();
+    pass_inv(yr, yi, wb);
+#pragma unroll
+    for (int m = 0; m < 8; m++) { const d2 v = pa[128 * m]; xr[m] = v.x; xi[m] = v.y; }
+    team_sync();
+#pragma unroll
+    for (int m = 0; m < 8; m++) pb1[16 * m] = d2{yr[m], yi[m]};
+    team_sync();
+    pass_inv(xr, xi, wa);
+#pragma unroll
+    for (int m = 0; m < 8; m++) { const d2 v = pa[128 * m]; yr[m] = v.x; yi[m] = v.y; }
+    pass_inv(yr, yi, wa);
+    team_sync();
+  }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -480,6 +531,54 @@ struct Fft4096 {
       for (int m = 0; m < 8; m++) { const d2 v = r[256 * m]; re[m] = v.x; im[m] = v.y; }
     }
     pass_inv(re, im, wa);
+    team_sync();
+  }
+
+  __device__ __forceinline__ void inverse2(double (&xr)[8], double (&xi)[8], double (&yr)[8], double (&yi)[8], d2 *xch, int t) const {
+    d2 *pd = xch + base_d3(t), *pc = xch + base_c(t), *pb2 = xch + base_b2(t), *pb1 = xch + base_b1(t), *pa = xch + base_a(t);
+    pass_d_inv(xr, xi);
+#pragma unroll
+    for (int m = 0; m < 8; m++) pd[m] = d2{xr[m], xi[m]};
+    wave_lds_sync();
+    pass_d_inv(yr, yi);
+#pragma unroll
+    for (int m = 0; m < 8; m++) { const d2 v = pc[off_c3(m)]; xr[m] = v.x; xi[m] = v.y; }
+    wave_lds_sync();
+#pragma unroll
+    for (int m = 0; m < 8; m++) pd[m] = d2{yr[m], yi[m]};
+    wave_lds_sync();
+    pass_inv(xr, xi, wc);
+#pragma unroll
+    for (int m = 0; m < 8; m++) { const d2 v = pc[off_c3(m)]; yr[m] = v.x; yi[m] = v.y; }
+    wave_lds_sync();
+#pragma unroll
+    for (int m = 0; m < 8; m++) pc[4 * m] = d2{xr[m], xi[m]};
+    wave_lds_sync();
+    pass_inv(yr, yi, wc);
+#pragma unroll
+    for (int m = 0; m < 8; m++) { const d2 v = pb2[36 * m]; xr[m] = v.x; xi[m] = v.y; }
+    wave_lds_sync();
+#pragma unroll
+    for (int m = 0; m < 8; m++) pc[4 * m] = d2{yr[m], yi[m]};
+    wave_lds_sync();
+    pass_inv(xr, xi, wb);
+#pragma unroll
+    for (int m = 0; m < 8; m++) { const d2 v = pb2[36 * m]; yr[m] = v.x; yi[m] = v.y; }
+    team_sync();
+#pragma unroll
+    for (int m = 0; m < 8; m++) pb1[32 * m] = d2{xr[m], xi[m]};
+    team_sync();
+    pass_inv(yr, yi, wb);
+#pragma unroll
+    for (int m = 0; m < 8; m++) { const d2 v = pa[256 * m]; xr[m] = v.x; xi[m] = v.y; }
+    team_sync();
+#pragma unroll
+    for (int m = 0; m < 8; m++) pb1[32 * m] = d2{yr[m], yi[m]};
+    team_sync();
+    pass_inv(xr, xi, wa);
+#pragma unroll
+    for (int m = 0; m < 8; m++) { const d2 v = pa[256 * m]; yr[m] = v.x; yi[m] = v.y; }
+    pass_inv(yr, yi, wa);
     team_sync();
   }
 };
