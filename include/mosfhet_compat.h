@@ -194,6 +194,33 @@ void functional_bootstrap_trgsw_phase2(TLWE out, TRGSW_DFT in, TRLWE tv);       
 void mosfhet_gen_priv_sk_ks_key_flat(Torus *out /*[n+1][t][2^bb-1][2][N]*/, TRLWE_Key out_key, TLWE_Key in_key, int t, int base_bit);
 void mosfhet_gen_bootstrap_key_unfolded_flat(Torus *out /*[n 2^u/u][2l][2][N]*/, TRGSW_Key out_key, TLWE_Key in_key, int unfolding);
 
+/* ---- on-disk formats.  Torus-domain objects are written byte for byte as the reference writes them (table keys: its uncompressed
+ * row form); DFT-domain keys keep the reference's integer header, then a layout tag and the engine's own image (DFT contents are backend-defined in
+ * the reference as well, src/polynomial.c:336-357).  Short reads abort. ---- */
+void tlwe_save_sample(FILE *fd, TLWE c);                         /* tlwe.c:43-46 */
+void tlwe_load_sample(FILE *fd, TLWE c);                         /* tlwe.c:55-58 */
+TLWE tlwe_load_new_sample(FILE *fd, int n);                      /* tlwe.c:48-53 */
+void tlwe_save_key(FILE *fd, TLWE_Key key);                      /* tlwe.c:85-89 */
+TLWE_Key tlwe_load_new_key(FILE *fd);                            /* tlwe.c:91-99 */
+void trlwe_save_sample(FILE *fd, TRLWE c);                       /* trlwe.c:24-29 */
+void trlwe_load_sample(FILE *fd, TRLWE c);                       /* trlwe.c:31-37 */
+TRLWE trlwe_load_new_sample(FILE *fd, int k, int N);             /* trlwe.c:39-43 */
+void trlwe_save_key(FILE *fd, TRLWE_Key key);                    /* trlwe.c:230-237 */
+TRLWE_Key trlwe_load_new_key(FILE *fd);                          /* trlwe.c:239-251 */
+void trgsw_save_key(FILE *fd, TRGSW_Key key);                    /* trgsw.c:38-42 */
+TRGSW_Key trgsw_load_new_key(FILE *fd);                          /* trgsw.c:29-36 */
+void trgsw_save_sample(FILE *fd, TRGSW c);                       /* trgsw.c:60-64 */
+void trgsw_load_sample(FILE *fd, TRGSW c);
+TRGSW trgsw_load_new_sample(FILE *fd, int l, int Bg_bit, int k, int N);   /* trgsw.c:66-72 */
+void tlwe_save_KS_key(FILE *fd, TLWE_KS_Key key);                /* tlwe.c:275-287 */
+TLWE_KS_Key tlwe_load_new_KS_key(FILE *fd);                      /* tlwe.c:247-273 */
+void trlwe_save_generic_ks_key(FILE *fd, Generic_KS_Key key);    /* keyswitch.c:409-424 */
+Generic_KS_Key trlwe_load_new_generic_ks_key(FILE *fd);          /* keyswitch.c:426-455 */
+void trlwe_save_KS_key(FILE *fd, TRLWE_KS_Key key);              /* keyswitch.c:122-134 */
+TRLWE_KS_Key trlwe_load_new_KS_key(FILE *fd);                    /* keyswitch.c:136-160 */
+void save_bootstrap_key(FILE *fd, Bootstrap_Key key);            /* bootstrap.c:63-81 */
+Bootstrap_Key load_new_bootstrap_key(FILE *fd);                  /* bootstrap.c:83-104 */
+
 /* ---- batch extensions (new): arrays of `count` samples, one shared test vector ---- */
 void functional_bootstrap_batch(TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_Key key, int torus_base);
 void programmable_bootstrap_batch(TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_Key key,

@@ -276,6 +276,26 @@ int mosfhet_hip_keyswitch_functional_bootstrap_batch(mosfhet_hip_ctx_t ctx, mosf
 int mosfhet_hip_cmux_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, int key_index, uint64_t *d_out /*[count][2][N]*/, const uint64_t *d_in0,
                            const uint64_t *d_in1, int count, void *stream);
 
+/* Key images for the on-disk formats (save_bootstrap_key / load_new_bootstrap_key src/bootstrap.c:63-104, trlwe_save_KS_key /
+ * trlwe_load_new_KS_key src/keyswitch.c:122-160, tlwe_save_KS_key / tlwe_load_new_KS_key src/tlwe.c:247-287, trlwe_save_generic_ks_key /
+ * trlwe_load_new_generic_ks_key src/keyswitch.c:409-455).  DFT-domain contents are backend-defined in the reference too (src/polynomial.c:336-357):
+ * an image is the engine's own layout (tag mosfhet_hip_dft_layout_id), mosfhet_hip_bsk_bytes / mosfhet_hip_trlwe_ksk_bytes long, and exact -- an
+ * exported and re-imported key gives bit-identical results.  An unfolded bootstrap key's image is its torus-domain samples.  Table keys are the
+ * reference's uncompressed row order and stream row-wise (ksk_export_rows / ksk_alloc + ksk_import_rows), 2N or n_out + 1 words per row.
+ * info arrays: bsk {n, k, N, l, Bg_bit, unfolding}; trlwe_ksk {entries, N, t, base_bit}; ksk {n_in, row words, b_word, t, base_bit, kind}
+ * with kind 0 = LWE -> LWE, 1 = packing, 2 = private (n_in counts the b entry). */
+unsigned mosfhet_hip_dft_layout_id(void);
+int mosfhet_hip_bsk_info(mosfhet_hip_bsk_t bsk, int *out6);
+int mosfhet_hip_bsk_export(mosfhet_hip_bsk_t bsk, void *h_out);
+int mosfhet_hip_bsk_import(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t *out, const void *h_image, int n, int k, int N, int l, int Bg_bit, int unfolding);
+int mosfhet_hip_trlwe_ksk_info(mosfhet_hip_gak_t tks, int *out4);
+size_t mosfhet_hip_trlwe_ksk_bytes(mosfhet_hip_gak_t tks);
+int mosfhet_hip_trlwe_ksk_export(mosfhet_hip_gak_t tks, void *h_out);
+int mosfhet_hip_trlwe_ksk_import(mosfhet_hip_ctx_t ctx, mosfhet_hip_gak_t *out, const void *h_image, int entries, int N, int t, int base_bit);
+int mosfhet_hip_ksk_info(mosfhet_hip_ksk_t ksk, int *out6);
+int mosfhet_hip_ksk_alloc(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t *out, int kind, int n, int n_out_or_N, int t, int base_bit);
+int mosfhet_hip_ksk_import_rows(mosfhet_hip_ksk_t ksk, size_t first_row, size_t count, const uint64_t *h_in);
+
 /* Timing hook for bench.py: runs `reps` launches of the programmable-bootstrap kernel on `stream`
  * bracketed by hipEvents ON THAT STREAM and returns the average kernel time in milliseconds
  * (synchronises the stream). */

@@ -845,18 +845,16 @@ void mosfhet_gen_tlwe_ks_key_flat(Torus *out, TLWE_Key out_key, TLWE_Key in_key,
                                  in_key->s[i] * (Torus)v * ((Torus)1 << (W - (j + 1) * base_bit)), out_key);
 }
 
-TLWE_KS_Key tlwe_new_KS_key(TLWE_Key out_key, TLWE_Key in_key, int t, int base_bit) {
+/* host view with the reference's shape s[i][j][v] (mosfhet.h:62-65): TLWE headers aliasing the flat table, which the key owns; + device copy */
+static TLWE_KS_Key tlwe_ks_wrap(Torus *flat, int n_in, int n_out, int t, int base_bit, const char *who) {
   const int base = 1 << base_bit;
-  const size_t row = (size_t)out_key->n + 1, words = (size_t)in_key->n * t * (base - 1) * row;
+  const size_t row = (size_t)n_out + 1;
   TLWE_KS_Key res = (TLWE_KS_Key)xmalloc(sizeof(*res));
   res->base_bit = base_bit;
   res->t = t;
-  res->n = in_key->n;
-  Torus *flat = (Torus *)xmalloc(sizeof(Torus) * words);
-  mosfhet_gen_tlwe_ks_key_flat(flat, out_key, in_key, t, base_bit);
-  /* host view with the reference's shape s[i][j][v] (mosfhet.h:62-65): TLWE headers aliasing the flat table */
-  res->s = (TLWE ***)xmalloc(sizeof(TLWE **) * (size_t)in_key->n);
-  for (int i = 0; i < in_key->n; i++) {
+  res->n = n_in;
+  res->s = (TLWE ***)xmalloc(sizeof(TLWE **) * (size_t)n_in);
+  for (int i = 0; i < n_in; i++) {
     res->s[i] = (TLWE **)xmalloc(sizeof(TLWE *) * (size_t)t);
     for (int j = 0; j < t; j++) {
       res->s[i][j] = (TLWE *)xmalloc(sizeof(TLWE) * (size_t)(base - 1));
@@ -864,16 +862,23 @@ TLWE_KS_Key tlwe_new_KS_key(TLWE_Key out_key, TLWE_Key in_key, int t, int base_b
         Torus *r = flat + (((size_t)i * t + j) * (base - 1) + v) * row;
         TLWE c = (TLWE)xmalloc(sizeof(*c));
         c->a = r;
-        c->b = r[out_key->n];
-        c->n = out_key->n;
+        c->b = r[n_out];
+        c->n = n_out;
         res->s[i][j][v] = c;
       }
     }
   }
   mosfhet_hip_ksk_t dev = NULL;
-  if (mosfhet_hip_ksk_create((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, flat, in_key->n, out_key->n, t, base_bit)) die("tlwe_new_KS_key");
+  if (mosfhet_hip_ksk_create((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, flat, n_in, n_out, t, base_bit)) die(who);
   res->device = dev;
   return res;
+}
+
+TLWE_KS_Key tlwe_new_KS_key(TLWE_Key out_key, TLWE_Key in_key, int t, int base_bit) {
+  const size_t words = (size_t)in_key->n * t * ((1 << base_bit) - 1) * ((size_t)out_key->n + 1);
+  Torus *flat = (Torus *)xmalloc(sizeof(Torus) * words);
+  mosfhet_gen_tlwe_ks_key_flat(flat, out_key, in_key, t, base_bit);
+  return tlwe_ks_wrap(flat, in_key->n, out_key->n, t, base_bit, "tlwe_new_KS_key");
 }
 
 void free_tlwe_ks_key(TLWE_KS_Key key) {
@@ -1326,4 +1331,228 @@ void functional_bootstrap_trgsw_phase2(TLWE out, TRGSW_DFT in, TRLWE tv) {
     }
   fprintf(stderr, "mosfhet_amd: functional_bootstrap_trgsw_phase2: no bootstrap key with this ring / gadget is alive\n");
   abort();
+}
+
+/* ------------------------------------------------------------------ on-disk formats
+ * Torus-domain objects (secret keys, samples, the LWE key-switch table, the table-lookup TRLWE keys) are written byte for byte as the reference
+ * writes them (uncompressed rows: the reference's PORTABLE / A_PRNG=none shape of _MACRO_trlwe_save_sample, src/keyswitch.c:236-240).  DFT-domain
+ * keys keep the reference's integer header and then hold the engine's own image, preceded by its layout tag -- the reference's DFT contents are
+ * backend-defined too (src/polynomial.c:336-357), so such files were never portable between builds.  A short read aborts (the reference ignores
+ * fread's result and goes on with garbage). */
+static void xwrite(const void *p, size_t size, size_t count, FILE *fd) {
+  if (fwrite(p, size, count, fd) != count) { perror("mosfhet_amd: write failed"); abort(); }
+}
+static void xread(void *p, size_t size, size_t count, FILE *fd) {
+  if (fread(p, size, count, fd) != count) { fprintf(stderr, "mosfhet_amd: key / sample file is truncated\n"); abort(); }
+}
+static void read_ints(FILE *fd, int *v, int count) { xread(v, sizeof(int), (size_t)count, fd); }
+static void check_layout_tag(FILE *fd, const char *who) {
+  unsigned tag = 0;
+  xread(&tag, sizeof(tag), 1, fd);
+  if (tag != mosfhet_hip_dft_layout_id()) {
+    fprintf(stderr, "mosfhet_amd: %s: file holds DFT layout %08x, this engine uses %08x (files with DFT-domain keys are not portable between FFT back-ends)\n",
+            who, tag, mosfhet_hip_dft_layout_id());
+    abort();
+  }
+}
+
+void tlwe_save_sample(FILE *fd, TLWE c) { xwrite(c->a, sizeof(Torus), (size_t)c->n, fd); xwrite(&c->b, sizeof(Torus), 1, fd); }
+void tlwe_load_sample(FILE *fd, TLWE c) { xread(c->a, sizeof(Torus), (size_t)c->n, fd); xread(&c->b, sizeof(Torus), 1, fd); }
+TLWE tlwe_load_new_sample(FILE *fd, int n) { TLWE c = tlwe_alloc_sample(n); tlwe_load_sample(fd, c); return c; }
+
+void tlwe_save_key(FILE *fd, TLWE_Key key) {
+  xwrite(&key->n, sizeof(int), 1, fd);
+  xwrite(&key->sigma, sizeof(double), 1, fd);
+  xwrite(key->s, sizeof(Torus), (size_t)key->n, fd);
+}
+TLWE_Key tlwe_load_new_key(FILE *fd) {
+  int n; double sigma;
+  read_ints(fd, &n, 1);
+  xread(&sigma, sizeof(double), 1, fd);
+  TLWE_Key key = tlwe_alloc_key(n, sigma);
+  xread(key->s, sizeof(Torus), (size_t)n, fd);
+  return key;
+}
+
+void trlwe_save_sample(FILE *fd, TRLWE c) {
+  for (int i = 0; i < c->k; i++) xwrite(c->a[i]->coeffs, sizeof(Torus), (size_t)c->b->N, fd);
+  xwrite(c->b->coeffs, sizeof(Torus), (size_t)c->b->N, fd);
+}
+void trlwe_load_sample(FILE *fd, TRLWE c) {
+  for (int i = 0; i < c->k; i++) xread(c->a[i]->coeffs, sizeof(Torus), (size_t)c->b->N, fd);
+  xread(c->b->coeffs, sizeof(Torus), (size_t)c->b->N, fd);
+}
+TRLWE trlwe_load_new_sample(FILE *fd, int k, int N) { TRLWE c = trlwe_alloc_new_sample(k, N); trlwe_load_sample(fd, c); return c; }
+
+void trlwe_save_key(FILE *fd, TRLWE_Key key) {
+  xwrite(&key->k, sizeof(int), 1, fd);
+  xwrite(&key->s[0]->N, sizeof(int), 1, fd);
+  xwrite(&key->sigma, sizeof(double), 1, fd);
+  for (int i = 0; i < key->k; i++) xwrite(key->s[i]->coeffs, sizeof(Torus), (size_t)key->s[0]->N, fd);
+}
+TRLWE_Key trlwe_load_new_key(FILE *fd) {
+  int kN[2]; double sigma;
+  read_ints(fd, kN, 2);
+  xread(&sigma, sizeof(double), 1, fd);
+  TRLWE_Key key = trlwe_alloc_key(kN[1], kN[0], sigma);
+  for (int i = 0; i < key->k; i++) xread(key->s[i]->coeffs, sizeof(Torus), (size_t)kN[1], fd);
+  return key;
+}
+
+void trgsw_save_key(FILE *fd, TRGSW_Key key) {
+  xwrite(&key->l, sizeof(int), 1, fd);
+  xwrite(&key->Bg_bit, sizeof(int), 1, fd);
+  trlwe_save_key(fd, key->trlwe_key);
+}
+TRGSW_Key trgsw_load_new_key(FILE *fd) {
+  int v[2];
+  read_ints(fd, v, 2);
+  return trgsw_new_key(trlwe_load_new_key(fd), v[0], v[1]);
+}
+
+void trgsw_save_sample(FILE *fd, TRGSW c) {
+  for (int i = 0; i < c->l * (c->samples[0]->k + 1); i++) trlwe_save_sample(fd, c->samples[i]);
+}
+void trgsw_load_sample(FILE *fd, TRGSW c) {
+  for (int i = 0; i < c->l * (c->samples[0]->k + 1); i++) trlwe_load_sample(fd, c->samples[i]);
+}
+TRGSW trgsw_load_new_sample(FILE *fd, int l, int Bg_bit, int k, int N) {
+  TRGSW c = trgsw_alloc_new_sample(l, Bg_bit, k, N);
+  trgsw_load_sample(fd, c);
+  return c;
+}
+
+/* LWE key-switch key: header n, t, base_bit, n_out, then every row a[n_out], b -- the flat table as it is (src/tlwe.c:247-287) */
+void tlwe_save_KS_key(FILE *fd, TLWE_KS_Key key) {
+  const int n_out = key->s[0][0][0]->n;
+  xwrite(&key->n, sizeof(int), 1, fd);
+  xwrite(&key->t, sizeof(int), 1, fd);
+  xwrite(&key->base_bit, sizeof(int), 1, fd);
+  xwrite(&n_out, sizeof(int), 1, fd);
+  xwrite(key->s[0][0][0]->a, sizeof(Torus), (size_t)key->n * key->t * ((1 << key->base_bit) - 1) * ((size_t)n_out + 1), fd);
+}
+TLWE_KS_Key tlwe_load_new_KS_key(FILE *fd) {
+  int v[4];  /* n, t, base_bit, n_out */
+  read_ints(fd, v, 4);
+  if (v[0] < 1 || v[1] < 1 || v[2] < 1 || v[2] > 8 || v[3] < 1) { fprintf(stderr, "mosfhet_amd: tlwe_load_new_KS_key: bad header\n"); abort(); }
+  const size_t words = (size_t)v[0] * v[1] * ((1 << v[2]) - 1) * ((size_t)v[3] + 1);
+  Torus *flat = (Torus *)xmalloc(sizeof(Torus) * words);
+  xread(flat, sizeof(Torus), words, fd);
+  return tlwe_ks_wrap(flat, v[0], v[3], v[1], v[2], "tlwe_load_new_KS_key");
+}
+
+/* table-lookup TRLWE keys (packing / private): header base_bit, t, n, k, N, include_b, then (n + include_b) t (2^bb - 1) rows a[N], b[N]
+ * (src/keyswitch.c:409-455, uncompressed rows), streamed through a bounded host buffer: the config-4 packing key is 6 GB */
+#define KS_IO_CHUNK_BYTES ((size_t)64 << 20)
+void trlwe_save_generic_ks_key(FILE *fd, Generic_KS_Key key) {
+  int info[6];
+  if (mosfhet_hip_ksk_info((mosfhet_hip_ksk_t)key->device, info)) die("trlwe_save_generic_ks_key");
+  const int N = info[1] / 2, k = 1;
+  xwrite(&key->base_bit, sizeof(int), 1, fd);
+  xwrite(&key->t, sizeof(int), 1, fd);
+  xwrite(&key->n, sizeof(int), 1, fd);
+  xwrite(&k, sizeof(int), 1, fd);
+  xwrite(&N, sizeof(int), 1, fd);
+  xwrite(&key->include_b, sizeof(int), 1, fd);
+  const size_t rows = (size_t)info[0] * key->t * ((1 << key->base_bit) - 1), row_bytes = (size_t)info[1] * sizeof(Torus);
+  size_t chunk = KS_IO_CHUNK_BYTES / row_bytes;
+  if (chunk < 1) chunk = 1;
+  Torus *buf = (Torus *)xmalloc(chunk * row_bytes);
+  for (size_t r = 0; r < rows; r += chunk) {
+    const size_t c = rows - r < chunk ? rows - r : chunk;
+    if (mosfhet_hip_ksk_export_rows((mosfhet_hip_ksk_t)key->device, r, c, buf)) die("trlwe_save_generic_ks_key");
+    xwrite(buf, row_bytes, c, fd);
+  }
+  free(buf);
+}
+Generic_KS_Key trlwe_load_new_generic_ks_key(FILE *fd) {
+  int v[6];  /* base_bit, t, n, k, N, include_b */
+  read_ints(fd, v, 6);
+  if (v[3] != 1 || v[5] < 0 || v[5] > 1) { fprintf(stderr, "mosfhet_amd: trlwe_load_new_generic_ks_key: k = 1 keys only\n"); abort(); }
+  Generic_KS_Key res = (Generic_KS_Key)xmalloc(sizeof(*res));
+  res->s = NULL; res->base_bit = v[0]; res->t = v[1]; res->n = v[2]; res->include_b = v[5];
+  mosfhet_hip_ksk_t dev = NULL;
+  if (mosfhet_hip_ksk_alloc((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, v[5] ? 2 : 1, v[2], v[4], v[1], v[0])) die("trlwe_load_new_generic_ks_key");
+  const size_t rows = (size_t)(v[2] + v[5]) * v[1] * ((1 << v[0]) - 1), row_bytes = (size_t)2 * v[4] * sizeof(Torus);
+  size_t chunk = KS_IO_CHUNK_BYTES / row_bytes;
+  if (chunk < 1) chunk = 1;
+  Torus *buf = (Torus *)xmalloc(chunk * row_bytes);
+  for (size_t r = 0; r < rows; r += chunk) {
+    const size_t c = rows - r < chunk ? rows - r : chunk;
+    xread(buf, row_bytes, c, fd);
+    if (mosfhet_hip_ksk_import_rows(dev, r, c, buf)) die("trlwe_load_new_generic_ks_key");
+  }
+  free(buf);
+  res->device = dev;
+  return res;
+}
+
+/* FFT-based TRLWE key-switch key: header base_bit, t, k_in, k, N (src/keyswitch.c:122-160), layout tag, image of this key's t rows */
+void trlwe_save_KS_key(FILE *fd, TRLWE_KS_Key key) {
+  int info[4];
+  if (mosfhet_hip_trlwe_ksk_info((mosfhet_hip_gak_t)key->device, info)) die("trlwe_save_KS_key");
+  const int one = 1, N = info[1];
+  const unsigned tag = mosfhet_hip_dft_layout_id();
+  xwrite(&key->base_bit, sizeof(int), 1, fd);
+  xwrite(&key->t, sizeof(int), 1, fd);
+  xwrite(&one, sizeof(int), 1, fd);
+  xwrite(&one, sizeof(int), 1, fd);
+  xwrite(&N, sizeof(int), 1, fd);
+  xwrite(&tag, sizeof(tag), 1, fd);
+  const size_t bytes = mosfhet_hip_trlwe_ksk_bytes((mosfhet_hip_gak_t)key->device), entry_bytes = bytes / (size_t)info[0];
+  char *img = (char *)xmalloc(bytes);
+  if (mosfhet_hip_trlwe_ksk_export((mosfhet_hip_gak_t)key->device, img)) die("trlwe_save_KS_key");
+  xwrite(img + (size_t)key->entry * entry_bytes, 1, entry_bytes, fd);
+  free(img);
+}
+TRLWE_KS_Key trlwe_load_new_KS_key(FILE *fd) {
+  int v[5];  /* base_bit, t, k_in, k, N */
+  read_ints(fd, v, 5);
+  if (v[2] != 1 || v[3] != 1) { fprintf(stderr, "mosfhet_amd: trlwe_load_new_KS_key: k = 1 keys only\n"); abort(); }
+  check_layout_tag(fd, "trlwe_load_new_KS_key");
+  const size_t bytes = (size_t)v[1] * 2 * v[4] * sizeof(double);
+  char *img = (char *)xmalloc(bytes);
+  xread(img, 1, bytes, fd);
+  mosfhet_hip_gak_t dev = NULL;
+  if (mosfhet_hip_trlwe_ksk_import((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, img, 1, v[4], v[1], v[0])) die("trlwe_load_new_KS_key");
+  free(img);
+  return trlwe_ks_header(dev, 0, 1, v[1], v[0]);
+}
+
+/* bootstrap key: header n, l, k, N, Bg_bit, unfolding (src/bootstrap.c:63-104), layout tag, image (DFT rows; torus-domain samples when unfolded) */
+void save_bootstrap_key(FILE *fd, Bootstrap_Key key) {
+  mosfhet_hip_bsk_t dev = (mosfhet_hip_bsk_t)mosfhet_bootstrap_key_device(key);
+  const unsigned tag = mosfhet_hip_dft_layout_id();
+  xwrite(&key->n, sizeof(int), 1, fd);
+  xwrite(&key->l, sizeof(int), 1, fd);
+  xwrite(&key->k, sizeof(int), 1, fd);
+  xwrite(&key->N, sizeof(int), 1, fd);
+  xwrite(&key->Bg_bit, sizeof(int), 1, fd);
+  xwrite(&key->unfolding, sizeof(int), 1, fd);
+  xwrite(&tag, sizeof(tag), 1, fd);
+  const size_t bytes = mosfhet_hip_bsk_bytes(dev);
+  char *img = (char *)xmalloc(bytes);
+  if (mosfhet_hip_bsk_export(dev, img)) die("save_bootstrap_key");
+  xwrite(img, 1, bytes, fd);
+  free(img);
+}
+Bootstrap_Key load_new_bootstrap_key(FILE *fd) {
+  int v[6];  /* n, l, k, N, Bg_bit, unfolding */
+  read_ints(fd, v, 6);
+  check_layout_tag(fd, "load_new_bootstrap_key");
+  if (v[0] < 1 || v[1] < 1 || v[2] < 1 || v[3] < 2 || v[5] < 1 || v[5] > 8) { fprintf(stderr, "mosfhet_amd: load_new_bootstrap_key: bad header\n"); abort(); }
+  const size_t bytes = v[5] == 1 ? (size_t)v[0] * (v[2] + 1) * v[1] * (v[2] + 1) * v[3] * sizeof(double)
+                                 : (size_t)v[0] * ((size_t)1 << v[5]) / v[5] * 2 * v[1] * 2 * v[3] * sizeof(Torus);
+  char *img = (char *)xmalloc(bytes);
+  xread(img, 1, bytes, fd);
+  Bootstrap_Key res = (Bootstrap_Key)xmalloc(sizeof(*res));
+  res->n = v[0]; res->l = v[1]; res->k = v[2]; res->N = v[3]; res->Bg_bit = v[4]; res->unfolding = v[5];
+  res->su = NULL;
+  mosfhet_hip_bsk_t dev = NULL;
+  if (mosfhet_hip_bsk_import((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, img, v[0], v[2], v[3], v[1], v[4], v[5])) die("load_new_bootstrap_key");
+  free(img);
+  res->s = (TRGSW_DFT *)xmalloc(sizeof(TRGSW_DFT));
+  res->s[0] = (TRGSW_DFT)dev;
+  remember_key(res);
+  return res;
 }

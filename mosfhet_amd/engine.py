@@ -348,6 +348,35 @@ class Engine:
                                                           s_in.ctypes.data_as(C.c_void_p), s_in.size, t, base_bit, C.c_double(sigma), C.c_uint64(seed)))
         return KeySwitchKey(self, h, s_in.size + kind, 2 * s_out.size - 1, t, base_bit)
 
+    # ---- key images (on-disk formats; include/mosfhet_hip.h "Key images") ----
+    def export_bootstrap_key(self, bsk):
+        """The engine's own image of a bootstrap key (DFT rows; torus-domain samples for an unfolded key) as raw bytes."""
+        out = np.empty(bsk.nbytes, dtype=np.uint8)
+        _check(lib().mosfhet_hip_bsk_export(bsk.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def import_bootstrap_key(self, image, n, k, N, l, Bg_bit, unfolding=1):
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        h = C.c_void_p()
+        _check(lib().mosfhet_hip_bsk_import(self.h, C.byref(h), image.ctypes.data_as(C.c_void_p), n, k, N, l, Bg_bit, unfolding))
+        return BootstrapKey(self, h, n, k, N, l, Bg_bit)
+
+    def bootstrap_key_info(self, bsk):
+        v = (C.c_int * 6)()
+        _check(lib().mosfhet_hip_bsk_info(bsk.h, v))
+        return tuple(v)
+
+    def alloc_keyswitch_key(self, kind, n, n_out_or_N, t, base_bit):
+        """Empty table key to be filled by import_keyswitch_rows: kind 0 LWE -> LWE (n_out), 1 packing (N), 2 private (N)."""
+        h = C.c_void_p()
+        _check(lib().mosfhet_hip_ksk_alloc(self.h, C.byref(h), kind, n, n_out_or_N, t, base_bit))
+        return KeySwitchKey(self, h, n + (kind == 2), n_out_or_N if kind == 0 else 2 * n_out_or_N - 1, t, base_bit)
+
+    def import_keyswitch_rows(self, ksk, first_row, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        assert rows.shape[1] == ksk.n_out + 1
+        _check(lib().mosfhet_hip_ksk_import_rows(ksk.h, C.c_size_t(first_row), C.c_size_t(rows.shape[0]), rows.ctypes.data_as(C.c_void_p)))
+
     def export_key_rows(self, ksk, first_row, count):
         out = np.empty((count, ksk.n_out + 1), dtype=np.uint64)
         _check(lib().mosfhet_hip_ksk_export_rows(ksk.h, C.c_size_t(first_row), C.c_size_t(count), out.ctypes.data_as(C.c_void_p)))

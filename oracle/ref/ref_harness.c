@@ -665,6 +665,48 @@ void ref_trlwe_mv_extract(Torus *out, const Torus *in, int N, int mode, int amou
 /* ---------- CPU baseline: time `reps` reference programmable bootstraps on the calling thread.
  * Re-entrant across threads once ref_init(N) has run on the main thread (FFT processors are
  * __thread, src/polynomial.c:338-349). Returns elapsed seconds. ---------- */
+/* ---------- on-disk formats: the reference's own writers / readers (src/tlwe.c:43-99,247-287, src/trlwe.c:24-43,230-251, src/trgsw.c:29-42) ---------- */
+int ref_save_host_objects(const char *path, const Torus *lwe_s, int n, double lwe_sigma, const Torus *rlwe_s, int k, int N, double rlwe_sigma, int l,
+                          int Bg_bit, const Torus *tlwe_ct, const Torus *trlwe_ct) {
+  FILE *fd = fopen(path, "wb");
+  if (!fd) return 1;
+  TLWE_Key lk = tlwe_alloc_key(n, lwe_sigma);
+  memcpy(lk->s, lwe_s, sizeof(Torus) * n);
+  TRLWE_Key rk = trlwe_alloc_key(N, k, rlwe_sigma);
+  for (int i = 0; i < k; i++) memcpy(rk->s[i]->coeffs, rlwe_s + (size_t)i * N, sizeof(Torus) * N);
+  TRGSW_Key gk = trgsw_new_key(rk, l, Bg_bit);
+  TLWE c = tlwe_from_flat(tlwe_ct, n);
+  TRLWE rc = trlwe_from_flat(trlwe_ct, k, N);
+  tlwe_save_key(fd, lk);
+  trlwe_save_key(fd, rk);
+  trgsw_save_key(fd, gk);
+  tlwe_save_sample(fd, c);
+  trlwe_save_sample(fd, rc);
+  fclose(fd);
+  free_tlwe(c);
+  free_trlwe(rc);
+  free_trgsw_key(gk);
+  free_trlwe_key(rk);
+  free_tlwe_key(lk);
+  return 0;
+}
+
+int ref_ksk_save(const char *path, void *h) {
+  FILE *fd = fopen(path, "wb");
+  if (!fd) return 1;
+  tlwe_save_KS_key(fd, (TLWE_KS_Key)h);
+  fclose(fd);
+  return 0;
+}
+
+void *ref_ksk_load(const char *path) {
+  FILE *fd = fopen(path, "rb");
+  if (!fd) return NULL;
+  TLWE_KS_Key k = tlwe_load_new_KS_key(fd);
+  fclose(fd);
+  return k;
+}
+
 double ref_bench_programmable_bootstrap(const Torus *tv, const Torus *in, void *h, int precision, int reps) {
   Bootstrap_Key bk = (Bootstrap_Key)h;
   TRLWE t = trlwe_from_flat(tv, bk->k, bk->N);

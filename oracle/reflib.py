@@ -325,6 +325,25 @@ class Ref:
         self.l.ref_trlwe_mv_extract(_u(out), _u(c), N, mode, amount)
         return out if mode == 0 else out[0]
 
+    def save_host_objects(self, path, lwe_s, lwe_sigma, rlwe_s, rlwe_sigma, l, Bg_bit, tlwe_ct, trlwe_ct):
+        """tlwe_save_key, trlwe_save_key, trgsw_save_key, tlwe_save_sample, trlwe_save_sample into one file, in that order."""
+        k, N = rlwe_s.shape
+        self.l.ref_save_host_objects.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+                                                 C.c_void_p, C.c_void_p]
+        rc = self.l.ref_save_host_objects(path.encode(), _u(lwe_s), len(lwe_s), lwe_sigma, _u(rlwe_s), k, N, rlwe_sigma, l, Bg_bit, _u(tlwe_ct), _u(trlwe_ct))
+        assert rc == 0
+
+    def ksk_save(self, path, h):
+        self.l.ref_ksk_save.argtypes = [C.c_char_p, C.c_void_p]
+        assert self.l.ref_ksk_save(path.encode(), h) == 0
+
+    def ksk_load(self, path):
+        self.l.ref_ksk_load.argtypes = [C.c_char_p]
+        self.l.ref_ksk_load.restype = C.c_void_p
+        h = self.l.ref_ksk_load(path.encode())
+        assert h
+        return C.c_void_p(h)
+
     def bench_programmable_bootstrap(self, tv, c, h, precision, reps):
         """Seconds for `reps` programmable_bootstrap calls on the calling thread (GIL released)."""
         return self.l.ref_bench_programmable_bootstrap(_u(tv), _u(c), h, precision, reps)

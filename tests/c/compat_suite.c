@@ -370,6 +370,96 @@ static void case_radix_integer_add(void) {
   free_tlwe(tmp); free_trlwe(addsub); free_trlwe(tmp2); free_tlwe_ks_key(ksk);
 }
 
+/* on-disk formats (src/bootstrap.c:63-104, src/tlwe.c:43-99,247-287, src/trlwe.c:24-43,230-251, src/keyswitch.c:122-160,409-455): every key
+ * written to a file, read back, and used beside the original -- the results must be IDENTICAL, the operations are deterministic in the key */
+static int same_tlwe(TLWE a, TLWE b) { return a->n == b->n && a->b == b->b && !memcmp(a->a, b->a, sizeof(Torus) * a->n); }
+static int same_trlwe(TRLWE a, TRLWE b) {
+  return !memcmp(a->a[0]->coeffs, b->a[0]->coeffs, sizeof(Torus) * N) && !memcmp(a->b->coeffs, b->b->coeffs, sizeof(Torus) * N);
+}
+static void case_key_files(void) {
+  wide_setup();
+  FILE *fd = tmpfile();
+  CHECK(fd != NULL, "tmpfile");
+  if (!fd) return;
+  TLWE_KS_Key ksk = tlwe_new_KS_key(lwe_key, extracted_key, ks_t, ks_bb);
+  TRLWE_KS_Key *priv2 = trlwe_new_priv_KS_key(wkey, wkey, 20, 2);
+  Bootstrap_Key ubk = new_bootstrap_key(wgkey, lwe_key, 2);
+  TLWE ct = tlwe_new_sample(double2torus(0.125), lwe_key);
+  TorusPolynomial msg = polynomial_new_torus_polynomial(N);
+  for (int i = 0; i < N; i++) msg->coeffs[i] = double2torus((i % 8) / 8.);
+  TRLWE rct = trlwe_alloc_new_sample(k, N);
+  trlwe_sample(rct, msg, wkey);
+  TRGSW g = trgsw_alloc_new_sample(wl, wBg, k, N);
+  trgsw_monomial_sample(g, 1, 3, wgkey);
+  /* write everything into one file ... */
+  tlwe_save_key(fd, lwe_key); trlwe_save_key(fd, wkey); trgsw_save_key(fd, wgkey);
+  tlwe_save_sample(fd, ct); trlwe_save_sample(fd, rct); trgsw_save_sample(fd, g);
+  save_bootstrap_key(fd, bk); save_bootstrap_key(fd, ubk);
+  tlwe_save_KS_key(fd, ksk);
+  trlwe_save_KS_key(fd, priv2[0]); trlwe_save_KS_key(fd, priv2[1]);
+  trlwe_save_generic_ks_key(fd, wpack); trlwe_save_generic_ks_key(fd, wpriv);
+  const long bytes = ftell(fd);
+  rewind(fd);
+  /* ... and read it back */
+  TLWE_Key lwe2 = tlwe_load_new_key(fd);
+  TRLWE_Key wkey2 = trlwe_load_new_key(fd);
+  TRGSW_Key wgkey2 = trgsw_load_new_key(fd);
+  TLWE ct2 = tlwe_load_new_sample(fd, n);
+  TRLWE rct2 = trlwe_load_new_sample(fd, k, N);
+  TRGSW g2 = trgsw_load_new_sample(fd, wl, wBg, k, N);
+  Bootstrap_Key bk2 = load_new_bootstrap_key(fd), ubk2 = load_new_bootstrap_key(fd);
+  TLWE_KS_Key ksk2 = tlwe_load_new_KS_key(fd);
+  TRLWE_KS_Key priv2b[2];
+  priv2b[0] = trlwe_load_new_KS_key(fd); priv2b[1] = trlwe_load_new_KS_key(fd);
+  Generic_KS_Key wpack2 = trlwe_load_new_generic_ks_key(fd), wpriv2 = trlwe_load_new_generic_ks_key(fd);
+  CHECK(ftell(fd) == bytes && fgetc(fd) == EOF, "the readers consumed %ld of %ld bytes", ftell(fd), bytes);
+  fclose(fd);
+  /* host objects */
+  CHECK(lwe2->n == n && lwe2->sigma == lwe_key->sigma && !memcmp(lwe2->s, lwe_key->s, sizeof(Torus) * n), "tlwe key");
+  CHECK(wkey2->k == k && wkey2->sigma == wkey->sigma && !memcmp(wkey2->s[0]->coeffs, wkey->s[0]->coeffs, sizeof(Torus) * N), "trlwe key");
+  CHECK(wgkey2->l == wl && wgkey2->Bg_bit == wBg && !memcmp(wgkey2->trlwe_key->s[0]->coeffs, wkey->s[0]->coeffs, sizeof(Torus) * N), "trgsw key");
+  CHECK(same_tlwe(ct, ct2), "tlwe sample");
+  CHECK(same_trlwe(rct, rct2), "trlwe sample");
+  for (int q = 0; q < 2 * wl; q++) CHECK(same_trlwe(g->samples[q], g2->samples[q]), "trgsw sample row %d", q);
+  /* bootstrap keys: plain and unfolded */
+  Torus lut[4] = {int2torus(1, 4), int2torus(5, 4), int2torus(9, 4), int2torus(13, 4)};
+  TRLWE tv = trlwe_alloc_new_sample(k, N);
+  trlwe_torus_packing(tv, lut, 4);
+  TLWE o1 = tlwe_alloc_sample(N), o2 = tlwe_alloc_sample(N);
+  CHECK(bk2->n == bk->n && bk2->l == bk->l && bk2->k == bk->k && bk2->N == bk->N && bk2->Bg_bit == bk->Bg_bit && bk2->unfolding == 1, "bootstrap key header");
+  functional_bootstrap(o1, tv, ct, bk, 4); functional_bootstrap(o2, tv, ct, bk2, 4);
+  CHECK(same_tlwe(o1, o2), "bootstrap with the reloaded key differs");
+  WITHIN(1ULL << 58, lut[1], tlwe_phase(o2, extracted_key), "bootstrap with the reloaded key");
+  CHECK(ubk2->unfolding == 2, "unfolded key header");
+  functional_bootstrap(o1, tv, ct, ubk, 4); functional_bootstrap(o2, tv, ct, ubk2, 4);
+  CHECK(same_tlwe(o1, o2), "bootstrap with the reloaded unfolded key differs");
+  /* LWE key switch (the loaded key also has the host table view) */
+  TLWE big = tlwe_new_sample(double2torus(0.375), extracted_key), s1 = tlwe_alloc_sample(n), s2 = tlwe_alloc_sample(n);
+  tlwe_keyswitch(s1, big, ksk); tlwe_keyswitch(s2, big, ksk2);
+  CHECK(same_tlwe(s1, s2), "key switch with the reloaded key differs");
+  CHECK(ksk2->n == ksk->n && ksk2->t == ks_t && ksk2->base_bit == ks_bb && same_tlwe(ksk->s[N - 1][ks_t - 1][2], ksk2->s[N - 1][ks_t - 1][2]), "key-switch key host view");
+  /* FFT-based private key switch (two entries of one device key set, saved one by one) */
+  TRLWE r1 = trlwe_alloc_new_sample(k, N), r2 = trlwe_alloc_new_sample(k, N);
+  trlwe_priv_keyswitch_2(r1, rct, priv2);
+  trlwe_keyswitch(r2, rct, priv2b[0]); trlwe_keyswitch(r1, rct, priv2[0]);
+  CHECK(same_trlwe(r1, r2), "trlwe_keyswitch with reloaded key 0 differs");
+  trlwe_keyswitch(r2, rct, priv2b[1]); trlwe_keyswitch(r1, rct, priv2[1]);
+  CHECK(same_trlwe(r1, r2), "trlwe_keyswitch with reloaded key 1 differs");
+  /* table-lookup TRLWE keys */
+  TLWE lw = tlwe_new_sample(double2torus(0.125), wkey_extracted);
+  trlwe_packing1_keyswitch(r1, lw, wpack); trlwe_packing1_keyswitch(r2, lw, wpack2);
+  CHECK(same_trlwe(r1, r2), "packing key switch with the reloaded key differs");
+  trlwe_priv_keyswitch(r1, lw, wpriv); trlwe_priv_keyswitch(r2, lw, wpriv2);
+  CHECK(same_trlwe(r1, r2), "private key switch with the reloaded key differs");
+  CHECK(wpack2->n == wpack->n && wpack2->t == wpack->t && wpack2->base_bit == wpack->base_bit && wpack2->include_b == 0 && wpriv2->include_b == 1, "generic key header");
+  free_tlwe(lw); free_trlwe(r1); free_trlwe(r2); free_tlwe(big); free_tlwe(s1); free_tlwe(s2); free_tlwe(o1); free_tlwe(o2); free_trlwe(tv);
+  free_trlwe_generic_ks_key(wpack2); free_trlwe_generic_ks_key(wpriv2); free_trlwe_ks_key(priv2b[0]); free_trlwe_ks_key(priv2b[1]);
+  free_tlwe_ks_key(ksk2); free_bootstrap_key(bk2); free_bootstrap_key(ubk2); free_trgsw(g2); free_trlwe(rct2); free_tlwe(ct2);
+  free_trlwe_key(wgkey2->trlwe_key); free_trgsw_key(wgkey2); free_trlwe_key(wkey2); free_tlwe_key(lwe2);
+  free_trgsw(g); free_trlwe(rct); free_polynomial(msg); free_tlwe(ct); free_bootstrap_key(ubk);
+  free_trlwe_ks_key(priv2[0]); free_trlwe_ks_key(priv2[1]); free(priv2); free_tlwe_ks_key(ksk);
+}
+
 int main(int argc, char **argv) {
   setvbuf(stdout, NULL, _IOLBF, 0);
   mosfhet_seed(0x4D4F5346);
@@ -386,6 +476,7 @@ int main(int argc, char **argv) {
     {"circuit_bootstrap", case_circuit_bootstrap},       {"unfolded", case_unfolded},
     {"fdfb_variants", case_fdfb_variants},               {"multivalue_phases", case_multivalue_phases},
     {"circuit_2+mux+trgsw", case_circuit_2_mux_trgsw},   {"radix_integer_add", case_radix_integer_add},
+    {"key_files", case_key_files},
   };
   for (unsigned i = 0; i < sizeof(cases) / sizeof(cases[0]); i++) {
     if (argc > 1 && strcmp(argv[1], cases[i].name)) continue;

@@ -134,3 +134,46 @@ def test_compat_c_suite_compiles_and_links(native_lib, tmp_path):
     subprocess.check_call(["gcc", "-O1", "-std=gnu11", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
                            os.path.join(root, "tests", "c", "compat_suite.c"), "-o", str(tmp_path / "compat_suite"),
                            "-L" + libdir, "-lmosfhet_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+
+
+def _build_fileio_helper(tmp_path):
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "mosfhet_amd")
+    exe = str(tmp_path / "fileio_host")
+    subprocess.check_call(["gcc", "-O1", "-std=gnu11", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "c", "fileio_host.c"),
+                           "-o", exe, "-L" + libdir, "-lmosfhet_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_on_disk_formats_of_host_objects_are_the_references(native_lib, oracle, tmp_path):
+    """tests/golden/fileio.npz holds a file written by the REFERENCE's tlwe_save_key, trlwe_save_key, trgsw_save_key, tlwe_save_sample and
+    trlwe_save_sample (tests/golden/make_fileio_golden.py).  The compat readers must take it, and the compat writers must reproduce it byte for byte
+    (src/tlwe.c:43-99, src/trlwe.c:24-43,230-251, src/trgsw.c:29-42)."""
+    import os
+    import struct
+    import subprocess
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fileio.npz"))
+    n, N, k, l, Bg = (int(g[x]) for x in ("n", "N", "k", "l", "Bg_bit"))
+    # the documented layout, spelled out: it must be what the reference wrote
+    key_part = struct.pack("<id", n, float(g["lwe_sigma"])) + g["lwe_s"].tobytes()
+    rkey = struct.pack("<iid", k, N, float(g["rlwe_sigma"])) + g["rlwe_s"].tobytes()
+    expect = key_part + rkey + struct.pack("<ii", l, Bg) + rkey + g["tlwe_ct"].tobytes() + g["trlwe_ct"].tobytes()
+    assert g["host_file"].tobytes() == expect
+    exe = _build_fileio_helper(tmp_path)
+    src, dst = str(tmp_path / "ref.bin"), str(tmp_path / "mine.bin")
+    g["host_file"].tofile(src)
+    r = subprocess.run([exe, "host", src, dst], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout
+    assert open(dst, "rb").read() == expect
+    fields = dict(kv.split("=") for kv in r.stdout.split())
+    assert (int(fields["n"]), int(fields["k"]), int(fields["N"]), int(fields["l"]), int(fields["Bg_bit"])) == (n, k, N, l, Bg)
+    assert float(fields["lwe_sigma"]) == float(g["lwe_sigma"]) and float(fields["rlwe_sigma"]) == float(g["rlwe_sigma"])
+    assert int(fields["c.b"]) == int(g["tlwe_ct"][n]) and int(fields["rc.b0"]) == int(g["trlwe_ct"][k, 0])
+    assert int(fields["phase"]) == int(oracle.tlwe_phase(g["tlwe_ct"], g["lwe_s"]))
+    # the LWE key-switch key file (src/tlwe.c:275-287): header n, t, base_bit, n_out, then the table rows a[n_out], b as they lie in the flat layout
+    table = g["ks_table"]
+    n_in, t, cands, row = table.shape
+    assert g["ks_file"].tobytes() == struct.pack("<iiii", n_in, t, int(g["ks_base_bit"]), row - 1) + table.tobytes()
+    assert (oracle.tlwe_keyswitch(g["ks_in"], table, row - 1, t, int(g["ks_base_bit"])) == g["ks_switched"]).all()
