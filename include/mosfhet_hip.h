@@ -23,10 +23,11 @@
  *                    error, like the reference's assert/exit behaviour (src/misc.c:104-128).
  *   supported        k = 1; N = 1024, 2048, 4096 (all ring degrees of the reference's parameter sets, test/tests.c:37-62);
  *                    l <= 4 with l*Bg_bit < 64 (compile-time specialisations for 2x8, 4x9, 1x23); any n.
- *   threading        a context and its key handles may be used from several host threads, but calls that share a
- *                    KEY HANDLE must be serialised by the caller (compositions keep their temporaries in the handle);
- *                    independent handles / streams are independent.  (The reference is re-entrant through
- *                    thread-local scratch, src/polynomial.c:269-352.)
+ *   threading        re-entrant, like the reference (thread-local scratch there, src/polynomial.c:269-352): a context and its key
+ *                    handles are read-only after creation and may be shared by any number of host threads; device temporaries of
+ *                    the compositions and of the table key switches belong to the CALLING THREAD (grown on demand, released at
+ *                    thread exit).  A thread that spreads compositions over several streams must order them itself (its
+ *                    temporaries are shared between its own launches); create / destroy of a handle must not race with its use.
  * DFT-domain data (bootstrap key) is device-resident in the engine's own slot order and never leaves it,
  * as in the reference where the element order is private to the FFT back-end (src/polynomial.c:336-357).
  */

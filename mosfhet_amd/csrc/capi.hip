@@ -39,9 +39,55 @@ static int fail(int code, const char *fmt, ...) {
 struct mosfhet_hip_ctx {
   int device;
   d2 *tw1024, *tw2048, *tw4096;  // device twiddle tables
-  uint64_t *scratch[3] = {nullptr, nullptr, nullptr};  // temporaries of compositions without a bootstrap key (tlwe_mul, tensor product)
-  size_t scratch_words[3] = {0, 0, 0};
 };
+
+// Temporaries of the compositions (FDFB, multi-value, circuit bootstraps, tlwe_mul, ...) and the transposed batches of the table key
+// switches live in a pool that belongs to the CALLING HOST THREAD (one set of growable device buffers per device), never in a context or key
+// handle: handles are read-only after creation, so any number of host threads may share them, as the reference's callers share its keys
+// (re-entrant through thread-local scratch, src/polynomial.c:269-352).  A thread's launches are ordered by the stream it passes; buffers are
+// released at thread exit (hipFree waits for work in flight).
+enum { POOL_BSK = 0, POOL_EXT0 = 1, POOL_EXT1 = 2, POOL_CTX0 = 3, POOL_SLOTS = 6 };
+struct ThreadPool {
+  struct Dev {
+    int device = -1;
+    KsWorkspace ws;
+    uint64_t *buf[POOL_SLOTS] = {};
+    size_t words[POOL_SLOTS] = {};
+  };
+  std::vector<Dev> devs;
+  Dev &get(int device) {
+    for (Dev &d : devs)
+      if (d.device == device) return d;
+    devs.emplace_back();
+    devs.back().device = device;
+    return devs.back();
+  }
+  ~ThreadPool() {
+    for (Dev &d : devs) {
+      if (hipSetDevice(d.device) != hipSuccess) continue;
+      if (d.ws.inT) (void)hipFree(d.ws.inT);
+      if (d.ws.outT) (void)hipFree(d.ws.outT);
+      for (int i = 0; i < POOL_SLOTS; i++)
+        if (d.buf[i]) (void)hipFree(d.buf[i]);
+    }
+  }
+};
+static thread_local ThreadPool t_pool;
+
+static KsWorkspace &tl_ws(int device) { return t_pool.get(device).ws; }
+
+static int pool_get(int device, int slot, size_t words, uint64_t **out) {
+  ThreadPool::Dev &d = t_pool.get(device);
+  if (d.words[slot] < words) {
+    if (d.buf[slot]) (void)hipFree(d.buf[slot]);
+    d.buf[slot] = nullptr;
+    d.words[slot] = 0;
+    HIP_TRY(hipMalloc((void **)&d.buf[slot], words * sizeof(uint64_t)));
+    d.words[slot] = words;
+  }
+  *out = d.buf[slot];
+  return MOSFHET_HIP_OK;
+}
 
 struct mosfhet_hip_bsk {
   mosfhet_hip_ctx_t ctx;
@@ -50,10 +96,6 @@ struct mosfhet_hip_bsk {
   int unfolding = 1;          // > 1: d_bk is null and d_su holds the torus-domain samples of new_bootstrap_key (src/bootstrap.c:23-48)
   uint64_t *d_su = nullptr;   // [n 2^u / u][2l][2][N]
   size_t bytes;
-  uint64_t *scratch = nullptr;  // FDFB / multi-value temporaries, grown on demand
-  size_t scratch_words = 0;
-  uint64_t *ext_scratch[2] = {nullptr, nullptr};  // temporaries of the wider compositions (capi_ext.inc); slot 1 = nested (tlwe_mul)
-  size_t ext_words[2] = {0, 0};
 };
 
 struct mosfhet_hip_ksk {
@@ -62,7 +104,6 @@ struct mosfhet_hip_ksk {
   int n_in, n_out, t, base_bit;
   int row, b_word;  // output row words and the word that receives in.b (LWE: n_out + 1, n_out; packing -> TRLWE: 2N, N)
   size_t bytes;
-  KsWorkspace ws;  // transposed batch buffers, grown on demand
 };
 
 struct mosfhet_hip_gak {
@@ -143,8 +184,6 @@ extern "C" int mosfhet_hip_ctx_destroy(mosfhet_hip_ctx_t ctx) {
   hipFree(ctx->tw1024);
   hipFree(ctx->tw2048);
   hipFree(ctx->tw4096);
-  for (int i = 0; i < 3; i++)
-    if (ctx->scratch[i]) hipFree(ctx->scratch[i]);
   delete ctx;
   return MOSFHET_HIP_OK;
 }
@@ -217,9 +256,6 @@ extern "C" int mosfhet_hip_bsk_destroy(mosfhet_hip_bsk_t bsk) {
   hipSetDevice(bsk->ctx->device);
   if (bsk->d_bk) hipFree(bsk->d_bk);
   if (bsk->d_su) hipFree(bsk->d_su);
-  if (bsk->scratch) hipFree(bsk->scratch);
-  for (int i = 0; i < 2; i++)
-    if (bsk->ext_scratch[i]) hipFree(bsk->ext_scratch[i]);
   delete bsk;
   return MOSFHET_HIP_OK;
 }
@@ -462,8 +498,6 @@ extern "C" int mosfhet_hip_ksk_destroy(mosfhet_hip_ksk_t ksk) {
   if (!ksk) return MOSFHET_HIP_OK;
   hipSetDevice(ksk->ctx->device);
   hipFree(ksk->d_ksk);
-  if (ksk->ws.inT) hipFree(ksk->ws.inT);
-  if (ksk->ws.outT) hipFree(ksk->ws.outT);
   delete ksk;
   return MOSFHET_HIP_OK;
 }
@@ -476,7 +510,7 @@ extern "C" int mosfhet_hip_tlwe_keyswitch_batch(mosfhet_hip_ctx_t ctx, mosfhet_h
   HIP_TRY(hipSetDevice(ctx->device));
   if (ksk->b_word != ksk->n_out) return fail(MOSFHET_HIP_EINVAL, "tlwe_keyswitch: this key is a packing (LWE -> TRLWE) key");
   HIP_TRY(launch_tlwe_keyswitch(ksk->d_ksk, d_out, (size_t)ksk->row, d_in, (size_t)ksk->n_in + 1, count, ksk->n_in, ksk->row, ksk->b_word, ksk->t,
-                                ksk->base_bit, ksk->ws, pick(ctx, stream)));
+                                ksk->base_bit, tl_ws(ctx->device), pick(ctx, stream)));
   return MOSFHET_HIP_OK;
 }
 
@@ -502,15 +536,7 @@ extern "C" int mosfhet_hip_tlwe_addto_batch(mosfhet_hip_ctx_t ctx, uint64_t *d_o
   return MOSFHET_HIP_OK;
 }
 
-static int bsk_scratch(mosfhet_hip_bsk_t bsk, size_t words) {
-  if (bsk->scratch_words >= words) return MOSFHET_HIP_OK;
-  if (bsk->scratch) hipFree(bsk->scratch);
-  bsk->scratch = nullptr;
-  bsk->scratch_words = 0;
-  HIP_TRY(hipMalloc((void **)&bsk->scratch, words * sizeof(uint64_t)));
-  bsk->scratch_words = words;
-  return MOSFHET_HIP_OK;
-}
+static int bsk_scratch(mosfhet_hip_bsk_t bsk, size_t words, uint64_t **out) { return pool_get(bsk->ctx->device, POOL_BSK, words, out); }
 
 extern "C" int mosfhet_hip_full_domain_functional_bootstrap_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, mosfhet_hip_ksk_t ksk,
                                                                   uint64_t *d_out, const uint64_t *d_tv, int tv_count,
@@ -523,9 +549,10 @@ extern "C" int mosfhet_hip_full_domain_functional_bootstrap_batch(mosfhet_hip_ct
   HIP_TRY(hipSetDevice(ctx->device));
   const int N = bsk->N, n = bsk->n;
   const size_t w_tv = (size_t)2 * N, w_sign = (size_t)count * (N + 1), w_in2 = (size_t)count * (n + 1);
-  int rc = bsk_scratch(bsk, w_tv + w_sign + w_in2);
+  uint64_t *tv_sign = nullptr;
+  int rc = bsk_scratch(bsk, w_tv + w_sign + w_in2, &tv_sign);
   if (rc) return rc;
-  uint64_t *tv_sign = bsk->scratch, *ct_sign = tv_sign + w_tv, *in2 = ct_sign + w_sign;
+  uint64_t *ct_sign = tv_sign + w_tv, *in2 = ct_sign + w_sign;
   hipStream_t s = pick(ctx, stream);
   // src/bootstrap.c:525-527: sign = 2^62 - 2^(62 - precision), constant test vector
   const uint64_t sign = (1ull << 62) - (1ull << (62 - precision));
@@ -546,14 +573,15 @@ extern "C" int mosfhet_hip_multivalue_bootstrap_CLOT21_batch(mosfhet_hip_ctx_t c
   if (N % (n_luts * torus_base)) return fail(MOSFHET_HIP_EINVAL, "multivalue_CLOT21: N not divisible by n_luts * torus_base");
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
-  int rc = bsk_scratch(bsk, (size_t)count * 2 * N);
+  uint64_t *rotated = nullptr;
+  int rc = bsk_scratch(bsk, (size_t)count * 2 * N, &rotated);
   if (rc) return rc;
-  if ((rc = mosfhet_hip_functional_bootstrap_wo_extract_batch(ctx, bsk, bsk->scratch, d_tv, tv_count, d_in, count, torus_base * n_luts, stream)))
+  if ((rc = mosfhet_hip_functional_bootstrap_wo_extract_batch(ctx, bsk, rotated, d_tv, tv_count, d_in, count, torus_base * n_luts, stream)))
     return rc;
   const int slot = N / (n_luts * torus_base);
   for (int i = 0; i < n_luts; i++)
     hipLaunchKernelGGL(trlwe_extract_kernel, dim3((N + 255) / 256, count), dim3(256), 0, pick(ctx, stream), d_out + (size_t)i * (N + 1),
-                       (size_t)n_luts * (N + 1), bsk->scratch, (size_t)2 * N, N, i * slot);
+                       (size_t)n_luts * (N + 1), rotated, (size_t)2 * N, N, i * slot);
   HIP_TRY(hipGetLastError());
   return MOSFHET_HIP_OK;
 }
@@ -704,7 +732,7 @@ extern "C" int mosfhet_hip_trlwe_packing1_keyswitch_batch(mosfhet_hip_ctx_t ctx,
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(launch_tlwe_keyswitch(ksk->d_ksk, d_out, (size_t)ksk->row, d_in, (size_t)ksk->n_in + 1, count, ksk->n_in, ksk->row, ksk->b_word, ksk->t,
-                                ksk->base_bit, ksk->ws, pick(ctx, stream)));
+                                ksk->base_bit, tl_ws(ctx->device), pick(ctx, stream)));
   return MOSFHET_HIP_OK;
 }
 
@@ -727,9 +755,10 @@ extern "C" int mosfhet_hip_circuit_bootstrap_3_batch(mosfhet_hip_ctx_t ctx, mosf
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
   const size_t w_tv = (size_t)2 * N, w_acc = (size_t)count * 2 * N, w_ext = (size_t)count * (N + 1);
-  int rc = bsk_scratch(bsk, w_tv + w_acc + w_ext);
+  uint64_t *tv = nullptr;
+  int rc = bsk_scratch(bsk, w_tv + w_acc + w_ext, &tv);
   if (rc) return rc;
-  uint64_t *tv = bsk->scratch, *acc = tv + w_tv, *ext = acc + w_acc;
+  uint64_t *acc = tv + w_tv, *ext = acc + w_acc;
   hipStream_t s = pick(ctx, stream);
   hipLaunchKernelGGL(circuit_bootstrap_lut_kernel, dim3((N + 255) / 256), dim3(256), 0, s, tv, N, l, bsk->Bg_bit);
   if ((rc = mosfhet_hip_functional_bootstrap_wo_extract_batch(ctx, bsk, acc, tv, 1, d_in, count, 2 * l, stream))) return rc;
@@ -738,7 +767,7 @@ extern "C" int mosfhet_hip_circuit_bootstrap_3_batch(mosfhet_hip_ctx_t ctx, mosf
   for (int i = 0; i < l; i++) {
     hipLaunchKernelGGL(trlwe_extract_kernel, dim3((N + 255) / 256, count), dim3(256), 0, s, ext, (size_t)N + 1, acc, (size_t)2 * N, N, i * slot);
     uint64_t *row_b = d_out + (size_t)(l + i) * 2 * N, *row_a = d_out + (size_t)i * 2 * N;
-    HIP_TRY(launch_tlwe_keyswitch(kskb->d_ksk, row_b, trgsw, ext, (size_t)N + 1, count, N, 2 * N, N, kskb->t, kskb->base_bit, kskb->ws, s));
+    HIP_TRY(launch_tlwe_keyswitch(kskb->d_ksk, row_b, trgsw, ext, (size_t)N + 1, count, N, 2 * N, N, kskb->t, kskb->base_bit, tl_ws(ctx->device), s));
     if ((rc = launch_fft_ks(ctx, kska, kska->d_ak, kska->d_ak + esz, row_a, trgsw, row_b, trgsw, count, 1, s))) return rc;
   }
   HIP_TRY(hipGetLastError());

@@ -11,6 +11,7 @@
 #include "mosfhet_hip.h"
 
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -49,20 +50,36 @@ void mosfhet_set_device(int device) {
   g_device = device;
 }
 
+/* The layer is re-entrant like the reference (thread-local FFT state there, src/polynomial.c:269-352): the engine is created once under a lock,
+ * keys are read-only after creation and may be shared by any number of host threads (device temporaries belong to the calling thread,
+ * csrc/capi.hip), every thread has its own staging buffer and its own random stream. */
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+
 void *mosfhet_engine_ctx(void) {
+  mosfhet_hip_ctx_t c = __atomic_load_n(&g_ctx, __ATOMIC_ACQUIRE);
+  if (c) return c;
+  pthread_mutex_lock(&g_lock);
   if (!g_ctx) {
     if (g_device < 0) {
       const char *e = getenv("MOSFHET_HIP_DEVICE");
       g_device = e ? atoi(e) : 0;
     }
-    if (mosfhet_hip_ctx_create(&g_ctx, g_device)) die("engine start-up");
+    mosfhet_hip_ctx_t fresh = NULL;
+    if (mosfhet_hip_ctx_create(&fresh, g_device)) die("engine start-up");
+    __atomic_store_n(&g_ctx, fresh, __ATOMIC_RELEASE);
   }
+  pthread_mutex_unlock(&g_lock);
   return g_ctx;
 }
 
 /* ------------------------------------------------------------------ randomness: xoshiro256** */
-static uint64_t g_rng[4];
-static int g_rng_ready = 0;
+/* One stream per host thread.  mosfhet_seed seeds the CALLING thread's stream (a single-threaded program is reproducible exactly as before) and
+ * becomes the base from which threads that never seeded derive theirs (base, then a per-thread ticket): no shared generator state. */
+static __thread uint64_t g_rng[4];
+static __thread int g_rng_ready = 0;
+static uint64_t g_base_seed = 0;
+static int g_base_seed_set = 0;
+static uint64_t g_thread_ticket = 0;
 
 static uint64_t splitmix(uint64_t *x) {
   uint64_t z = (*x += 0x9E3779B97F4A7C15ull);
@@ -71,20 +88,33 @@ static uint64_t splitmix(uint64_t *x) {
   return z ^ (z >> 31);
 }
 
-void mosfhet_seed(uint64_t seed) {
+static void seed_this_thread(uint64_t seed) {
   for (int i = 0; i < 4; i++) g_rng[i] = splitmix(&seed);
   g_rng_ready = 1;
+}
+
+void mosfhet_seed(uint64_t seed) {
+  pthread_mutex_lock(&g_lock);
+  g_base_seed = seed;
+  g_base_seed_set = 1;
+  pthread_mutex_unlock(&g_lock);
+  seed_this_thread(seed);
 }
 
 static inline uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
 
 static uint64_t rnd64(void) {
   if (!g_rng_ready) {
-    uint64_t seed = 0;
-    FILE *f = fopen("/dev/urandom", "rb");
-    if (!f || fread(&seed, sizeof(seed), 1, f) != 1) seed = 0x4D4F5346ull;
-    if (f) fclose(f);
-    mosfhet_seed(seed);
+    pthread_mutex_lock(&g_lock);
+    if (!g_base_seed_set) {
+      FILE *f = fopen("/dev/urandom", "rb");
+      if (!f || fread(&g_base_seed, sizeof(g_base_seed), 1, f) != 1) g_base_seed = 0x4D4F5346ull;
+      if (f) fclose(f);
+      g_base_seed_set = 1;
+    }
+    uint64_t seed = g_base_seed ^ (0xA24BAED4963EE407ull * ++g_thread_ticket);
+    pthread_mutex_unlock(&g_lock);
+    seed_this_thread(splitmix(&seed));
   }
   const uint64_t r = rotl(g_rng[1] * 5, 7) * 9, t = g_rng[1] << 17;
   g_rng[2] ^= g_rng[0];
@@ -537,15 +567,20 @@ void mosfhet_gen_bootstrap_key_flat(Torus *out, TRGSW_Key out_key, TLWE_Key in_k
 static Bootstrap_Key g_keys[MAX_KEYS];
 
 static void remember_key(Bootstrap_Key key) {
+  pthread_mutex_lock(&g_lock);
+  int seen = 0;
   for (int i = 0; i < MAX_KEYS; i++)
-    if (g_keys[i] == key) return;
-  for (int i = 0; i < MAX_KEYS; i++)
-    if (!g_keys[i]) { g_keys[i] = key; return; }
+    if (g_keys[i] == key) seen = 1;
+  for (int i = 0; i < MAX_KEYS && !seen; i++)
+    if (!g_keys[i]) { g_keys[i] = key; seen = 1; }
+  pthread_mutex_unlock(&g_lock);
 }
 
 static void forget_key(Bootstrap_Key key) {
+  pthread_mutex_lock(&g_lock);
   for (int i = 0; i < MAX_KEYS; i++)
     if (g_keys[i] == key) g_keys[i] = NULL;
+  pthread_mutex_unlock(&g_lock);
 }
 
 /* Bootstrap_Key.s is an opaque token: a one-element array holding the device key handle. */
@@ -705,8 +740,10 @@ void multivalue_bootstrap_CLOT21(TLWE *out, TRLWE tv, TLWE in, Bootstrap_Key key
 
 void blind_rotate(TRLWE tv, Torus *a, TRGSW_DFT *s, int size) {
   Bootstrap_Key key = NULL;
+  pthread_mutex_lock(&g_lock);
   for (int i = 0; i < MAX_KEYS; i++)
     if (g_keys[i] && g_keys[i]->s == s) key = g_keys[i];
+  pthread_mutex_unlock(&g_lock);
   if (!key || size != key->n) {
     fprintf(stderr, "mosfhet_amd: blind_rotate: `s` must be the .s member of a Bootstrap_Key made by new_bootstrap_key "
                     "and size its n (device-resident key)\n");
@@ -1324,11 +1361,15 @@ void functional_bootstrap_trgsw_phase2_key(TLWE out, TRGSW_DFT in, TRLWE tv, Boo
 /* the reference's signature has no key argument (src/bootstrap.c:297); the gadget comes from the TRGSW_DFT, the engine handle from
  * any registered bootstrap key of that ring and gadget */
 void functional_bootstrap_trgsw_phase2(TLWE out, TRGSW_DFT in, TRLWE tv) {
-  for (int i = 0; i < MAX_KEYS; i++)
-    if (g_keys[i] && g_keys[i]->unfolding == 1 && g_keys[i]->N == in->N && g_keys[i]->l == in->l && g_keys[i]->Bg_bit == in->Bg_bit) {
-      functional_bootstrap_trgsw_phase2_key(out, in, tv, g_keys[i]);
-      return;
-    }
+  Bootstrap_Key key = NULL;
+  pthread_mutex_lock(&g_lock);
+  for (int i = 0; i < MAX_KEYS && !key; i++)
+    if (g_keys[i] && g_keys[i]->unfolding == 1 && g_keys[i]->N == in->N && g_keys[i]->l == in->l && g_keys[i]->Bg_bit == in->Bg_bit) key = g_keys[i];
+  pthread_mutex_unlock(&g_lock);
+  if (key) {
+    functional_bootstrap_trgsw_phase2_key(out, in, tv, key);
+    return;
+  }
   fprintf(stderr, "mosfhet_amd: functional_bootstrap_trgsw_phase2: no bootstrap key with this ring / gadget is alive\n");
   abort();
 }

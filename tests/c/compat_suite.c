@@ -4,6 +4,7 @@
  * libmosfhet_hip.so only.  Every case decrypts with the secret keys and applies the reference test's own tolerance.
  * Run by tests/test_gpu_parity.py::test_compat_c_api_suite; exit status = number of failed cases.
  */
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -460,6 +461,84 @@ static void case_key_files(void) {
   free_trlwe_ks_key(priv2[0]); free_trlwe_ks_key(priv2[1]); free(priv2); free_tlwe_ks_key(ksk);
 }
 
+/* Re-entrancy (SURVEY 8(b) threading; the reference is re-entrant through thread-local FFT state, src/polynomial.c:269-352): several host threads
+ * run bootstraps, key switches and the compositions that need device temporaries AT THE SAME TIME on the SAME keys.  Every operation is
+ * deterministic in (key, input), so each thread must reproduce, bit for bit, what the main thread computed alone beforehand. */
+enum { TH = 4, TH_CT = 6, TH_LUTS = 2, TH_ROUNDS = 3 };
+typedef struct {
+  int id, bad;
+  TLWE *in, *big;                                  /* TH_CT inputs under lwe_key / extracted_key */
+  TLWE *want_pbs, *want_ks, *want_fdfb, *want_mv;  /* results of the single-threaded pass */
+  TRGSW want_cb;
+  TLWE_KS_Key ksk;
+  TRLWE tv, tv_fdfb, tv_mv;
+} ThreadJob;
+static int tlwe_arrays_differ(TLWE *a, TLWE *b, int count) {
+  int bad = 0;
+  for (int i = 0; i < count; i++) bad += !same_tlwe(a[i], b[i]);
+  return bad;
+}
+static void thread_ops(ThreadJob *j, TLWE *pbs, TLWE *ks, TLWE *fdfb, TLWE *mv, TRGSW cb) {
+  programmable_bootstrap_batch(pbs, j->tv, j->in, TH_CT, bk, 3, 0, 0);
+  tlwe_keyswitch_batch(ks, j->big, TH_CT, j->ksk);
+  full_domain_functional_bootstrap_batch(fdfb, j->tv_fdfb, j->in, TH_CT, bk, j->ksk, 3);
+  multivalue_bootstrap_CLOT21(mv, j->tv_mv, j->in[j->id % TH_CT], bk, 4, TH_LUTS);
+  circuit_bootstrap_2_batch(&cb, &j->in[(j->id + 1) % TH_CT], 1, wbk, wpriv, wpack);
+}
+static void *thread_main(void *arg) {
+  ThreadJob *j = (ThreadJob *)arg;
+  TLWE *pbs = tlwe_alloc_sample_array(TH_CT, N), *ks = tlwe_alloc_sample_array(TH_CT, n), *fdfb = tlwe_alloc_sample_array(TH_CT, N);
+  TLWE *mv = tlwe_alloc_sample_array(TH_LUTS, N);
+  TRGSW cb = trgsw_alloc_new_sample(wl, wBg, k, N);
+  for (int r = 0; r < TH_ROUNDS; r++) {
+    thread_ops(j, pbs, ks, fdfb, mv, cb);
+    j->bad += tlwe_arrays_differ(pbs, j->want_pbs, TH_CT) + tlwe_arrays_differ(ks, j->want_ks, TH_CT) + tlwe_arrays_differ(fdfb, j->want_fdfb, TH_CT) +
+              tlwe_arrays_differ(mv, j->want_mv, TH_LUTS);
+    for (int q = 0; q < 2 * wl; q++) j->bad += !same_trlwe(cb->samples[q], j->want_cb->samples[q]);
+    /* each thread draws from its own random stream: fresh samples must decrypt */
+    TLWE fresh = tlwe_new_sample(double2torus(0.125), lwe_key);
+    j->bad += tdist(tlwe_phase(fresh, lwe_key), double2torus(0.125)) >= (1ULL << 54);
+    free_tlwe(fresh);
+  }
+  free_trgsw(cb); free_tlwe_array(mv, TH_LUTS); free_tlwe_array(fdfb, TH_CT); free_tlwe_array(ks, TH_CT); free_tlwe_array(pbs, TH_CT);
+  return NULL;
+}
+static void case_threads(void) {
+  wide_setup();
+  TLWE_KS_Key ksk = tlwe_new_KS_key(lwe_key, extracted_key, ks_t, ks_bb);
+  Torus lut[4] = {int2torus(3, 4), int2torus(7, 4), int2torus(11, 4), int2torus(15, 4)}, lut8[8];
+  for (int i = 0; i < 8; i++) lut8[i] = int2torus((uint64_t)((3 * i + 1) & 7), 3);
+  TRLWE tv = trlwe_alloc_new_sample(k, N), tv_fdfb = trlwe_alloc_new_sample(k, N), tv_mv = trlwe_alloc_new_sample(k, N);
+  trlwe_torus_packing(tv, lut, 4);
+  trlwe_torus_packing_many_LUT(tv_fdfb, lut8, 4, 2);
+  trlwe_torus_packing_many_LUT(tv_mv, lut8, 4, TH_LUTS);
+  ThreadJob jobs[TH];
+  pthread_t th[TH];
+  for (int t = 0; t < TH; t++) {
+    ThreadJob *j = &jobs[t];
+    j->id = t; j->bad = 0; j->ksk = ksk; j->tv = tv; j->tv_fdfb = tv_fdfb; j->tv_mv = tv_mv;
+    j->in = tlwe_alloc_sample_array(TH_CT, n); j->big = tlwe_alloc_sample_array(TH_CT, N);
+    for (int i = 0; i < TH_CT; i++) {
+      tlwe_sample(j->in[i], double2torus(((i + t) % 4) / 8.), lwe_key);
+      tlwe_sample(j->big[i], double2torus(((i + 2 * t) % 8) / 8.), extracted_key);
+    }
+    j->want_pbs = tlwe_alloc_sample_array(TH_CT, N); j->want_ks = tlwe_alloc_sample_array(TH_CT, n);
+    j->want_fdfb = tlwe_alloc_sample_array(TH_CT, N); j->want_mv = tlwe_alloc_sample_array(TH_LUTS, N);
+    j->want_cb = trgsw_alloc_new_sample(wl, wBg, k, N);
+    thread_ops(j, j->want_pbs, j->want_ks, j->want_fdfb, j->want_mv, j->want_cb);
+    for (int i = 0; i < TH_CT; i++) WITHIN(1ULL << 58, lut[(i + t) % 4], tlwe_phase(j->want_pbs[i], extracted_key), "single-threaded pass");
+  }
+  for (int t = 0; t < TH; t++) CHECK(!pthread_create(&th[t], NULL, thread_main, &jobs[t]), "pthread_create");
+  for (int t = 0; t < TH; t++) {
+    pthread_join(th[t], NULL);
+    CHECK(jobs[t].bad == 0, "thread %d: %d results differ from the single-threaded pass", t, jobs[t].bad);
+    ThreadJob *j = &jobs[t];
+    free_trgsw(j->want_cb); free_tlwe_array(j->want_mv, TH_LUTS); free_tlwe_array(j->want_fdfb, TH_CT); free_tlwe_array(j->want_ks, TH_CT);
+    free_tlwe_array(j->want_pbs, TH_CT); free_tlwe_array(j->big, TH_CT); free_tlwe_array(j->in, TH_CT);
+  }
+  free_trlwe(tv); free_trlwe(tv_fdfb); free_trlwe(tv_mv); free_tlwe_ks_key(ksk);
+}
+
 int main(int argc, char **argv) {
   setvbuf(stdout, NULL, _IOLBF, 0);
   mosfhet_seed(0x4D4F5346);
@@ -476,7 +555,7 @@ int main(int argc, char **argv) {
     {"circuit_bootstrap", case_circuit_bootstrap},       {"unfolded", case_unfolded},
     {"fdfb_variants", case_fdfb_variants},               {"multivalue_phases", case_multivalue_phases},
     {"circuit_2+mux+trgsw", case_circuit_2_mux_trgsw},   {"radix_integer_add", case_radix_integer_add},
-    {"key_files", case_key_files},
+    {"key_files", case_key_files},                       {"threads", case_threads},
   };
   for (unsigned i = 0; i < sizeof(cases) / sizeof(cases[0]); i++) {
     if (argc > 1 && strcmp(argv[1], cases[i].name)) continue;

@@ -132,7 +132,7 @@ def test_compat_c_suite_compiles_and_links(native_lib, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     libdir = os.path.join(root, "mosfhet_amd")
     subprocess.check_call(["gcc", "-O1", "-std=gnu11", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
-                           os.path.join(root, "tests", "c", "compat_suite.c"), "-o", str(tmp_path / "compat_suite"),
+                           os.path.join(root, "tests", "c", "compat_suite.c"), "-o", str(tmp_path / "compat_suite"), "-pthread",
                            "-L" + libdir, "-lmosfhet_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
 
 
