@@ -143,3 +143,52 @@ def test_bootstrap_phases_match_reference(oracle, case):
         ph_a = oracle.trlwe_phase(wo, rlwe_s)
         ph_b = oracle.trlwe_phase(g["%s_wo_extract_%s" % (case, be)], rlwe_s)
         assert oracle.torus_dist(ph_a, ph_b).max() < tol
+
+
+def test_callers_match_reference_golden(oracle):
+    """The callers either side of the bootstrap against outputs of the REAL reference (both back-ends) stored in callers.npz
+    (tests/golden/make_callers_golden.py; inputs and keys replayed from the seeds in tests/golden/callers_setup.py): full-domain functional
+    bootstrap, multi-value bootstrap, FFT-based TRLWE key switch, automorphisms, Galois-automorphism bootstrap, the private and packing key
+    switches, the unfolded bootstrap.  Integer paths bit-exact; FFT paths within the short-key ciphertext tolerances of
+    tests/test_oracle_vs_reference.py, and by phase against the plaintext."""
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import callers_setup as S
+    g = load("callers.npz")
+    O = oracle
+    A, GA, K, U = S.fdfb_multivalue(O), S.galois(O), S.key_switches(O), S.unfolded(O)
+    assert (np.array([A["c_mv"][0], GA["cts"][3][0], K["cs"][1][0], U["cts"][3][0]], dtype=np.uint64) == g["fp"]).all()   # streams replayed exactly
+    N, l, Bg = S.N, S.L, S.BG
+    bk_dft = O.bk_to_dft(A["bk"], 1, l)
+    fdfb = np.stack([O.full_domain_functional_bootstrap(A["tv"], c, bk_dft, A["ksk"], l, Bg, A["t"], A["bb"], 3) for c in A["cts"]])
+    mv = O.multivalue_bootstrap_CLOT21(A["tv16"], A["c_mv"], bk_dft, l, Bg, 2, 8)
+    out_s = A["rlwe_s"].reshape(-1)
+    for m in range(8):
+        assert O.torus_dist(O.tlwe_phase(fdfb[m], out_s), A["lut"][m]) < 2.0 ** 58
+    ks_mine = O.trlwe_keyswitch(GA["c_ks"], O.ks_to_dft(GA["ks"]), 4, 8)
+    ak_dft = O.ks_to_dft(GA["ak"])
+    aut = np.stack([O.trlwe_eval_automorphism(GA["c_aut"], gen, ak_dft[(gen - 1) // 2], l, Bg) for gen in GA["gens"]])
+    ga_dft = O.bk_to_dft(GA["bk"], 1, l)
+    ga = np.stack([O.functional_bootstrap_ga(GA["tv"], c, ga_dft, ak_dft, l, Bg, 4) for c in GA["cts"]])
+    for m in range(4):
+        assert O.torus_dist(O.tlwe_phase(ga[m], GA["s"]), GA["lut"][m]) < 2.0 ** 58
+    priv = O.trlwe_priv_keyswitch_2(K["ct"], O.ks_to_dft(K["ks0"]), O.ks_to_dft(K["ks1"]), 10, 3)
+    pack = np.stack([O.trlwe_packing1_keyswitch(c, K["kskb"], 3) for c in K["cs"]])
+    unf = np.stack([O.functional_bootstrap_unfolded(U["tv"], c, U["su"], l, Bg, 4, U["unfolding"]) for c in U["cts"]])
+    seen = 0
+    for be in ("avx512", "ffnt"):
+        if "fdfb_" + be not in g:
+            continue
+        seen += 1
+        assert O.torus_dist(fdfb, g["fdfb_" + be]).max() < 2.0 ** 40, be
+        assert O.torus_dist(mv, g["multivalue_" + be]).max() < 2.0 ** 38, be
+        assert O.torus_dist(ks_mine, g["trlwe_keyswitch_" + be]).max() < 2.0 ** 34, be
+        assert O.torus_dist(aut, g["automorphism_" + be]).max() < 2.0 ** 34, be
+        assert O.torus_dist(ga, g["ga_" + be]).max() < 2.0 ** 42, be
+        assert O.torus_dist(priv, g["priv_keyswitch_2_" + be]).max() < 2.0 ** 36, be
+        assert (pack == g["packing1_" + be]).all(), be                      # table lookup: integer, bit-exact
+        for m in range(4):
+            ph_m, ph_r = O.tlwe_phase(unf[m], U["s"]), O.tlwe_phase(np.ascontiguousarray(g["unfolded_" + be][m]), U["s"])
+            assert O.torus_dist(ph_m, U["lut"][m]) < 2.0 ** 58 and O.torus_dist(ph_r, U["lut"][m]) < 2.0 ** 58
+            assert O.torus_dist(ph_m, ph_r) < 2.0 ** 50, (be, m)
+    assert seen >= 1
