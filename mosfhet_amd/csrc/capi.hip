@@ -211,7 +211,7 @@ extern "C" int mosfhet_hip_ctx_sync(mosfhet_hip_ctx_t ctx, void *stream) {
 static int check_params(const char *who, int k, int N, int l, int Bg_bit) {
   if (k != 1) return fail(MOSFHET_HIP_EINVAL, "%s: only k = 1 is supported (got %d)", who, k);
   if (!ring_ok(N)) return fail(MOSFHET_HIP_EINVAL, "%s: ring degree N = %d not supported (1024, 2048, 4096)", who, N);
-  if (l < 1 || Bg_bit < 1 || l * Bg_bit >= 64) return fail(MOSFHET_HIP_EINVAL, "%s: bad gadget l=%d Bg_bit=%d", who, l, Bg_bit);
+  if (l < 1 || Bg_bit < 1 || Bg_bit > 31 || l * Bg_bit >= 64) return fail(MOSFHET_HIP_EINVAL, "%s: bad gadget l=%d Bg_bit=%d (Bg_bit <= 31, l*Bg_bit < 64)", who, l, Bg_bit);
   if (l != 1 && l != 2 && l != 3 && l != 4) return fail(MOSFHET_HIP_EINVAL, "%s: l = %d not instantiated (1..4)", who, l);
   return MOSFHET_HIP_OK;
 }

@@ -50,7 +50,7 @@ constexpr int KS_W = 32;         // output words per wavefront slice
 constexpr int KS_NW = 4;         // wavefronts (x 64 ciphertexts) per workgroup
 constexpr int KS_LDS_BYTES = 16384;
 
-constexpr int KS_PF_MAX = 8;     // upper bound of staged row elements a thread prefetches per stage
+constexpr int KS_PF_MAX = 16;    // upper bound of staged row elements a thread prefetches per stage
 
 // inT: [n_in + 1][Bp] (word i of ciphertext c at inT[i * Bp + c]; Bp a multiple of 64 * NW, padding zero-filled)
 // outT: [row][Bp]; rows have `row` words and the input's b word is added into word `b_word`
@@ -234,15 +234,26 @@ inline hipError_t launch_tlwe_keyswitch_nw(const uint64_t *ksk, uint64_t *out, s
   static const int lds_env = getenv("MOSFHET_KS_LDS_BYTES") ? atoi(getenv("MOSFHET_KS_LDS_BYTES")) : 0;
   const int lds_budget = lds_env ? lds_env : (cands >= 7 ? 4352 : KS_LDS_BYTES);
   int JB = lds_budget / ((cands + 1) * (W + 2) * 8);          // per LDS buffer
-  const int pf_cap = KS_PF_MAX * (TILE / W) / cands;             // rows a stage can prefetch through registers
+  // rows a stage can prefetch through registers: 8 per thread, 16 for the widest digit sets (base_bit 8 with a 256-ciphertext tile, where
+  // one digit position alone has more candidate rows than 8 per thread cover)
+  const int pf_regs = cands > 8 * (TILE / W) ? KS_PF_MAX : 8;
+  const int pf_cap = pf_regs * (TILE / W) / cands;
   if (JB > pf_cap) JB = pf_cap;
   if (JB < 1) JB = 1;
   if (JB > t) JB = t;
-  if (cands > KS_PF_MAX * (TILE / W)) return hipErrorInvalidValue;  // base_bit too large for the staging registers
+  if (cands > KS_PF_MAX * (TILE / W)) return hipErrorInvalidValue;  // base_bit too large for the staging registers (cannot happen for base_bit <= 8)
   const size_t lds = 2 * (size_t)JB * (cands + 1) * (W + 2) * 8;
   const int pf = (JB * cands + TILE / W - 1) / (TILE / W);
   const dim3 grid(slices, ct_blocks, split);
-#define KS_LAUNCH(PF) hipLaunchKernelGGL((tlwe_keyswitch_kernel<W, NW, PF>), grid, dim3(TILE), lds, s, ksk, ws.inT, ws.outT, Bp, n_in, row, b_word, t, base_bit, JB, i_per_split)
+  // stages of base_bit 7 / 8 need 70 / 139 KiB of the CU's 160 KiB: beyond the 64 KiB a kernel gets without asking
+#define KS_LAUNCH(PF)                                                                                                                          \
+  do {                                                                                                                                         \
+    if (lds > 65536 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&tlwe_keyswitch_kernel<W, NW, PF>),                            \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)                          \
+      return e;                                                                                                                                \
+    hipLaunchKernelGGL((tlwe_keyswitch_kernel<W, NW, PF>), grid, dim3(TILE), lds, s, ksk, ws.inT, ws.outT, Bp, n_in, row, b_word, t, base_bit, JB, \
+                       i_per_split);                                                                                                           \
+  } while (0)
   switch (pf) {
     case 1: KS_LAUNCH(1); break;
     case 2: KS_LAUNCH(2); break;
@@ -251,7 +262,11 @@ inline hipError_t launch_tlwe_keyswitch_nw(const uint64_t *ksk, uint64_t *out, s
     case 5: KS_LAUNCH(5); break;
     case 6: KS_LAUNCH(6); break;
     case 7: KS_LAUNCH(7); break;
-    default: KS_LAUNCH(8); break;
+    case 8: KS_LAUNCH(8); break;
+    case 9: case 10: KS_LAUNCH(10); break;
+    case 11: case 12: KS_LAUNCH(12); break;
+    case 13: case 14: KS_LAUNCH(14); break;
+    default: KS_LAUNCH(16); break;
   }
 #undef KS_LAUNCH
   // outT[row][Bp] -> out[count][row]
