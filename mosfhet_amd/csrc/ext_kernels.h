@@ -125,9 +125,9 @@ __global__ __launch_bounds__(256) void mv_phase2_kernel(const uint64_t *__restri
   extern __shared__ uint64_t tmp[];  // [2][N]
   const int tid = threadIdx.x;
   const uint64_t *r = rot + (size_t)blockIdx.x * (torus_base + 1) * 2 * N;
-  uint64_t acc[8], acc_b = 0;        // a words x = tid + 256 k
+  uint64_t acc[16], acc_b = 0;       // a words x = tid + 256 k (N <= 4096)
 #pragma unroll
-  for (int k = 0; k < 8; k++) acc[k] = 0;
+  for (int k = 0; k < 16; k++) acc[k] = 0;
   for (int j = 0; j < log_torus_base; j++) {
     for (int pos = tid; pos < 2 * N; pos += 256) {
       uint64_t v = 0;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void mv_phase2_kernel(const uint64_t *__restri
       const bool add = e < amount / 2;
       const int idx = add ? e : N - 1 - (e - amount / 2);
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
+      for (int k = 0; k < 16; k++) {
         const int x = tid + 256 * k;
         if (x < N) {
           const uint64_t v = x <= idx ? tmp[idx - x] : (uint64_t)0 - tmp[N + idx - x];
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void mv_phase2_kernel(const uint64_t *__restri
   }
   uint64_t *o = out + (size_t)blockIdx.x * (N + 1);
 #pragma unroll
-  for (int k = 0; k < 8; k++)
+  for (int k = 0; k < 16; k++)
     if (tid + 256 * k < N) o[tid + 256 * k] = acc[k];
   if (tid == 0) o[N] = acc_b;
 }
