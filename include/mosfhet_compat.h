@@ -123,7 +123,7 @@ void free_trgsw(void *p);
 void trgsw_monomial_sample(TRGSW out, int64_t m, int e, TRGSW_Key key);   /* :152-168 */
 
 /* ---- bootstrap (src/bootstrap.c)  -> GPU ---- */
-Bootstrap_Key new_bootstrap_key(TRGSW_Key out_key, TLWE_Key in_key, int unfolding);   /* :3-48 (unfolding 1..8; n divisible by it) */
+Bootstrap_Key new_bootstrap_key(TRGSW_Key out_key, TLWE_Key in_key, int unfolding);   /* :3-48 (unfolding 1, 2, 4, 8; n divisible by it) */
 void free_bootstrap_key(Bootstrap_Key key);                                            /* :51-61 */
 void blind_rotate(TRLWE tv, Torus *a, TRGSW_DFT *s, int size);                         /* :107-122 */
 void functional_bootstrap_wo_extract(TRLWE out, TRLWE tv, TLWE in, Bootstrap_Key key, int torus_base);  /* :192-198 */

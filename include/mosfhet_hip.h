@@ -232,7 +232,8 @@ int mosfhet_hip_full_domain_functional_bootstrap_CLOT21_batch(mosfhet_hip_ctx_t 
                                                               uint64_t *d_out /*[count][N+1]*/, const uint64_t *d_tv, const uint64_t *d_in, int count,
                                                               int precision, int variant, void *stream);
 
-/* Bootstrap key with blind-rotate unfolding u in 2..8 (new_bootstrap_key(.., unfolding), src/bootstrap.c:23-48): h_su =
+/* Bootstrap key with blind-rotate unfolding u = 2, 4 or 8 (new_bootstrap_key(.., unfolding), src/bootstrap.c:23-48; the reference's group
+ * stride 2^u / u is an integer quotient, :34-45, so other factors make overlapping groups there and are rejected here): h_su =
  * Torus[n 2^u / u][2l][2][N], torus domain; n divisible by u.  The handle works with functional_bootstrap[_wo_extract]_batch and the
  * compositions built on them (they take the blind_rotate_unfolded branch, src/bootstrap.c:124-149,196-197). */
 int mosfhet_hip_bsk_unfolded_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t *out, const uint64_t *h_su, int n, int N, int l, int Bg_bit,

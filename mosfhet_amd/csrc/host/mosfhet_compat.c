@@ -603,8 +603,9 @@ void mosfhet_gen_bootstrap_key_unfolded_flat(Torus *out, TRGSW_Key out_key, TLWE
 
 Bootstrap_Key new_bootstrap_key(TRGSW_Key out_key, TLWE_Key in_key, int unfolding) {
   const int l = out_key->l, k = out_key->trlwe_key->k, N = out_key->trlwe_key->s[0]->N, n = in_key->n;
-  if (unfolding < 1 || unfolding > 8 || n % unfolding || (unfolding > 1 && k != 1)) {
-    fprintf(stderr, "mosfhet_amd: new_bootstrap_key: unfolding = %d needs 1 <= unfolding <= 8, n divisible by it (test/tests.c:34), k = 1\n", unfolding);
+  if ((unfolding != 1 && unfolding != 2 && unfolding != 4 && unfolding != 8) || n % unfolding || (unfolding > 1 && k != 1)) {
+    fprintf(stderr, "mosfhet_amd: new_bootstrap_key: unfolding = %d must be 1, 2, 4 or 8 with n divisible by it (test/tests.c:34) and k = 1; the "
+                    "reference's key layout (src/bootstrap.c:34-45: group stride 2^u / u as an integer) is only consistent for powers of two\n", unfolding);
     abort();
   }
   Bootstrap_Key res = (Bootstrap_Key)xmalloc(sizeof(*res));
