@@ -426,7 +426,7 @@ extern "C" int mosfhet_hip_blind_rotate_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip
 
 extern "C" int mosfhet_hip_external_product_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, int key_index, uint64_t *d_out,
                                                   const uint64_t *d_in, int count, void *stream) {
-  if (!ctx || !bsk || !d_out || !d_in || count < 0 || key_index < 0 || key_index >= bsk->n)
+  if (!ctx || !bsk || (count > 0 && !d_out) || (count > 0 && !d_in) || count < 0 || key_index < 0 || key_index >= bsk->n)
     return fail(MOSFHET_HIP_EINVAL, "external_product: bad argument");
   if (bsk->unfolding > 1) return fail(MOSFHET_HIP_EINVAL, "external_product: an unfolded key has no DFT entries");
   if (count == 0) return MOSFHET_HIP_OK;
@@ -447,7 +447,7 @@ extern "C" int mosfhet_hip_external_product_batch(mosfhet_hip_ctx_t ctx, mosfhet
 
 // ---- polynomial-level entry points ----
 extern "C" int mosfhet_hip_torus_to_dft_batch(mosfhet_hip_ctx_t ctx, double *d_out, const uint64_t *d_in, int N, int count, void *stream) {
-  if (!ctx || !d_out || !d_in || count < 0) return fail(MOSFHET_HIP_EINVAL, "torus_to_dft: bad argument");
+  if (!ctx || (count > 0 && !d_out) || (count > 0 && !d_in) || count < 0) return fail(MOSFHET_HIP_EINVAL, "torus_to_dft: bad argument");
   if (!ring_ok(N)) return fail(MOSFHET_HIP_EINVAL, "torus_to_dft: N = %d not supported (1024, 2048, 4096)", N);
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
@@ -457,7 +457,7 @@ extern "C" int mosfhet_hip_torus_to_dft_batch(mosfhet_hip_ctx_t ctx, double *d_o
 }
 
 extern "C" int mosfhet_hip_dft_to_torus_batch(mosfhet_hip_ctx_t ctx, uint64_t *d_out, const double *d_in, int N, int count, void *stream) {
-  if (!ctx || !d_out || !d_in || count < 0) return fail(MOSFHET_HIP_EINVAL, "dft_to_torus: bad argument");
+  if (!ctx || (count > 0 && !d_out) || (count > 0 && !d_in) || count < 0) return fail(MOSFHET_HIP_EINVAL, "dft_to_torus: bad argument");
   if (!ring_ok(N)) return fail(MOSFHET_HIP_EINVAL, "dft_to_torus: N = %d not supported (1024, 2048, 4096)", N);
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
@@ -468,7 +468,7 @@ extern "C" int mosfhet_hip_dft_to_torus_batch(mosfhet_hip_ctx_t ctx, uint64_t *d
 
 extern "C" int mosfhet_hip_dft_mul_batch(mosfhet_hip_ctx_t ctx, double *d_out, const double *d_a, const double *d_b, int N,
                                          int count, int addto, void *stream) {
-  if (!ctx || !d_out || !d_a || !d_b || count < 0 || N < 2) return fail(MOSFHET_HIP_EINVAL, "dft_mul: bad argument");
+  if (!ctx || (count > 0 && !d_out) || (count > 0 && !d_a) || (count > 0 && !d_b) || count < 0 || N < 2) return fail(MOSFHET_HIP_EINVAL, "dft_mul: bad argument");
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
   const size_t total = (size_t)count * (N / 2);
@@ -517,7 +517,7 @@ extern "C" int mosfhet_hip_tlwe_keyswitch_batch(mosfhet_hip_ctx_t ctx, mosfhet_h
 // ---- glue entry points ----
 extern "C" int mosfhet_hip_trlwe_extract_tlwe_batch(mosfhet_hip_ctx_t ctx, uint64_t *d_out, const uint64_t *d_in, int N, int idx, int count,
                                                     void *stream) {
-  if (!ctx || !d_out || !d_in || N < 1 || idx < 0 || idx >= N || count < 0) return fail(MOSFHET_HIP_EINVAL, "trlwe_extract: bad argument");
+  if (!ctx || (count > 0 && !d_out) || (count > 0 && !d_in) || N < 1 || idx < 0 || idx >= N || count < 0) return fail(MOSFHET_HIP_EINVAL, "trlwe_extract: bad argument");
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
   hipLaunchKernelGGL(trlwe_extract_kernel, dim3((N + 255) / 256, count), dim3(256), 0, pick(ctx, stream), d_out, (size_t)N + 1, d_in,
@@ -527,7 +527,7 @@ extern "C" int mosfhet_hip_trlwe_extract_tlwe_batch(mosfhet_hip_ctx_t ctx, uint6
 }
 
 extern "C" int mosfhet_hip_tlwe_addto_batch(mosfhet_hip_ctx_t ctx, uint64_t *d_out, const uint64_t *d_in, int n, int count, void *stream) {
-  if (!ctx || !d_out || !d_in || n < 0 || count < 0) return fail(MOSFHET_HIP_EINVAL, "tlwe_addto: bad argument");
+  if (!ctx || (count > 0 && !d_out) || (count > 0 && !d_in) || n < 0 || count < 0) return fail(MOSFHET_HIP_EINVAL, "tlwe_addto: bad argument");
   const size_t words = (size_t)count * (n + 1);
   if (!words) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
@@ -541,7 +541,7 @@ static int bsk_scratch(mosfhet_hip_bsk_t bsk, size_t words, uint64_t **out) { re
 extern "C" int mosfhet_hip_full_domain_functional_bootstrap_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, mosfhet_hip_ksk_t ksk,
                                                                   uint64_t *d_out, const uint64_t *d_tv, int tv_count,
                                                                   const uint64_t *d_in, int count, int precision, void *stream) {
-  if (!ctx || !bsk || !ksk || !d_out || !d_tv || !d_in || count < 0) return fail(MOSFHET_HIP_EINVAL, "fdfb: bad argument");
+  if (!ctx || !bsk || !ksk || (count > 0 && !d_out) || (count > 0 && !d_tv) || (count > 0 && !d_in) || count < 0) return fail(MOSFHET_HIP_EINVAL, "fdfb: bad argument");
   if (precision < 1 || precision > 30) return fail(MOSFHET_HIP_EINVAL, "fdfb: precision %d", precision);
   if (ksk->n_in != bsk->k * bsk->N || ksk->n_out != bsk->n)
     return fail(MOSFHET_HIP_EINVAL, "fdfb: key-switch key is %d -> %d, expected %d -> %d", ksk->n_in, ksk->n_out, bsk->k * bsk->N, bsk->n);
@@ -567,7 +567,7 @@ extern "C" int mosfhet_hip_full_domain_functional_bootstrap_batch(mosfhet_hip_ct
 extern "C" int mosfhet_hip_multivalue_bootstrap_CLOT21_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_out,
                                                              const uint64_t *d_tv, int tv_count, const uint64_t *d_in, int count,
                                                              int torus_base, int n_luts, void *stream) {
-  if (!ctx || !bsk || !d_out || !d_tv || !d_in || count < 0 || torus_base < 1 || n_luts < 1)
+  if (!ctx || !bsk || (count > 0 && !d_out) || (count > 0 && !d_tv) || (count > 0 && !d_in) || count < 0 || torus_base < 1 || n_luts < 1)
     return fail(MOSFHET_HIP_EINVAL, "multivalue_CLOT21: bad argument");
   const int N = bsk->N;
   if (N % (n_luts * torus_base)) return fail(MOSFHET_HIP_EINVAL, "multivalue_CLOT21: N not divisible by n_luts * torus_base");
@@ -641,7 +641,7 @@ static int launch_ga_f(int l, int Bg_bit, const GaParams &g, int count, hipStrea
 
 extern "C" int mosfhet_hip_trlwe_eval_automorphism_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_gak_t gak, uint64_t *d_out,
                                                          const uint64_t *d_in, int gen, int count, void *stream) {
-  if (!ctx || !gak || !d_out || !d_in || count < 0) return fail(MOSFHET_HIP_EINVAL, "eval_automorphism: bad argument");
+  if (!ctx || !gak || (count > 0 && !d_out) || (count > 0 && !d_in) || count < 0) return fail(MOSFHET_HIP_EINVAL, "eval_automorphism: bad argument");
   if (gen < 1 || gen >= 2 * gak->N || !(gen & 1)) return fail(MOSFHET_HIP_EINVAL, "eval_automorphism: generator %d must be odd and < 2N", gen);
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
@@ -662,7 +662,7 @@ extern "C" int mosfhet_hip_trlwe_eval_automorphism_batch(mosfhet_hip_ctx_t ctx, 
 extern "C" int mosfhet_hip_functional_bootstrap_ga_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, mosfhet_hip_gak_t gak,
                                                          uint64_t *d_out, const uint64_t *d_tv, int tv_count, const uint64_t *d_in,
                                                          int count, int torus_base, int extract, void *stream) {
-  if (!ctx || !bsk || !gak || !d_out || !d_tv || !d_in || count < 0 || torus_base < 1)
+  if (!ctx || !bsk || !gak || (count > 0 && !d_out) || (count > 0 && !d_tv) || (count > 0 && !d_in) || count < 0 || torus_base < 1)
     return fail(MOSFHET_HIP_EINVAL, "functional_bootstrap_ga: bad argument");
   if (tv_count != 1 && tv_count != count) return fail(MOSFHET_HIP_EINVAL, "functional_bootstrap_ga: tv_count must be 1 or count");
   if (bsk->unfolding > 1) return fail(MOSFHET_HIP_EINVAL, "functional_bootstrap_ga: needs a key without unfolding");
@@ -700,7 +700,7 @@ static int launch_fft_ks(mosfhet_hip_ctx_t ctx, mosfhet_hip_gak_t tks, const d2 
 
 extern "C" int mosfhet_hip_trlwe_keyswitch_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_gak_t tks, int entry, uint64_t *d_out, const uint64_t *d_in,
                                                  int count, void *stream) {
-  if (!ctx || !tks || !d_out || !d_in || count < 0 || entry < 0 || entry >= tks->entries) return fail(MOSFHET_HIP_EINVAL, "trlwe_keyswitch: bad argument");
+  if (!ctx || !tks || (count > 0 && !d_out) || (count > 0 && !d_in) || count < 0 || entry < 0 || entry >= tks->entries) return fail(MOSFHET_HIP_EINVAL, "trlwe_keyswitch: bad argument");
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
   const d2 *k = tks->d_ak + (size_t)entry * tks->t * 2 * (tks->N / 2);
@@ -709,7 +709,7 @@ extern "C" int mosfhet_hip_trlwe_keyswitch_batch(mosfhet_hip_ctx_t ctx, mosfhet_
 
 extern "C" int mosfhet_hip_trlwe_priv_keyswitch_2_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_gak_t tks, uint64_t *d_out, const uint64_t *d_in,
                                                         int count, void *stream) {
-  if (!ctx || !tks || !d_out || !d_in || count < 0 || tks->entries != 2) return fail(MOSFHET_HIP_EINVAL, "priv_keyswitch_2: needs a 2-entry key set");
+  if (!ctx || !tks || (count > 0 && !d_out) || (count > 0 && !d_in) || count < 0 || tks->entries != 2) return fail(MOSFHET_HIP_EINVAL, "priv_keyswitch_2: needs a 2-entry key set");
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
   const size_t esz = (size_t)tks->t * 2 * (tks->N / 2);
@@ -727,7 +727,7 @@ extern "C" int mosfhet_hip_packing1_ksk_create(mosfhet_hip_ctx_t ctx, mosfhet_hi
 
 extern "C" int mosfhet_hip_trlwe_packing1_keyswitch_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t ksk, uint64_t *d_out, const uint64_t *d_in,
                                                           int count, void *stream) {
-  if (!ctx || !ksk || !d_out || !d_in || count < 0) return fail(MOSFHET_HIP_EINVAL, "packing1_keyswitch: bad argument");
+  if (!ctx || !ksk || (count > 0 && !d_out) || (count > 0 && !d_in) || count < 0) return fail(MOSFHET_HIP_EINVAL, "packing1_keyswitch: bad argument");
   if (ksk->b_word == ksk->n_out) return fail(MOSFHET_HIP_EINVAL, "packing1_keyswitch: this key is an LWE -> LWE key");
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
@@ -747,7 +747,7 @@ __global__ void circuit_bootstrap_lut_kernel(uint64_t *__restrict__ tv, int N, i
 
 extern "C" int mosfhet_hip_circuit_bootstrap_3_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, mosfhet_hip_gak_t kska, mosfhet_hip_ksk_t kskb,
                                                      uint64_t *d_out, const uint64_t *d_in, int count, void *stream) {
-  if (!ctx || !bsk || !kska || !kskb || !d_out || !d_in || count < 0) return fail(MOSFHET_HIP_EINVAL, "circuit_bootstrap_3: bad argument");
+  if (!ctx || !bsk || !kska || !kskb || (count > 0 && !d_out) || (count > 0 && !d_in) || count < 0) return fail(MOSFHET_HIP_EINVAL, "circuit_bootstrap_3: bad argument");
   const int N = bsk->N, l = bsk->l;
   if (kska->entries != 2 || kska->N != N) return fail(MOSFHET_HIP_EINVAL, "circuit_bootstrap_3: kska must be the 2-entry private key-switch set for N");
   if (kskb->row != 2 * N || kskb->b_word != N || kskb->n_in != N) return fail(MOSFHET_HIP_EINVAL, "circuit_bootstrap_3: kskb must be a packing key N -> TRLWE(N)");
