@@ -539,6 +539,45 @@ static void case_threads(void) {
   free_trlwe(tv); free_trlwe(tv_fdfb); free_trlwe(tv_mv); free_tlwe_ks_key(ksk);
 }
 
+/* the reference's default parameter set SET_2 (test/tests.c:43-45: N = 2048, l = 1, Bg = 2^23) and its largest, SET_3 (:47-49: N = 4096, l = 1,
+ * Bg = 2^22), with a shortened LWE key: bootstraps, the batch entry, the key switch back and the full-domain bootstrap on those rings */
+static void case_other_rings(void) {
+  static const struct { int N, Bg_bit; double sigma; } sets[2] = {{2048, 23, 2.2148688116005568e-16}, {4096, 22, 2.2148688116005568e-16}};
+  for (int q = 0; q < 2; q++) {
+    const int N2 = sets[q].N, l2 = 1, Bg2 = sets[q].Bg_bit, n2 = 64;
+    TLWE_Key lk = tlwe_new_binary_key(n2, 1.0e-7);
+    TRLWE_Key rk = trlwe_new_binary_key(N2, 1, sets[q].sigma);
+    TLWE_Key xk = tlwe_alloc_key(N2, rk->sigma);
+    trlwe_extract_tlwe_key(xk, rk);
+    TRGSW_Key gk = trgsw_new_key(rk, l2, Bg2);
+    Bootstrap_Key b2 = new_bootstrap_key(gk, lk, 1);
+    TLWE_KS_Key ks2 = tlwe_new_KS_key(lk, xk, 5, 3);
+    Torus lut[4] = {int2torus(1, 4), int2torus(5, 4), int2torus(9, 4), int2torus(13, 4)}, lut8[8];
+    for (int i = 0; i < 8; i++) lut8[i] = int2torus((uint64_t)((3 * i + 1) & 7), 3);
+    TRLWE tv = trlwe_alloc_new_sample(1, N2), tv8 = trlwe_alloc_new_sample(1, N2);
+    trlwe_torus_packing(tv, lut, 4);
+    trlwe_torus_packing_many_LUT(tv8, lut8, 4, 2);
+    enum { COUNT = 9 };
+    TLWE *in = tlwe_alloc_sample_array(COUNT, n2), *out = tlwe_alloc_sample_array(COUNT, N2), *back = tlwe_alloc_sample_array(COUNT, n2);
+    for (int i = 0; i < COUNT; i++) tlwe_sample(in[i], double2torus((i % 4) / 8.), lk);
+    programmable_bootstrap_batch(out, tv, in, COUNT, b2, 3, 0, 0);
+    for (int i = 0; i < COUNT; i++) WITHIN(1ULL << 58, lut[i % 4], tlwe_phase(out[i], xk), "programmable_bootstrap_batch on the larger rings");
+    TLWE one = tlwe_alloc_sample(N2);
+    functional_bootstrap(one, tv, in[3], b2, 4);
+    CHECK(same_tlwe(one, out[3]), "N = %d: functional_bootstrap differs from the programmable batch entry", N2);
+    tlwe_keyswitch_batch(back, out, COUNT, ks2);
+    for (int i = 0; i < COUNT; i++) WITHIN(1ULL << 59, lut[i % 4], tlwe_phase(back[i], lk), "key switch back from the larger rings");
+    for (int m = 0; m < 8; m++) {
+      TLWE c = tlwe_new_sample(int2torus((uint64_t)m, 3), lk);
+      full_domain_functional_bootstrap(one, tv8, c, b2, ks2, 3);
+      WITHIN(1ULL << 58, lut8[m], tlwe_phase(one, xk), "full_domain_functional_bootstrap on the larger rings");
+      free_tlwe(c);
+    }
+    free_tlwe(one); free_tlwe_array(in, COUNT); free_tlwe_array(out, COUNT); free_tlwe_array(back, COUNT); free_trlwe(tv); free_trlwe(tv8);
+    free_tlwe_ks_key(ks2); free_bootstrap_key(b2); free_trgsw_key(gk); free_tlwe_key(xk); free_trlwe_key(rk); free_tlwe_key(lk);
+  }
+}
+
 int main(int argc, char **argv) {
   setvbuf(stdout, NULL, _IOLBF, 0);
   mosfhet_seed(0x4D4F5346);
@@ -556,6 +595,7 @@ int main(int argc, char **argv) {
     {"fdfb_variants", case_fdfb_variants},               {"multivalue_phases", case_multivalue_phases},
     {"circuit_2+mux+trgsw", case_circuit_2_mux_trgsw},   {"radix_integer_add", case_radix_integer_add},
     {"key_files", case_key_files},                       {"threads", case_threads},
+    {"other_rings", case_other_rings},
   };
   for (unsigned i = 0; i < sizeof(cases) / sizeof(cases[0]); i++) {
     if (argc > 1 && strcmp(argv[1], cases[i].name)) continue;
