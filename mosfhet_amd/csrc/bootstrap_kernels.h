@@ -286,13 +286,13 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
     fft.inverse2(o_re[0], o_im[0], o_re[1], o_im[1], xch, t);
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-      al[m] += round_mod_2_64(o_re[0][m], scale);
-      ah[m] += round_mod_2_64(o_im[0][m], scale);
+      al[m] = add_rounded(al[m], o_re[0][m], scale);
+      ah[m] = add_rounded(ah[m], o_im[0][m], scale);
     }
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-      acc1[m * T + t] += round_mod_2_64(o_re[1][m], scale);
-      acc1[M + m * T + t] += round_mod_2_64(o_im[1][m], scale);
+      acc1[m * T + t] = add_rounded(acc1[m * T + t], o_re[1][m], scale);
+      acc1[M + m * T + t] = add_rounded(acc1[M + m * T + t], o_im[1][m], scale);
     }
     F::sync();
   }
@@ -406,8 +406,8 @@ __global__ __launch_bounds__(64 * 2 * L) void pbs_team_kernel(PbsParams p) {
       fft.inverse(o_re, o_im, xinv[w], t);
 #pragma unroll
       for (int m = 0; m < 8; m++) {
-        acc[w][m * T + t] += round_mod_2_64(o_re[m], scale);
-        acc[w][M + m * T + t] += round_mod_2_64(o_im[m], scale);
+        acc[w][m * T + t] = add_rounded(acc[w][m * T + t], o_re[m], scale);
+        acc[w][M + m * T + t] = add_rounded(acc[w][M + m * T + t], o_im[m], scale);
       }
     }
     __syncthreads();

@@ -613,6 +613,24 @@ __device__ __forceinline__ uint64_t round_mod_2_64(double v, const RoundCtx &rc)
   return ((uint64_t)hi << 32) | (uint64_t)(uint32_t)c;
 }
 
+// acc + round_mod_2_64(v) with the 64-bit sum spelled as two 32-bit halves and an explicit carry: the rounded value exists as two
+// unrelated 32-bit registers (low words of A and C), and a 64-bit add would first have to move them into a register pair
+__device__ __forceinline__ uint64_t add_rounded(uint64_t acc, double v, const RoundCtx &rc) {
+  double f = v * rc.scale;
+  f = f - __builtin_rint(f);
+  const double A = __builtin_fma(f, rc.two32, rc.magic);
+  const double B = A - rc.magic;
+  const double q = __builtin_fma(f, rc.two32, -B);
+  const double C = __builtin_fma(q, rc.two32, rc.magic);
+  const uint64_t a = (uint64_t)__double_as_longlong(A), c = (uint64_t)__double_as_longlong(C);
+  const uint32_t c_lo = (uint32_t)c;
+  const uint32_t lo = (uint32_t)acc + c_lo;
+  const uint32_t carry = lo < c_lo ? 1u : 0u;
+  const uint32_t borrow = (uint32_t)(int)__builtin_amdgcn_sbfe((uint32_t)(c >> 32), 0u, 1u);   // 0 or 0xffffffff: -(bit 32 of C), one v_bfe_i32
+  const uint32_t hi = (uint32_t)(acc >> 32) + (uint32_t)a + borrow + carry;
+  return ((uint64_t)hi << 32) | (uint64_t)lo;
+}
+
 // (double)(int64_t)x, correctly rounded (matches the C cast used by the reference and the oracle)
 __device__ __forceinline__ double torus_to_double(uint64_t x) { return (double)(int64_t)x; }
 
