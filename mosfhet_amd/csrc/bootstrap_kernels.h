@@ -78,6 +78,11 @@ __device__ __forceinline__ uint64_t rot_coeff(const uint64_t *poly, int i, int a
 //   mode SPLIT  (Bg compile-time, L*Bg  > 32, at most 16 bits of digits reach below bit 32): the high dword per
 //               coefficient plus one shared 32-bit word with the low-level digits of both coefficients;
 //   mode WIDE   (run-time Bg or anything else): the full 64-bit words.
+template <int X>
+struct kCeilLog2 { static constexpr int value = X <= 1 ? 0 : 1 + kCeilLog2<(X + 1) / 2>::value; };
+template <>
+struct kCeilLog2<1> { static constexpr int value = 0; };
+
 template <int L, int BG>
 struct Digits {
   static constexpr int lo_levels() {
@@ -222,6 +227,10 @@ __device__ __forceinline__ void cmux_rows(const typename Digits<L, BG>::word_t (
 template <class F, int L, int BG>
 __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
   constexpr int N = F::N, M = F::M, T = F::THREADS, LOG2N2 = F::LOGM + 2;
+  // Every output of the external product is a sum of 2L * N products digit * key coefficient with |digit| <= 2^(BG-1) and |key| <= 2^63
+  // (the key is (double)(int64_t) of torus words): |sum| <= 2^(ceil log2(2L) + log2 N + BG - 1 + 63).  Below 2^83 the rounding needs no
+  // reduction mod 1 in front (add_rounded); that holds for SET_1's 2 x 2^8 gadget at N = 1024 (2^82) and is decided at compile time.
+  constexpr bool kReduce = !(BG > 0 && kCeilLog2<2 * L>::value + (F::LOGM + 1) + BG - 1 + 63 < 83);
   __shared__ __attribute__((aligned(16))) d2 xch[F::XCH_SLOTS];
   __shared__ __attribute__((aligned(16))) uint64_t acc1[N];
   const int t = threadIdx.x;
@@ -286,13 +295,13 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
     fft.inverse2(o_re[0], o_im[0], o_re[1], o_im[1], xch, t);
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-      al[m] = add_rounded(al[m], o_re[0][m], scale);
-      ah[m] = add_rounded(ah[m], o_im[0][m], scale);
+      al[m] = add_rounded<kReduce>(al[m], o_re[0][m], scale);
+      ah[m] = add_rounded<kReduce>(ah[m], o_im[0][m], scale);
     }
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-      acc1[m * T + t] = add_rounded(acc1[m * T + t], o_re[1][m], scale);
-      acc1[M + m * T + t] = add_rounded(acc1[M + m * T + t], o_im[1][m], scale);
+      acc1[m * T + t] = add_rounded<kReduce>(acc1[m * T + t], o_re[1][m], scale);
+      acc1[M + m * T + t] = add_rounded<kReduce>(acc1[M + m * T + t], o_im[1][m], scale);
     }
     F::sync();
   }
@@ -334,6 +343,7 @@ template <int L, int BG>
 __global__ __launch_bounds__(64 * 2 * L) void pbs_team_kernel(PbsParams p) {
   using F = Fft1024;
   constexpr int N = F::N, M = F::M, T = F::THREADS, LOG2N2 = F::LOGM + 2, R = 2 * L, TEAM = T * R;
+  constexpr bool kReduce = !(BG > 0 && kCeilLog2<2 * L>::value + (F::LOGM + 1) + BG - 1 + 63 < 83);   // see pbs_kernel
   __shared__ __attribute__((aligned(16))) d2 xch[R][F::XCH_SLOTS];     // transposes; after the forward transform: D_w (slots m T + t)
   __shared__ __attribute__((aligned(16))) d2 xinv[2][F::XCH_SLOTS];    // transposes of the two inverse transforms
   __shared__ __attribute__((aligned(16))) uint64_t acc[2][N];
@@ -406,8 +416,8 @@ __global__ __launch_bounds__(64 * 2 * L) void pbs_team_kernel(PbsParams p) {
       fft.inverse(o_re, o_im, xinv[w], t);
 #pragma unroll
       for (int m = 0; m < 8; m++) {
-        acc[w][m * T + t] = add_rounded(acc[w][m * T + t], o_re[m], scale);
-        acc[w][M + m * T + t] = add_rounded(acc[w][M + m * T + t], o_im[m], scale);
+        acc[w][m * T + t] = add_rounded<kReduce>(acc[w][m * T + t], o_re[m], scale);
+        acc[w][M + m * T + t] = add_rounded<kReduce>(acc[w][M + m * T + t], o_im[m], scale);
       }
     }
     __syncthreads();

@@ -615,9 +615,13 @@ __device__ __forceinline__ uint64_t round_mod_2_64(double v, const RoundCtx &rc)
 
 // acc + round_mod_2_64(v) with the 64-bit sum spelled as two 32-bit halves and an explicit carry: the rounded value exists as two
 // unrelated 32-bit registers (low words of A and C), and a 64-bit add would first have to move them into a register pair
+// REDUCE = false skips the reduction mod 1 in front: the magic-number add rounds f 2^32 to an integer exactly as long as |f 2^32| < 2^51,
+// and the low 32 bits of that integer do not care about whole multiples of 2^32, so for |f| < 2^19 the two results are the same bits.  The
+// caller may only ask for it when the bound holds for EVERY input (see pbs_kernel: |sum| <= rows * N * Bg/2 * 2^63 by construction).
+template <bool REDUCE = true>
 __device__ __forceinline__ uint64_t add_rounded(uint64_t acc, double v, const RoundCtx &rc) {
   double f = v * rc.scale;
-  f = f - __builtin_rint(f);
+  if constexpr (REDUCE) f = f - __builtin_rint(f);
   const double A = __builtin_fma(f, rc.two32, rc.magic);
   const double B = A - rc.magic;
   const double q = __builtin_fma(f, rc.two32, -B);
