@@ -533,11 +533,17 @@ static void *dev_alloc(size_t bytes) {
  * growable buffer per host thread is reused instead of a hipMalloc / hipFree pair per call (those cost more than the copies). */
 static __thread void *g_stage = NULL;
 static __thread size_t g_stage_bytes = 0;
+static pthread_key_t g_stage_key;                      /* its destructor releases a thread's buffer when the thread exits */
+static pthread_once_t g_stage_once = PTHREAD_ONCE_INIT;
+static void stage_release(void *p) { if (p) hipFree(p); }
+static void stage_key_init(void) { pthread_key_create(&g_stage_key, stage_release); }
 static void *stage_alloc(size_t bytes) {
   if (bytes > g_stage_bytes) {
     if (g_stage) hipFree(g_stage);
     g_stage_bytes = bytes < 65536 ? 65536 : bytes + bytes / 2;
     g_stage = dev_alloc(g_stage_bytes);
+    pthread_once(&g_stage_once, stage_key_init);
+    pthread_setspecific(g_stage_key, g_stage);
   }
   return g_stage;
 }
