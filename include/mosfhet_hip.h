@@ -259,6 +259,13 @@ int mosfhet_hip_trlwe_mv_extract_batch(mosfhet_hip_ctx_t ctx, uint64_t *d_out, c
 int mosfhet_hip_trlwe_table_ksk_generate(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t *out, int kind, const uint64_t *h_s_out, int N,
                                          const uint64_t *h_s_in, int n, int t, int base_bit, double sigma, uint64_t seed);
 int mosfhet_hip_ksk_export_rows(mosfhet_hip_ksk_t ksk, size_t first_row, size_t count, uint64_t *h_out);
+/* Seed-compressed form (the reference's USE_COMPRESSED_TRLWE key rows, src/keyswitch.c:231-241, regenerated by
+ * trlwe_compressed_subto, src/trlwe_compressed_vaes.c:139-160): the same rows as mosfhet_hip_trlwe_table_ksk_generate makes for this seed, but
+ * only the b halves stay in HBM (mosfhet_hip_ksk_bytes: half); every key switch that takes the handle regenerates the mask words inside the
+ * kernel from (seed, row, word).  Results are bit-identical to the uncompressed key's.  ksk_export_rows expands the rows. */
+int mosfhet_hip_trlwe_table_ksk_generate_compressed(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t *out, int kind, const uint64_t *h_s_out, int N,
+                                                    const uint64_t *h_s_in, int n, int t, int base_bit, double sigma, uint64_t seed);
+size_t mosfhet_hip_ksk_bytes(mosfhet_hip_ksk_t ksk);                     /* device bytes of a key-switch table */
 
 /* Kernel selection for the N = 1024 bootstraps: batches of at most `max_batch` ciphertexts run the latency-oriented kernel (one workgroup
  * of 2l wavefronts per ciphertext, ~1/3 of the latency), larger ones the throughput kernel (one wavefront per ciphertext).  Results are

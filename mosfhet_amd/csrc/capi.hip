@@ -103,6 +103,8 @@ struct mosfhet_hip_ksk {
   uint64_t *d_ksk;
   int n_in, n_out, t, base_bit;
   int row, b_word;  // output row words and the word that receives in.b (LWE: n_out + 1, n_out; packing -> TRLWE: 2N, N)
+  bool compressed = false;  // TRLWE table keys only: d_ksk holds the b halves [rows][N], the masks are keygen_mix(seed, row, word)
+  uint64_t seed = 0;
   size_t bytes;
 };
 
@@ -510,7 +512,7 @@ extern "C" int mosfhet_hip_tlwe_keyswitch_batch(mosfhet_hip_ctx_t ctx, mosfhet_h
   HIP_TRY(hipSetDevice(ctx->device));
   if (ksk->b_word != ksk->n_out) return fail(MOSFHET_HIP_EINVAL, "tlwe_keyswitch: this key is a packing (LWE -> TRLWE) key");
   HIP_TRY(launch_tlwe_keyswitch(ksk->d_ksk, d_out, (size_t)ksk->row, d_in, (size_t)ksk->n_in + 1, count, ksk->n_in, ksk->row, ksk->b_word, ksk->t,
-                                ksk->base_bit, tl_ws(ctx->device), pick(ctx, stream)));
+                                ksk->base_bit, tl_ws(ctx->device), pick(ctx, stream), ksk->compressed, ksk->seed));
   return MOSFHET_HIP_OK;
 }
 
@@ -732,7 +734,7 @@ extern "C" int mosfhet_hip_trlwe_packing1_keyswitch_batch(mosfhet_hip_ctx_t ctx,
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(launch_tlwe_keyswitch(ksk->d_ksk, d_out, (size_t)ksk->row, d_in, (size_t)ksk->n_in + 1, count, ksk->n_in, ksk->row, ksk->b_word, ksk->t,
-                                ksk->base_bit, tl_ws(ctx->device), pick(ctx, stream)));
+                                ksk->base_bit, tl_ws(ctx->device), pick(ctx, stream), ksk->compressed, ksk->seed));
   return MOSFHET_HIP_OK;
 }
 
@@ -767,7 +769,7 @@ extern "C" int mosfhet_hip_circuit_bootstrap_3_batch(mosfhet_hip_ctx_t ctx, mosf
   for (int i = 0; i < l; i++) {
     hipLaunchKernelGGL(trlwe_extract_kernel, dim3((N + 255) / 256, count), dim3(256), 0, s, ext, (size_t)N + 1, acc, (size_t)2 * N, N, i * slot);
     uint64_t *row_b = d_out + (size_t)(l + i) * 2 * N, *row_a = d_out + (size_t)i * 2 * N;
-    HIP_TRY(launch_tlwe_keyswitch(kskb->d_ksk, row_b, trgsw, ext, (size_t)N + 1, count, N, 2 * N, N, kskb->t, kskb->base_bit, tl_ws(ctx->device), s));
+    HIP_TRY(launch_tlwe_keyswitch(kskb->d_ksk, row_b, trgsw, ext, (size_t)N + 1, count, N, 2 * N, N, kskb->t, kskb->base_bit, tl_ws(ctx->device), s, kskb->compressed, kskb->seed));
     if ((rc = launch_fft_ks(ctx, kska, kska->d_ak, kska->d_ak + esz, row_a, trgsw, row_b, trgsw, count, 1, s))) return rc;
   }
   HIP_TRY(hipGetLastError());

@@ -23,7 +23,7 @@ __device__ __forceinline__ uint64_t keygen_mix(uint64_t seed, uint64_t row, uint
 // One workgroup of 256 threads per row; the mask lives in LDS while the key's set bits are walked.
 __global__ __launch_bounds__(256) void trlwe_table_keygen_kernel(uint64_t *__restrict__ rows, const uint64_t *__restrict__ s_out,
                                                                const uint64_t *__restrict__ s_in, int n, int N, int t, int base_bit, double sigma,
-                                                               uint64_t seed, int kind, size_t first_row) {
+                                                               uint64_t seed, int kind, size_t first_row, int compressed) {
   extern __shared__ uint64_t sh[];   // a[N], then the indices of the set key bits (uint16) packed behind it
   uint64_t *a = sh;
   uint16_t *ones = reinterpret_cast<uint16_t *>(sh + N);
@@ -32,7 +32,9 @@ __global__ __launch_bounds__(256) void trlwe_table_keygen_kernel(uint64_t *__res
   const size_t r = first_row + blockIdx.x;
   const int cands = (1 << base_bit) - 1;
   const int v = (int)(r % cands) + 1, j = (int)((r / cands) % t), i = (int)(r / ((size_t)cands * t));
-  uint64_t *dst = rows + r * 2 * (size_t)N;
+  // compressed: only the b halves are stored ([rows][N]); the mask of row r is keygen_mix(seed, r, x, 0) again whenever it is needed
+  uint64_t *dst = compressed ? rows + r * (size_t)N : rows + r * 2 * (size_t)N;
+  uint64_t *dst_b = compressed ? dst : dst + N;
   if (tid == 0) {
     int c = 0;
     for (int x = 0; x < N; x++)
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(256) void trlwe_table_keygen_kernel(uint64_t *__res
   for (int x = tid; x < N; x += 256) {
     const uint64_t ax = keygen_mix(seed, r, x, 0);
     a[x] = ax;
-    dst[x] = ax;
+    if (!compressed) dst[x] = ax;
   }
   __syncthreads();
   const uint64_t s_i = i < n ? s_in[i] : ~0ull;
@@ -61,7 +63,18 @@ __global__ __launch_bounds__(256) void trlwe_table_keygen_kernel(uint64_t *__res
     acc += (uint64_t)(int64_t)(18446744073709551616.0 * z);
     if (kind == 0) { if (x == 0) acc += dec; }
     else acc += ((uint64_t)0 - s_out[x]) * dec;
-    dst[N + x] = acc;
+    dst_b[x] = acc;
+  }
+}
+
+// rows [first_row, first_row + gridDim.x) of a seed-compressed table key in full ([2][N] each): mask regenerated, b half copied
+__global__ __launch_bounds__(256) void trlwe_table_expand_kernel(uint64_t *__restrict__ out, const uint64_t *__restrict__ b_rows, int N, uint64_t seed,
+                                                               size_t first_row) {
+  const size_t r = first_row + blockIdx.x;
+  uint64_t *dst = out + (size_t)blockIdx.x * 2 * N;
+  for (int x = threadIdx.x; x < N; x += 256) {
+    dst[x] = keygen_mix(seed, r, x, 0);
+    dst[N + x] = b_rows[r * (size_t)N + x];
   }
 }
 

@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "keygen_kernels.h"
+
 namespace mosfhet {
 
 // out[c][r] = sum_{s < parts} in[s * part_stride + r * ldin + c] for an R x C matrix of 64-bit words (leading
@@ -59,10 +61,13 @@ constexpr int KS_PF_MAX = 16;    // upper bound of staged row elements a thread 
 // stage are already in flight into registers and are written to the other buffer afterwards -- one barrier per stage.
 // PF = ceil(JB * cands / (64 NW / W)): candidate-row words each thread moves per stage (compile time: no predicated
 // load chains).  Requires t % JB == 0 or handles the short last block of an i by re-staging valid rows only.
-template <int W, int NW, int PF>
+// MASKGEN (seed-compressed TRLWE table keys; the reference: trlwe_compressed_subto, src/trlwe_compressed_vaes.c:139-160): ksk holds
+// only the b halves, [rows][row / 2]; workgroups whose slice lies in the mask half regenerate their candidate rows from (seed, row, word) with
+// the generator that made the key (keygen_mix) instead of loading them -- half the key bytes in HBM, no loads at all for half of the grid.
+template <int W, int NW, int PF, bool MASKGEN = false>
 __global__ __launch_bounds__(64 * NW) void tlwe_keyswitch_kernel(const uint64_t *__restrict__ ksk, const uint64_t *__restrict__ inT,
                                                                 uint64_t *__restrict__ outT, size_t Bp, int n_in, int row, int b_word, int t,
-                                                                int base_bit, int JB, int i_per_split) {
+                                                                int base_bit, int JB, int i_per_split, uint64_t seed) {
   extern __shared__ __attribute__((aligned(16))) uint64_t rows[];  // [2][JB][cands + 1][W + 2]
   constexpr int RS = W + 2;                                        // row stride in words (16-byte aligned, bank-skewed)
   constexpr int SV_STEP = (64 * NW) / W;
@@ -110,11 +115,22 @@ __global__ __launch_bounds__(64 * NW) void tlwe_keyswitch_kernel(const uint64_t 
   uint64_t pf[PF];
   const size_t i_stride = (size_t)t * cands * row;
   const uint64_t *__restrict__ kbase = ksk + w0 + sw;
+  // MASKGEN: candidate row vv of stage (i_, j_) is row ((i_ t + j_) cands + vv) of the key
+  const int half = row >> 1;
+  auto fetch_compressed = [&](int i_, int j_, int k, int last) -> uint64_t {
+    const int vv = sv0 + k * SV_STEP;
+    const size_t r = ((size_t)i_ * t + j_) * cands + (vv <= last ? vv : last);
+    if (w0 < half) return keygen_mix(seed, r, (uint64_t)(w0 + sw), 0);
+    return ksk[r * (size_t)half + (size_t)(w0 - half + sw)];
+  };
   // prefetch stage (i = i_begin, j0 = 0)
   {
     const int last = ((t < JB ? t : JB) * cands - 1);
 #pragma unroll
-    for (int k = 0; k < PF; k++) pf[k] = kbase[(size_t)i_begin * i_stride + ((sv0 + k * SV_STEP <= last) ? goff[k] : (size_t)last * row)];
+    for (int k = 0; k < PF; k++) {
+      if constexpr (MASKGEN) pf[k] = fetch_compressed(i_begin, 0, k, last);
+      else pf[k] = kbase[(size_t)i_begin * i_stride + ((sv0 + k * SV_STEP <= last) ? goff[k] : (size_t)last * row)];
+    }
   }
   uint64_t a_next = inT[(size_t)i_begin * Bp + ct] + round_off;
   int buf_sel = 0;
@@ -137,7 +153,10 @@ __global__ __launch_bounds__(64 * NW) void tlwe_keyswitch_kernel(const uint64_t 
           const int last = (((t - nj < JB) ? (t - nj) : JB) * cands - 1);
           const uint64_t *__restrict__ src = kbase + (size_t)ni * i_stride + (size_t)nj * cands * row;
 #pragma unroll
-          for (int k = 0; k < PF; k++) pf[k] = src[(sv0 + k * SV_STEP <= last) ? goff[k] : (size_t)last * row];
+          for (int k = 0; k < PF; k++) {
+            if constexpr (MASKGEN) pf[k] = fetch_compressed(ni, nj, k, last);
+            else pf[k] = src[(sv0 + k * SV_STEP <= last) ? goff[k] : (size_t)last * row];
+          }
         }
       }
       for (int jj = 0; jj < jb; jj++) {
@@ -195,7 +214,8 @@ struct KsWorkspace {
 // in: rows of n_in + 1 words (n_in when b_word < 0) spaced in_stride words apart; out: rows of `row` words spaced out_stride apart.
 template <int NW>
 inline hipError_t launch_tlwe_keyswitch_nw(const uint64_t *ksk, uint64_t *out, size_t out_stride, const uint64_t *in, size_t in_stride, int count,
-                                           int n_in, int row, int b_word, int t, int base_bit, KsWorkspace &ws, hipStream_t s) {
+                                           int n_in, int row, int b_word, int t, int base_bit, KsWorkspace &ws, hipStream_t s, bool compressed,
+                                           uint64_t seed) {
   constexpr int W = KS_W, TILE = 64 * NW;
   const size_t Bp = ((size_t)count + TILE - 1) / TILE * TILE;
   // split the mask words over blockIdx.z until the grid fills the chip (each workgroup walks its i-range serially)
@@ -246,13 +266,18 @@ inline hipError_t launch_tlwe_keyswitch_nw(const uint64_t *ksk, uint64_t *out, s
   const int pf = (JB * cands + TILE / W - 1) / (TILE / W);
   const dim3 grid(slices, ct_blocks, split);
   // stages of base_bit 7 / 8 need 70 / 139 KiB of the CU's 160 KiB: beyond the 64 KiB a kernel gets without asking
-#define KS_LAUNCH(PF)                                                                                                                          \
+#define KS_LAUNCH_MG(PF, MG)                                                                                                                   \
   do {                                                                                                                                         \
-    if (lds > 65536 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&tlwe_keyswitch_kernel<W, NW, PF>),                            \
+    if (lds > 65536 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&tlwe_keyswitch_kernel<W, NW, PF, MG>),                        \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)                          \
       return e;                                                                                                                                \
-    hipLaunchKernelGGL((tlwe_keyswitch_kernel<W, NW, PF>), grid, dim3(TILE), lds, s, ksk, ws.inT, ws.outT, Bp, n_in, row, b_word, t, base_bit, JB, \
-                       i_per_split);                                                                                                           \
+    hipLaunchKernelGGL((tlwe_keyswitch_kernel<W, NW, PF, MG>), grid, dim3(TILE), lds, s, ksk, ws.inT, ws.outT, Bp, n_in, row, b_word, t, base_bit, \
+                       JB, i_per_split, seed);                                                                                                 \
+  } while (0)
+#define KS_LAUNCH(PF)                 \
+  do {                                \
+    if (compressed) KS_LAUNCH_MG(PF, true); \
+    else KS_LAUNCH_MG(PF, false);     \
   } while (0)
   switch (pf) {
     case 1: KS_LAUNCH(1); break;
@@ -269,6 +294,7 @@ inline hipError_t launch_tlwe_keyswitch_nw(const uint64_t *ksk, uint64_t *out, s
     default: KS_LAUNCH(16); break;
   }
 #undef KS_LAUNCH
+#undef KS_LAUNCH_MG
   // outT[row][Bp] -> out[count][row]
   hipLaunchKernelGGL(transpose_u64_kernel, dim3((count + 31) / 32, (row + 31) / 32), dim3(32, 8), 0, s, ws.outT, out, row, count, Bp, out_stride,
                      split, (size_t)row * Bp);
@@ -278,9 +304,10 @@ inline hipError_t launch_tlwe_keyswitch_nw(const uint64_t *ksk, uint64_t *out, s
 // Tile of 256 ciphertexts per workgroup for small digit sets (the table is cache resident), 512 for base_bit >= 3, where the
 // multi-gigabyte table is re-read once per tile (packing switch 5.3 -> 4.9 ms, lvl2 LWE switch 4.45 -> 4.16 ms; SET_1 prefers 256).
 inline hipError_t launch_tlwe_keyswitch(const uint64_t *ksk, uint64_t *out, size_t out_stride, const uint64_t *in, size_t in_stride, int count,
-                                        int n_in, int row, int b_word, int t, int base_bit, KsWorkspace &ws, hipStream_t s) {
-  if (base_bit >= 3) return launch_tlwe_keyswitch_nw<8>(ksk, out, out_stride, in, in_stride, count, n_in, row, b_word, t, base_bit, ws, s);
-  return launch_tlwe_keyswitch_nw<KS_NW>(ksk, out, out_stride, in, in_stride, count, n_in, row, b_word, t, base_bit, ws, s);
+                                        int n_in, int row, int b_word, int t, int base_bit, KsWorkspace &ws, hipStream_t s, bool compressed = false,
+                                        uint64_t seed = 0) {
+  if (base_bit >= 3) return launch_tlwe_keyswitch_nw<8>(ksk, out, out_stride, in, in_stride, count, n_in, row, b_word, t, base_bit, ws, s, compressed, seed);
+  return launch_tlwe_keyswitch_nw<KS_NW>(ksk, out, out_stride, in, in_stride, count, n_in, row, b_word, t, base_bit, ws, s, compressed, seed);
 }
 
 }  // namespace mosfhet

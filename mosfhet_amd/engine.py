@@ -99,6 +99,12 @@ class KeySwitchKey:
         self.engine, self.h = engine, handle
         self.n_in, self.n_out, self.t, self.base_bit = n_in, n_out, t, base_bit
 
+    @property
+    def nbytes(self):
+        lib().mosfhet_hip_ksk_bytes.restype = C.c_size_t
+        lib().mosfhet_hip_ksk_bytes.argtypes = [C.c_void_p]
+        return lib().mosfhet_hip_ksk_bytes(self.h)
+
     def free(self):
         if self.h:
             lib().mosfhet_hip_ksk_destroy(self.h)
@@ -339,12 +345,14 @@ class Engine:
         _check(lib().mosfhet_hip_trlwe_mv_extract_batch(self.h, _ptr(out), _ptr(ct), N, mode, amount, count, self._stream()))
         return out
 
-    def generate_table_key(self, kind, s_out, s_in, t, base_bit, sigma, seed):
-        """On-device packing (kind 0) / private (kind 1) key-switch key; returns a KeySwitchKey."""
+    def generate_table_key(self, kind, s_out, s_in, t, base_bit, sigma, seed, compressed=False):
+        """On-device packing (kind 0) / private (kind 1) key-switch key; returns a KeySwitchKey.  compressed: keep only the b halves in HBM and
+        regenerate the masks inside the key-switch kernels (same rows, same results)."""
         s_out = np.ascontiguousarray(s_out, dtype=np.uint64)
         s_in = np.ascontiguousarray(s_in, dtype=np.uint64)
         h = C.c_void_p()
-        _check(lib().mosfhet_hip_trlwe_table_ksk_generate(self.h, C.byref(h), kind, s_out.ctypes.data_as(C.c_void_p), s_out.size,
+        gen = lib().mosfhet_hip_trlwe_table_ksk_generate_compressed if compressed else lib().mosfhet_hip_trlwe_table_ksk_generate
+        _check(gen(self.h, C.byref(h), kind, s_out.ctypes.data_as(C.c_void_p), s_out.size,
                                                           s_in.ctypes.data_as(C.c_void_p), s_in.size, t, base_bit, C.c_double(sigma), C.c_uint64(seed)))
         return KeySwitchKey(self, h, s_in.size + kind, 2 * s_out.size - 1, t, base_bit)
 
