@@ -266,6 +266,12 @@ int mosfhet_hip_ksk_export_rows(mosfhet_hip_ksk_t ksk, size_t first_row, size_t 
 int mosfhet_hip_trlwe_table_ksk_generate_compressed(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t *out, int kind, const uint64_t *h_s_out, int N,
                                                     const uint64_t *h_s_in, int n, int t, int base_bit, double sigma, uint64_t seed);
 size_t mosfhet_hip_ksk_bytes(mosfhet_hip_ksk_t ksk);                     /* device bytes of a key-switch table */
+/* On-device generation of the LWE -> LWE key-switch table of tlwe_new_KS_key (src/tlwe.c:193-212) from the two binary keys: rows
+ * TLWE_{s_out}(s_in[i] v 2^(64 - (j+1) base_bit)), masks from the counter-based generator, Gaussian noise sigma.  compressed != 0 stores one word
+ * per row (b) and tlwe_keyswitch regenerates the masks inside the kernel: lvl2's 1.2 GB table becomes 2 MB, results are bit-identical to the
+ * uncompressed key of the same seed.  The handle works with every entry point that takes an LWE key-switch key. */
+int mosfhet_hip_tlwe_ksk_generate(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t *out, const uint64_t *h_s_out, int n_out, const uint64_t *h_s_in, int n_in, int t,
+                                  int base_bit, double sigma, uint64_t seed, int compressed);
 
 /* Kernel selection for the N = 1024 bootstraps: batches of at most `max_batch` ciphertexts run the latency-oriented kernel (one workgroup
  * of 2l wavefronts per ciphertext, ~1/3 of the latency), larger ones the throughput kernel (one wavefront per ciphertext).  Results are

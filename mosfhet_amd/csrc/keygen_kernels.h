@@ -67,14 +67,38 @@ __global__ __launch_bounds__(256) void trlwe_table_keygen_kernel(uint64_t *__res
   }
 }
 
-// rows [first_row, first_row + gridDim.x) of a seed-compressed table key in full ([2][N] each): mask regenerated, b half copied
-__global__ __launch_bounds__(256) void trlwe_table_expand_kernel(uint64_t *__restrict__ out, const uint64_t *__restrict__ b_rows, int N, uint64_t seed,
-                                                               size_t first_row) {
+// rows [first_row, first_row + gridDim.x) of a seed-compressed table key in full (`row` words each): the first mask_words regenerated, the
+// rest copied from the stored b part ([rows][row - mask_words])
+__global__ __launch_bounds__(256) void table_expand_kernel(uint64_t *__restrict__ out, const uint64_t *__restrict__ b_rows, int row, int mask_words,
+                                                         uint64_t seed, size_t first_row) {
   const size_t r = first_row + blockIdx.x;
-  uint64_t *dst = out + (size_t)blockIdx.x * 2 * N;
-  for (int x = threadIdx.x; x < N; x += 256) {
-    dst[x] = keygen_mix(seed, r, x, 0);
-    dst[N + x] = b_rows[r * (size_t)N + x];
+  uint64_t *dst = out + (size_t)blockIdx.x * row;
+  for (int x = threadIdx.x; x < row; x += 256)
+    dst[x] = x < mask_words ? keygen_mix(seed, r, x, 0) : b_rows[r * (size_t)(row - mask_words) + (x - mask_words)];
+}
+
+// LWE -> LWE key-switch table (tlwe_new_KS_key, src/tlwe.c:193-212): row (i, j, v) = TLWE_{s_out}(s_in[i] v 2^(64 - (j+1) bb)), a uniform from the
+// counter-based generator, b = <a, s_out> + e + message.  One wavefront per row.  compressed: only b is stored ([rows] words).
+__global__ __launch_bounds__(64) void tlwe_ksk_keygen_kernel(uint64_t *__restrict__ rows, const uint64_t *__restrict__ s_out, const uint64_t *__restrict__ s_in,
+                                                            int n_out, int t, int base_bit, double sigma, uint64_t seed, size_t first_row, int compressed) {
+  const size_t r = first_row + blockIdx.x;
+  const int cands = (1 << base_bit) - 1, lane = threadIdx.x;
+  const int v = (int)(r % cands) + 1, j = (int)((r / cands) % t);
+  const size_t i = r / ((size_t)cands * t);
+  uint64_t *dst = compressed ? rows + r : rows + r * (size_t)(n_out + 1);
+  uint64_t acc = 0;
+  for (int x = lane; x < n_out; x += 64) {
+    const uint64_t ax = keygen_mix(seed, r, x, 0);
+    if (!compressed) dst[x] = ax;
+    acc += ax * s_out[x];
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) {
+    const double u1 = ((double)(keygen_mix(seed, r, 0, 1) >> 11) + 0.5) * 0x1p-53, u2 = ((double)(keygen_mix(seed, r, 0, 2) >> 11) + 0.5) * 0x1p-53;
+    const double z = cos(6.283185307179586 * u1) * sqrt(-2.0 * log(u2)) * sigma;
+    acc += (uint64_t)(int64_t)(18446744073709551616.0 * z);
+    acc += s_in[i] * (uint64_t)v * (1ull << (64 - (j + 1) * base_bit));
+    dst[compressed ? 0 : n_out] = acc;
   }
 }
 

@@ -67,7 +67,7 @@ constexpr int KS_PF_MAX = 16;    // upper bound of staged row elements a thread 
 template <int W, int NW, int PF, bool MASKGEN = false>
 __global__ __launch_bounds__(64 * NW) void tlwe_keyswitch_kernel(const uint64_t *__restrict__ ksk, const uint64_t *__restrict__ inT,
                                                                 uint64_t *__restrict__ outT, size_t Bp, int n_in, int row, int b_word, int t,
-                                                                int base_bit, int JB, int i_per_split, uint64_t seed) {
+                                                                int base_bit, int JB, int i_per_split, uint64_t seed, int mask_words) {
   extern __shared__ __attribute__((aligned(16))) uint64_t rows[];  // [2][JB][cands + 1][W + 2]
   constexpr int RS = W + 2;                                        // row stride in words (16-byte aligned, bank-skewed)
   constexpr int SV_STEP = (64 * NW) / W;
@@ -115,13 +115,14 @@ __global__ __launch_bounds__(64 * NW) void tlwe_keyswitch_kernel(const uint64_t 
   uint64_t pf[PF];
   const size_t i_stride = (size_t)t * cands * row;
   const uint64_t *__restrict__ kbase = ksk + w0 + sw;
-  // MASKGEN: candidate row vv of stage (i_, j_) is row ((i_ t + j_) cands + vv) of the key
-  const int half = row >> 1;
+  // MASKGEN: candidate row vv of stage (i_, j_) is row ((i_ t + j_) cands + vv) of the key; words below mask_words are regenerated, the others
+  // come from the stored b part, [rows][row - mask_words] (TRLWE rows: N of 2N words each; LWE rows: the single b word)
+  const int word = w0 + sw, b_stride = row - mask_words;
   auto fetch_compressed = [&](int i_, int j_, int k, int last) -> uint64_t {
     const int vv = sv0 + k * SV_STEP;
     const size_t r = ((size_t)i_ * t + j_) * cands + (vv <= last ? vv : last);
-    if (w0 < half) return keygen_mix(seed, r, (uint64_t)(w0 + sw), 0);
-    return ksk[r * (size_t)half + (size_t)(w0 - half + sw)];
+    if (word < mask_words) return keygen_mix(seed, r, (uint64_t)word, 0);
+    return ksk[r * (size_t)b_stride + (size_t)(word - mask_words)];
   };
   // prefetch stage (i = i_begin, j0 = 0)
   {
@@ -215,7 +216,7 @@ struct KsWorkspace {
 template <int NW>
 inline hipError_t launch_tlwe_keyswitch_nw(const uint64_t *ksk, uint64_t *out, size_t out_stride, const uint64_t *in, size_t in_stride, int count,
                                            int n_in, int row, int b_word, int t, int base_bit, KsWorkspace &ws, hipStream_t s, bool compressed,
-                                           uint64_t seed) {
+                                           uint64_t seed, int mask_words) {
   constexpr int W = KS_W, TILE = 64 * NW;
   const size_t Bp = ((size_t)count + TILE - 1) / TILE * TILE;
   // split the mask words over blockIdx.z until the grid fills the chip (each workgroup walks its i-range serially)
@@ -272,7 +273,7 @@ inline hipError_t launch_tlwe_keyswitch_nw(const uint64_t *ksk, uint64_t *out, s
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)                          \
       return e;                                                                                                                                \
     hipLaunchKernelGGL((tlwe_keyswitch_kernel<W, NW, PF, MG>), grid, dim3(TILE), lds, s, ksk, ws.inT, ws.outT, Bp, n_in, row, b_word, t, base_bit, \
-                       JB, i_per_split, seed);                                                                                                 \
+                       JB, i_per_split, seed, mask_words);                                                                                     \
   } while (0)
 #define KS_LAUNCH(PF)                 \
   do {                                \
@@ -306,8 +307,11 @@ inline hipError_t launch_tlwe_keyswitch_nw(const uint64_t *ksk, uint64_t *out, s
 inline hipError_t launch_tlwe_keyswitch(const uint64_t *ksk, uint64_t *out, size_t out_stride, const uint64_t *in, size_t in_stride, int count,
                                         int n_in, int row, int b_word, int t, int base_bit, KsWorkspace &ws, hipStream_t s, bool compressed = false,
                                         uint64_t seed = 0) {
-  if (base_bit >= 3) return launch_tlwe_keyswitch_nw<8>(ksk, out, out_stride, in, in_stride, count, n_in, row, b_word, t, base_bit, ws, s, compressed, seed);
-  return launch_tlwe_keyswitch_nw<KS_NW>(ksk, out, out_stride, in, in_stride, count, n_in, row, b_word, t, base_bit, ws, s, compressed, seed);
+  // compressed keys: TRLWE rows (b_word = N or none) keep their b polynomial, LWE rows (b_word = row - 1) their one b word
+  const int mask_words = !compressed ? 0 : (b_word == row - 1 ? row - 1 : row / 2);
+  if (base_bit >= 3)
+    return launch_tlwe_keyswitch_nw<8>(ksk, out, out_stride, in, in_stride, count, n_in, row, b_word, t, base_bit, ws, s, compressed, seed, mask_words);
+  return launch_tlwe_keyswitch_nw<KS_NW>(ksk, out, out_stride, in, in_stride, count, n_in, row, b_word, t, base_bit, ws, s, compressed, seed, mask_words);
 }
 
 }  // namespace mosfhet

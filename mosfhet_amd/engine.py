@@ -356,6 +356,15 @@ class Engine:
                                                           s_in.ctypes.data_as(C.c_void_p), s_in.size, t, base_bit, C.c_double(sigma), C.c_uint64(seed)))
         return KeySwitchKey(self, h, s_in.size + kind, 2 * s_out.size - 1, t, base_bit)
 
+    def generate_keyswitch_key(self, s_out, s_in, t, base_bit, sigma, seed, compressed=False):
+        """On-device LWE -> LWE key-switch table (tlwe_new_KS_key) from the binary keys s_in (switched from) and s_out (switched to)."""
+        s_out = np.ascontiguousarray(s_out, dtype=np.uint64)
+        s_in = np.ascontiguousarray(s_in, dtype=np.uint64)
+        h = C.c_void_p()
+        _check(lib().mosfhet_hip_tlwe_ksk_generate(self.h, C.byref(h), s_out.ctypes.data_as(C.c_void_p), s_out.size, s_in.ctypes.data_as(C.c_void_p), s_in.size,
+                                                   t, base_bit, C.c_double(sigma), C.c_uint64(seed), int(compressed)))
+        return KeySwitchKey(self, h, s_in.size, s_out.size, t, base_bit)
+
     # ---- key images (on-disk formats; include/mosfhet_hip.h "Key images") ----
     def export_bootstrap_key(self, bsk):
         """The engine's own image of a bootstrap key (DFT rows; torus-domain samples for an unfolded key) as raw bytes."""
