@@ -285,7 +285,8 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
     for (int c = 0; c < 2; c++)
 #pragma unroll
       for (int m = 0; m < 8; m++) { o_re[c][m] = 0.0; o_im[c][m] = 0.0; }
-#pragma unroll 1
+    constexpr int kUnrollQ = L == 1 ? 2 : 1;
+#pragma unroll kUnrollQ
     for (int q = 0; q < 2; q++) {
       typename Digits<L, BG>::word_t w_lo[8], w_hi[8];
       uint32_t ext[8];
