@@ -266,6 +266,11 @@ int mosfhet_hip_ksk_export_rows(mosfhet_hip_ksk_t ksk, size_t first_row, size_t 
 int mosfhet_hip_trlwe_table_ksk_generate_compressed(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t *out, int kind, const uint64_t *h_s_out, int N,
                                                     const uint64_t *h_s_in, int n, int t, int base_bit, double sigma, uint64_t seed);
 size_t mosfhet_hip_ksk_bytes(mosfhet_hip_ksk_t ksk);                     /* device bytes of a key-switch table */
+/* On-device generation of the bootstrap key (new_bootstrap_key without unfolding, src/bootstrap.c:3-21: BK_i = TRGSW(s_i); ga != 0: the
+ * TRGSW(X^{s_i}) samples of new_bootstrap_key_ga, src/bootstrap_ga.c:5-24) from the binary TRLWE key h_s_rlwe[N] and LWE key h_s_lwe[n]:
+ * encrypted in the torus domain by the counter-based generator (exact a * s, Gaussian noise sigma), then transformed -- no host key, no upload. */
+int mosfhet_hip_bsk_generate(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t *out, const uint64_t *h_s_rlwe, int N, const uint64_t *h_s_lwe, int n, int l, int Bg_bit,
+                             double sigma, uint64_t seed, int ga);
 /* On-device generation of the LWE -> LWE key-switch table of tlwe_new_KS_key (src/tlwe.c:193-212) from the two binary keys: rows
  * TLWE_{s_out}(s_in[i] v 2^(64 - (j+1) base_bit)), masks from the counter-based generator, Gaussian noise sigma.  compressed != 0 stores one word
  * per row (b) and tlwe_keyswitch regenerates the masks inside the kernel: lvl2's 1.2 GB table becomes 2 MB, results are bit-identical to the

@@ -618,12 +618,12 @@ Bootstrap_Key new_bootstrap_key(TRGSW_Key out_key, TLWE_Key in_key, int unfoldin
   res->n = n; res->k = k; res->l = l; res->N = N; res->Bg_bit = out_key->Bg_bit; res->unfolding = unfolding;
   res->su = NULL;   /* device resident as well (reference: host TRGSW array, src/bootstrap.c:35) */
   mosfhet_hip_bsk_t dev = NULL;
+  if (k != 1) { fprintf(stderr, "mosfhet_amd: new_bootstrap_key: k = 1 only (all of the reference's parameter sets, test/tests.c:37-62)\n"); abort(); }
   if (unfolding == 1) {
-    const size_t words = (size_t)n * (k + 1) * l * (k + 1) * N;
-    Torus *flat = (Torus *)xmalloc(sizeof(Torus) * words);
-    mosfhet_gen_bootstrap_key_flat(flat, out_key, in_key);
-    if (mosfhet_hip_bsk_create((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, flat, n, k, N, l, out_key->Bg_bit)) die("new_bootstrap_key");
-    free(flat);
+    /* encrypted on the device (counter-based generator seeded from this thread's stream), transformed there: no host copy of the key */
+    if (mosfhet_hip_bsk_generate((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, out_key->trlwe_key->s[0]->coeffs, N, in_key->s, n, l, out_key->Bg_bit,
+                                 out_key->trlwe_key->sigma, rnd64(), 0))
+      die("new_bootstrap_key");
   } else {
     const size_t words = (size_t)n * ((size_t)1 << unfolding) / unfolding * 2 * l * 2 * N;
     Torus *flat = (Torus *)xmalloc(sizeof(Torus) * words);
@@ -819,12 +819,11 @@ Bootstrap_GA_Key new_bootstrap_key_ga(TRGSW_Key out_key, TLWE_Key in_key) {
   Bootstrap_GA_Key res = (Bootstrap_GA_Key)xmalloc(sizeof(*res));
   res->n = n; res->k = k; res->l = l; res->N = N; res->Bg_bit = out_key->Bg_bit; res->unfolding = 1;
   res->su = NULL;
-  Torus *flat = (Torus *)xmalloc(sizeof(Torus) * (size_t)n * 2 * l * 2 * N);
-  mosfhet_gen_bootstrap_key_ga_flat(flat, out_key, in_key);
+  /* the TRGSW(X^{s_i}) samples are encrypted on the device (mosfhet_hip_bsk_generate, ga = 1) */
   mosfhet_hip_bsk_t dev = NULL;
-  if (mosfhet_hip_bsk_create(ctx, &dev, flat, n, k, N, l, out_key->Bg_bit)) die("new_bootstrap_key_ga");
-  free(flat);
-  flat = (Torus *)xmalloc(sizeof(Torus) * (size_t)N * l * 2 * N);
+  if (mosfhet_hip_bsk_generate(ctx, &dev, out_key->trlwe_key->s[0]->coeffs, N, in_key->s, n, l, out_key->Bg_bit, out_key->trlwe_key->sigma, rnd64(), 1))
+    die("new_bootstrap_key_ga");
+  Torus *flat = (Torus *)xmalloc(sizeof(Torus) * (size_t)N * l * 2 * N);
   mosfhet_gen_automorphism_keyset_flat(flat, out_key->trlwe_key, l, out_key->Bg_bit);   /* src/bootstrap_ga.c:10: t = l, base_bit = Bg_bit */
   mosfhet_hip_gak_t gak = NULL;
   if (mosfhet_hip_gak_create(ctx, &gak, flat, N, l, out_key->Bg_bit)) die("new_bootstrap_key_ga (automorphism keys)");

@@ -67,6 +67,47 @@ __global__ __launch_bounds__(256) void trlwe_table_keygen_kernel(uint64_t *__res
   }
 }
 
+// Bootstrap key in the torus domain, BK_i = TRGSW(s_i) (new_bootstrap_key, src/bootstrap.c:14-18) or, ga != 0, TRGSW(X^{s_i}) (new_bootstrap_key_ga,
+// src/bootstrap_ga.c:17-20): row r = i * 2l + q, q = c * l + j, is a fresh TRLWE(0) with m * 2^(64 - (j+1) Bg) added to coefficient e of component c
+// (trgsw_monomial_sample, src/trgsw.c:152-168; k = 1).  One workgroup per row, same generator and exact a * s as the table keys above.
+__global__ __launch_bounds__(256) void trgsw_bk_keygen_kernel(uint64_t *__restrict__ rows, const uint64_t *__restrict__ s_out, const uint64_t *__restrict__ s_in,
+                                                            int N, int l, int Bg_bit, double sigma, uint64_t seed, int ga) {
+  extern __shared__ uint64_t sh[];
+  uint64_t *a = sh;
+  uint16_t *ones = reinterpret_cast<uint16_t *>(sh + N);
+  __shared__ int n_ones;
+  const int tid = threadIdx.x;
+  const size_t r = blockIdx.x;
+  const int q = (int)(r % (2 * l)), c = q / l, j = q % l;
+  const size_t i = r / (2 * l);
+  uint64_t *dst = rows + r * 2 * (size_t)N;
+  if (tid == 0) {
+    int cnt = 0;
+    for (int x = 0; x < N; x++)
+      if (s_out[x] & 1) ones[cnt++] = (uint16_t)x;
+    n_ones = cnt;
+  }
+  for (int x = tid; x < N; x += 256) a[x] = keygen_mix(seed, r, x, 0);
+  __syncthreads();
+  const uint64_t h = 1ull << (64 - (j + 1) * Bg_bit);
+  const int e = ga ? (int)(s_in[i] & 1) : 0;
+  const uint64_t val = ga ? h : s_in[i] * h;
+  const int cnt = n_ones;
+  for (int x = tid; x < N; x += 256) {
+    uint64_t acc = 0;
+    for (int k = 0; k < cnt; k++) {
+      const int p = ones[k], src = x - p;
+      const uint64_t w = a[src & (N - 1)];
+      acc += src < 0 ? (uint64_t)0 - w : w;
+    }
+    const double u1 = ((double)(keygen_mix(seed, r, x, 1) >> 11) + 0.5) * 0x1p-53, u2 = ((double)(keygen_mix(seed, r, x, 2) >> 11) + 0.5) * 0x1p-53;
+    const double z = cos(6.283185307179586 * u1) * sqrt(-2.0 * log(u2)) * sigma;
+    acc += (uint64_t)(int64_t)(18446744073709551616.0 * z);
+    dst[x] = a[x] + ((c == 0 && x == e) ? val : 0);     // the gadget goes on the mask AFTER b = a * s + e was formed from the plain mask
+    dst[N + x] = acc + ((c == 1 && x == e) ? val : 0);
+  }
+}
+
 // rows [first_row, first_row + gridDim.x) of a seed-compressed table key in full (`row` words each): the first mask_words regenerated, the
 // rest copied from the stored b part ([rows][row - mask_words])
 __global__ __launch_bounds__(256) void table_expand_kernel(uint64_t *__restrict__ out, const uint64_t *__restrict__ b_rows, int row, int mask_words,

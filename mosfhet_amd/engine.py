@@ -356,6 +356,15 @@ class Engine:
                                                           s_in.ctypes.data_as(C.c_void_p), s_in.size, t, base_bit, C.c_double(sigma), C.c_uint64(seed)))
         return KeySwitchKey(self, h, s_in.size + kind, 2 * s_out.size - 1, t, base_bit)
 
+    def generate_bootstrap_key(self, s_rlwe, s_lwe, l, Bg_bit, sigma, seed, ga=False):
+        """On-device bootstrap key BK_i = TRGSW(s_lwe[i]) (ga: TRGSW(X^{s_lwe[i]})) under the binary TRLWE key s_rlwe."""
+        s_rlwe = np.ascontiguousarray(s_rlwe, dtype=np.uint64)
+        s_lwe = np.ascontiguousarray(s_lwe, dtype=np.uint64)
+        h = C.c_void_p()
+        _check(lib().mosfhet_hip_bsk_generate(self.h, C.byref(h), s_rlwe.ctypes.data_as(C.c_void_p), s_rlwe.size, s_lwe.ctypes.data_as(C.c_void_p), s_lwe.size,
+                                              l, Bg_bit, C.c_double(sigma), C.c_uint64(seed), int(ga)))
+        return BootstrapKey(self, h, s_lwe.size, 1, s_rlwe.size, l, Bg_bit)
+
     def generate_keyswitch_key(self, s_out, s_in, t, base_bit, sigma, seed, compressed=False):
         """On-device LWE -> LWE key-switch table (tlwe_new_KS_key) from the binary keys s_in (switched from) and s_out (switched to)."""
         s_out = np.ascontiguousarray(s_out, dtype=np.uint64)
