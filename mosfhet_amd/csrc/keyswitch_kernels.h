@@ -249,11 +249,15 @@ inline hipError_t launch_tlwe_keyswitch_nw(const uint64_t *ksk, uint64_t *out, s
   hipLaunchKernelGGL(transpose_u64_kernel, dim3((in_words + 31) / 32, (count + 31) / 32), dim3(32, 8), 0, s, in, ws.inT, count, in_words,
                      in_stride, Bp, 1, (size_t)0);
   const int cands = (1 << base_bit) - 1;
-  // LDS per buffer: with >= 7 candidates per digit one digit position per stage (4.3 KiB) keeps more workgroups resident and measured
-  // fastest (packing switch 6.3 -> 5.8 ms, lvl2 LWE switch 5.1 -> 4.7 ms); small digit sets (base_bit 2) prefer all of an input
-  // word's positions in one stage.  MOSFHET_KS_LDS_BYTES overrides (tuning).
+  // LDS per buffer = digit positions per stage (one barrier per stage).  Small digit sets (base_bit 2) take all of an input word's positions in
+  // one stage; base_bit 3 and 4 take TWO positions per stage (same-box sweep with the 512-ciphertext tile: packing switch 5.00 -> 4.40 ms per 1024
+  // and 18.9 -> 16.9 ms per 4096, lvl2 LWE switch 4.06 -> 3.54 ms; three positions are slower again); wider digit sets one.  A table whose
+  // every word is regenerated (seed-compressed LWE key) keeps one position: its stage is generator-bound, 4.02 vs 4.11 ms.
+  // MOSFHET_KS_LDS_BYTES overrides (tuning).
   static const int lds_env = getenv("MOSFHET_KS_LDS_BYTES") ? atoi(getenv("MOSFHET_KS_LDS_BYTES")) : 0;
-  const int lds_budget = lds_env ? lds_env : (cands >= 7 ? 4352 : KS_LDS_BYTES);
+  const int two_positions = 2 * (cands + 1) * (W + 2) * 8;
+  const bool all_generated = compressed && mask_words == row - 1;
+  const int lds_budget = lds_env ? lds_env : (cands < 7 ? KS_LDS_BYTES : ((cands <= 15 && !all_generated) ? two_positions : 4352));
   int JB = lds_budget / ((cands + 1) * (W + 2) * 8);          // per LDS buffer
   // rows a stage can prefetch through registers: 8 per thread, 16 for the widest digit sets (base_bit 8 with a 256-ciphertext tile, where
   // one digit position alone has more candidate rows than 8 per thread cover)
