@@ -313,7 +313,8 @@ inline hipError_t launch_tlwe_keyswitch(const uint64_t *ksk, uint64_t *out, size
                                         uint64_t seed = 0) {
   // compressed keys: TRLWE rows (b_word = N or none) keep their b polynomial, LWE rows (b_word = row - 1) their one b word
   const int mask_words = !compressed ? 0 : (b_word == row - 1 ? row - 1 : row / 2);
-  if (base_bit >= 3)
+  static const int tile_env = getenv("MOSFHET_KS_TILE") ? atoi(getenv("MOSFHET_KS_TILE")) : 0;   // tuning: 256 or 512 ciphertexts per workgroup
+  if (tile_env == 512 || (tile_env != 256 && base_bit >= 3))
     return launch_tlwe_keyswitch_nw<8>(ksk, out, out_stride, in, in_stride, count, n_in, row, b_word, t, base_bit, ws, s, compressed, seed, mask_words);
   return launch_tlwe_keyswitch_nw<KS_NW>(ksk, out, out_stride, in, in_stride, count, n_in, row, b_word, t, base_bit, ws, s, compressed, seed, mask_words);
 }
