@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <memory>
 #include <vector>
 
 #include "bootstrap_kernels.h"
@@ -36,9 +37,24 @@ static int fail(int code, const char *fmt, ...) {
       return fail(MOSFHET_HIP_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
+// Handles own their device memory: the destructors release it (on the handle's device), so a creation that fails half-way gives everything back.
 struct mosfhet_hip_ctx {
-  int device;
-  d2 *tw1024, *tw2048, *tw4096;  // device twiddle tables
+  int device = 0;
+  d2 *tw1024 = nullptr, *tw2048 = nullptr, *tw4096 = nullptr;  // device twiddle tables
+  ~mosfhet_hip_ctx() {
+    (void)hipSetDevice(device);
+    if (tw1024) (void)hipFree(tw1024);
+    if (tw2048) (void)hipFree(tw2048);
+    if (tw4096) (void)hipFree(tw4096);
+  }
+};
+
+// scoped device buffer for the temporaries of the creation functions
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+  template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
 // Temporaries of the compositions (FDFB, multi-value, circuit bootstraps, tlwe_mul, ...) and the transposed batches of the table key
@@ -90,29 +106,42 @@ static int pool_get(int device, int slot, size_t words, uint64_t **out) {
 }
 
 struct mosfhet_hip_bsk {
-  mosfhet_hip_ctx_t ctx;
-  d2 *d_bk;  // [n][(k+1)l][k+1][P][lanes]
+  mosfhet_hip_ctx_t ctx = nullptr;
+  d2 *d_bk = nullptr;  // [n][(k+1)l][k+1][P][lanes]
   int n, k, N, l, Bg_bit;
   int unfolding = 1;          // > 1: d_bk is null and d_su holds the torus-domain samples of new_bootstrap_key (src/bootstrap.c:23-48)
   uint64_t *d_su = nullptr;   // [n 2^u / u][2l][2][N]
-  size_t bytes;
+  size_t bytes = 0;
+  ~mosfhet_hip_bsk() {
+    if (ctx) (void)hipSetDevice(ctx->device);
+    if (d_bk) (void)hipFree(d_bk);
+    if (d_su) (void)hipFree(d_su);
+  }
 };
 
 struct mosfhet_hip_ksk {
-  mosfhet_hip_ctx_t ctx;
-  uint64_t *d_ksk;
+  mosfhet_hip_ctx_t ctx = nullptr;
+  uint64_t *d_ksk = nullptr;
   int n_in, n_out, t, base_bit;
   int row, b_word;  // output row words and the word that receives in.b (LWE: n_out + 1, n_out; packing -> TRLWE: 2N, N)
   bool compressed = false;  // TRLWE table keys only: d_ksk holds the b halves [rows][N], the masks are keygen_mix(seed, row, word)
   uint64_t seed = 0;
-  size_t bytes;
+  size_t bytes = 0;
+  ~mosfhet_hip_ksk() {
+    if (ctx) (void)hipSetDevice(ctx->device);
+    if (d_ksk) (void)hipFree(d_ksk);
+  }
 };
 
 struct mosfhet_hip_gak {
-  mosfhet_hip_ctx_t ctx;
-  d2 *d_ak;  // [entries][t][2][8][T]
+  mosfhet_hip_ctx_t ctx = nullptr;
+  d2 *d_ak = nullptr;  // [entries][t][2][8][T]
   int N, t, base_bit, entries;
-  size_t bytes;
+  size_t bytes = 0;
+  ~mosfhet_hip_gak() {
+    if (ctx) (void)hipSetDevice(ctx->device);
+    if (d_ak) (void)hipFree(d_ak);
+  }
 };
 
 extern "C" const char *mosfhet_hip_last_error(void) { return g_err; }
@@ -166,7 +195,7 @@ extern "C" int mosfhet_hip_ctx_create(mosfhet_hip_ctx_t *out, int device) {
     return fail(MOSFHET_HIP_ENODEV, "no HIP device visible (this library has no CPU fallback)");
   if (device < 0 || device >= ndev) return fail(MOSFHET_HIP_EINVAL, "ctx_create: device %d of %d", device, ndev);
   HIP_TRY(hipSetDevice(device));
-  mosfhet_hip_ctx *c = new mosfhet_hip_ctx();
+  std::unique_ptr<mosfhet_hip_ctx> c(new mosfhet_hip_ctx());
   c->device = device;
   for (int N : {1024, 2048, 4096}) {
     std::vector<double> tw;
@@ -175,7 +204,7 @@ extern "C" int mosfhet_hip_ctx_create(mosfhet_hip_ctx_t *out, int device) {
     HIP_TRY(hipMalloc((void **)&dst, tw.size() * sizeof(double)));
     HIP_TRY(hipMemcpy(dst, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice));
   }
-  *out = c;
+  *out = c.release();
   return MOSFHET_HIP_OK;
 }
 
@@ -183,9 +212,6 @@ extern "C" int mosfhet_hip_ctx_destroy(mosfhet_hip_ctx_t ctx) {
   if (!ctx) return MOSFHET_HIP_OK;
   hipSetDevice(ctx->device);
   hipDeviceSynchronize();
-  hipFree(ctx->tw1024);
-  hipFree(ctx->tw2048);
-  hipFree(ctx->tw4096);
   delete ctx;
   return MOSFHET_HIP_OK;
 }
@@ -225,14 +251,15 @@ extern "C" int mosfhet_hip_bsk_create_from_device(mosfhet_hip_ctx_t ctx, mosfhet
   int rc = check_params("bsk_create", k, N, l, Bg_bit);
   if (rc) return rc;
   HIP_TRY(hipSetDevice(ctx->device));
-  mosfhet_hip_bsk *b = new mosfhet_hip_bsk();
+  std::unique_ptr<mosfhet_hip_bsk> b_owner(new mosfhet_hip_bsk());
+  mosfhet_hip_bsk *b = b_owner.get();
   b->ctx = ctx; b->n = n; b->k = k; b->N = N; b->l = l; b->Bg_bit = Bg_bit;
   const size_t polys = (size_t)n * (k + 1) * l * (k + 1);
   b->bytes = polys * N * sizeof(double);
   HIP_TRY(hipMalloc((void **)&b->d_bk, b->bytes));
   RING_DISPATCH(ctx, N, hipLaunchKernelGGL(torus_to_dft_kernel<F>, dim3((unsigned)polys), dim3(F::THREADS), 0, pick(ctx, stream), d_bk, b->d_bk, TW));
   HIP_TRY(hipGetLastError());
-  *out = b;
+  *out = b_owner.release();
   return MOSFHET_HIP_OK;
 }
 
@@ -255,9 +282,6 @@ extern "C" int mosfhet_hip_bsk_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t *
 
 extern "C" int mosfhet_hip_bsk_destroy(mosfhet_hip_bsk_t bsk) {
   if (!bsk) return MOSFHET_HIP_OK;
-  hipSetDevice(bsk->ctx->device);
-  if (bsk->d_bk) hipFree(bsk->d_bk);
-  if (bsk->d_su) hipFree(bsk->d_su);
   delete bsk;
   return MOSFHET_HIP_OK;
 }
@@ -486,20 +510,19 @@ extern "C" int mosfhet_hip_ksk_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t *
   if (!ctx || !out || !h_ksk || n_in < 1 || n_out < 1 || t < 1 || base_bit < 1 || base_bit > 8 || t * base_bit >= 64)
     return fail(MOSFHET_HIP_EINVAL, "ksk_create: bad argument");
   HIP_TRY(hipSetDevice(ctx->device));
-  mosfhet_hip_ksk *k = new mosfhet_hip_ksk();
+  std::unique_ptr<mosfhet_hip_ksk> k_owner(new mosfhet_hip_ksk());
+  mosfhet_hip_ksk *k = k_owner.get();
   k->ctx = ctx; k->n_in = n_in; k->n_out = n_out; k->t = t; k->base_bit = base_bit;
   k->row = n_out + 1; k->b_word = n_out;
   k->bytes = (size_t)n_in * t * ((1u << base_bit) - 1) * (n_out + 1) * sizeof(uint64_t);
   HIP_TRY(hipMalloc((void **)&k->d_ksk, k->bytes));
   HIP_TRY(hipMemcpy(k->d_ksk, h_ksk, k->bytes, hipMemcpyHostToDevice));
-  *out = k;
+  *out = k_owner.release();
   return MOSFHET_HIP_OK;
 }
 
 extern "C" int mosfhet_hip_ksk_destroy(mosfhet_hip_ksk_t ksk) {
   if (!ksk) return MOSFHET_HIP_OK;
-  hipSetDevice(ksk->ctx->device);
-  hipFree(ksk->d_ksk);
   delete ksk;
   return MOSFHET_HIP_OK;
 }
@@ -595,19 +618,20 @@ extern "C" int mosfhet_hip_trlwe_ksk_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_g
   if (!ring_ok(N)) return fail(MOSFHET_HIP_EINVAL, "trlwe_ksk_create: N = %d not supported (1024, 2048, 4096)", N);
   if (t < 1 || base_bit < 1 || t * base_bit >= 64) return fail(MOSFHET_HIP_EINVAL, "trlwe_ksk_create: bad t = %d base_bit = %d", t, base_bit);
   HIP_TRY(hipSetDevice(ctx->device));
-  mosfhet_hip_gak *g = new mosfhet_hip_gak();
+  std::unique_ptr<mosfhet_hip_gak> g_owner(new mosfhet_hip_gak());
+  mosfhet_hip_gak *g = g_owner.get();
   g->ctx = ctx; g->N = N; g->t = t; g->base_bit = base_bit; g->entries = entries;
   const size_t polys = (size_t)entries * t * 2;
   g->bytes = polys * N * sizeof(double);
-  uint64_t *d_tmp = nullptr;
-  HIP_TRY(hipMalloc((void **)&d_tmp, g->bytes));
+  DevBuf tmp;                                      // torus-domain rows, released on every way out
+  HIP_TRY(tmp.alloc(g->bytes));
+  uint64_t *d_tmp = tmp.as<uint64_t>();
   HIP_TRY(hipMalloc((void **)&g->d_ak, g->bytes));
   HIP_TRY(hipMemcpy(d_tmp, h_rows, g->bytes, hipMemcpyHostToDevice));
   RING_DISPATCH(ctx, N, hipLaunchKernelGGL(torus_to_dft_kernel<F>, dim3((unsigned)polys), dim3(F::THREADS), 0, nullptr, d_tmp, g->d_ak, TW));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(nullptr));
-  hipFree(d_tmp);
-  *out = g;
+  *out = g_owner.release();
   return MOSFHET_HIP_OK;
 }
 
@@ -617,8 +641,6 @@ extern "C" int mosfhet_hip_gak_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_gak_t *
 
 extern "C" int mosfhet_hip_gak_destroy(mosfhet_hip_gak_t gak) {
   if (!gak) return MOSFHET_HIP_OK;
-  hipSetDevice(gak->ctx->device);
-  hipFree(gak->d_ak);
   delete gak;
   return MOSFHET_HIP_OK;
 }
