@@ -271,6 +271,12 @@ size_t mosfhet_hip_ksk_bytes(mosfhet_hip_ksk_t ksk);                     /* devi
  * encrypted in the torus domain by the counter-based generator (exact a * s, Gaussian noise sigma), then transformed -- no host key, no upload. */
 int mosfhet_hip_bsk_generate(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t *out, const uint64_t *h_s_rlwe, int N, const uint64_t *h_s_lwe, int n, int l, int Bg_bit,
                              double sigma, uint64_t seed, int ga);
+/* On-device generation of FFT-based TRLWE key-switch keys: entry e, row r < t = TRLWE_{s_out}(h_msgs[e](X) * 2^(64 - (r+1) base_bit)), then the
+ * engine's forward transform.  h_msgs = Torus[entries][N] holds the polynomial each entry switches FROM: the other key (trlwe_new_KS_key,
+ * src/keyswitch.c:12-37), its Galois images s(X^(2e+1)) for e < N (trlwe_new_automorphism_KS_keyset, :500-511), (-s * s_in, -s) (trlwe_new_priv_KS_key,
+ * :39-50) or s^2 (trlwe_new_RL_key, :3-10). */
+int mosfhet_hip_trlwe_ksk_generate(mosfhet_hip_ctx_t ctx, mosfhet_hip_gak_t *out, const uint64_t *h_s_out, int N, const uint64_t *h_msgs, int entries, int t,
+                                   int base_bit, double sigma, uint64_t seed);
 /* On-device generation of the LWE -> LWE key-switch table of tlwe_new_KS_key (src/tlwe.c:193-212) from the two binary keys: rows
  * TLWE_{s_out}(s_in[i] v 2^(64 - (j+1) base_bit)), masks from the counter-based generator, Gaussian noise sigma.  compressed != 0 stores one word
  * per row (b) and tlwe_keyswitch regenerates the masks inside the kernel: lvl2's 1.2 GB table becomes 2 MB, results are bit-identical to the

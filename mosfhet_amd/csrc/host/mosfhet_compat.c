@@ -812,6 +812,8 @@ void mosfhet_gen_automorphism_keyset_flat(Torus *out, TRLWE_Key key, int t, int 
   free_trlwe(tmp);
 }
 
+static mosfhet_hip_gak_t fft_ks_keys_new(TRLWE_Key out_key, const Torus *msgs, int entries, int t, int base_bit, const char *who);
+
 Bootstrap_GA_Key new_bootstrap_key_ga(TRGSW_Key out_key, TLWE_Key in_key) {
   const int l = out_key->l, k = out_key->trlwe_key->k, N = out_key->trlwe_key->s[0]->N, n = in_key->n;
   if (k != 1) { fprintf(stderr, "mosfhet_amd: new_bootstrap_key_ga: k = 1 only\n"); abort(); }
@@ -823,11 +825,16 @@ Bootstrap_GA_Key new_bootstrap_key_ga(TRGSW_Key out_key, TLWE_Key in_key) {
   mosfhet_hip_bsk_t dev = NULL;
   if (mosfhet_hip_bsk_generate(ctx, &dev, out_key->trlwe_key->s[0]->coeffs, N, in_key->s, n, l, out_key->Bg_bit, out_key->trlwe_key->sigma, rnd64(), 1))
     die("new_bootstrap_key_ga");
-  Torus *flat = (Torus *)xmalloc(sizeof(Torus) * (size_t)N * l * 2 * N);
-  mosfhet_gen_automorphism_keyset_flat(flat, out_key->trlwe_key, l, out_key->Bg_bit);   /* src/bootstrap_ga.c:10: t = l, base_bit = Bg_bit */
-  mosfhet_hip_gak_t gak = NULL;
-  if (mosfhet_hip_gak_create(ctx, &gak, flat, N, l, out_key->Bg_bit)) die("new_bootstrap_key_ga (automorphism keys)");
-  free(flat);
+  /* automorphism key set (src/bootstrap_ga.c:10: t = l, base_bit = Bg_bit): entry j switches from s(X^(2j+1)), encrypted on the device too */
+  Torus *msgs = (Torus *)xmalloc(sizeof(Torus) * (size_t)N * N);
+  TorusPolynomial perm = polynomial_new_torus_polynomial(N);
+  for (int j = 0; j < N; j++) {
+    polynomial_permute(perm, out_key->trlwe_key->s[0], (uint64_t)(2 * j + 1));
+    memcpy(msgs + (size_t)j * N, perm->coeffs, sizeof(Torus) * (size_t)N);
+  }
+  free_polynomial(perm);
+  mosfhet_hip_gak_t gak = fft_ks_keys_new(out_key->trlwe_key, msgs, N, l, out_key->Bg_bit, "new_bootstrap_key_ga (automorphism keys)");
+  free(msgs);
   res->s = (TRGSW_DFT *)xmalloc(sizeof(TRGSW_DFT));
   res->s[0] = (TRGSW_DFT)dev;
   res->ak = (void **)xmalloc(sizeof(void *));
@@ -1008,25 +1015,30 @@ static TRLWE_KS_Key trlwe_ks_header(void *dev, int entry, int owner, int t, int 
   return res;
 }
 
-TRLWE_KS_Key trlwe_new_KS_key(TRLWE_Key out_key, TRLWE_Key in_key, int t, int base_bit) {
-  const int N = out_key->s[0]->N;
-  if (out_key->k != 1 || in_key->k != 1) { fprintf(stderr, "mosfhet_amd: trlwe_new_KS_key: k = 1 only\n"); abort(); }
-  Torus *flat = (Torus *)xmalloc(sizeof(Torus) * (size_t)t * 2 * N);
-  mosfhet_gen_trlwe_ks_key_flat(flat, in_key->s[0]->coeffs, out_key, t, base_bit);
+/* FFT key-switch keys are encrypted on the device (mosfhet_hip_trlwe_ksk_generate): msgs = the polynomials being switched from, [entries][N] */
+static mosfhet_hip_gak_t fft_ks_keys_new(TRLWE_Key out_key, const Torus *msgs, int entries, int t, int base_bit, const char *who) {
   mosfhet_hip_gak_t dev = NULL;
-  if (mosfhet_hip_trlwe_ksk_create((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, flat, 1, N, t, base_bit)) die("trlwe_new_KS_key");
-  free(flat);
-  return trlwe_ks_header(dev, 0, 1, t, base_bit);
+  if (mosfhet_hip_trlwe_ksk_generate((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, out_key->s[0]->coeffs, out_key->s[0]->N, msgs, entries, t, base_bit,
+                                     out_key->sigma, rnd64()))
+    die(who);
+  return dev;
+}
+
+TRLWE_KS_Key trlwe_new_KS_key(TRLWE_Key out_key, TRLWE_Key in_key, int t, int base_bit) {
+  if (out_key->k != 1 || in_key->k != 1) { fprintf(stderr, "mosfhet_amd: trlwe_new_KS_key: k = 1 only\n"); abort(); }
+  return trlwe_ks_header(fft_ks_keys_new(out_key, in_key->s[0]->coeffs, 1, t, base_bit, "trlwe_new_KS_key"), 0, 1, t, base_bit);
 }
 
 TRLWE_KS_Key *trlwe_new_priv_KS_key(TRLWE_Key out_key, TRLWE_Key in_key, int t, int base_bit) {
   const int N = out_key->s[0]->N;
   if (out_key->k != 1 || in_key->k != 1) { fprintf(stderr, "mosfhet_amd: trlwe_new_priv_KS_key: k = 1 only\n"); abort(); }
-  Torus *flat = (Torus *)xmalloc(sizeof(Torus) * (size_t)2 * t * 2 * N);
-  mosfhet_gen_priv_ks_key_flat(flat, out_key, in_key, t, base_bit);
-  mosfhet_hip_gak_t dev = NULL;
-  if (mosfhet_hip_trlwe_ksk_create((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, flat, 2, N, t, base_bit)) die("trlwe_new_priv_KS_key");
-  free(flat);
+  /* entry 0 switches from -s_out * s_in, entry 1 from -s_out (src/keyswitch.c:39-50) */
+  Torus *msgs = (Torus *)xmalloc(sizeof(Torus) * (size_t)2 * N);
+  memset(msgs, 0, sizeof(Torus) * (size_t)N);
+  for (int i = 0; i < N; i++) msgs[N + i] = (Torus)0 - out_key->s[0]->coeffs[i];
+  negacyclic_mul_addto(msgs, msgs + N, in_key->s[0]->coeffs, N);
+  mosfhet_hip_gak_t dev = fft_ks_keys_new(out_key, msgs, 2, t, base_bit, "trlwe_new_priv_KS_key");
+  free(msgs);
   TRLWE_KS_Key *res = (TRLWE_KS_Key *)xmalloc(sizeof(TRLWE_KS_Key) * 2);
   res[0] = trlwe_ks_header(dev, 0, 1, t, base_bit);   /* entry 0 owns the shared device key set */
   res[1] = trlwe_ks_header(dev, 1, 0, t, base_bit);
@@ -1238,14 +1250,11 @@ void full_domain_functional_bootstrap_KS21_batch(TLWE *out, TorusPolynomial tv, 
 TRLWE_KS_Key trlwe_new_RL_key(TRLWE_Key key, int t, int base_bit) {
   const int N = key->s[0]->N;
   if (key->k != 1) { fprintf(stderr, "mosfhet_amd: trlwe_new_RL_key: k = 1 only\n"); abort(); }
-  Torus *s2 = (Torus *)xmalloc(sizeof(Torus) * (size_t)N), *flat = (Torus *)xmalloc(sizeof(Torus) * (size_t)t * 2 * N);
+  Torus *s2 = (Torus *)xmalloc(sizeof(Torus) * (size_t)N);
   memset(s2, 0, sizeof(Torus) * (size_t)N);
   negacyclic_mul_addto(s2, key->s[0]->coeffs, key->s[0]->coeffs, N);   /* s^2 (src/keyswitch.c:6) */
-  mosfhet_gen_trlwe_ks_key_flat(flat, s2, key, t, base_bit);
-  mosfhet_hip_gak_t dev = NULL;
-  if (mosfhet_hip_trlwe_ksk_create(ectx(), &dev, flat, 1, N, t, base_bit)) die("trlwe_new_RL_key");
+  mosfhet_hip_gak_t dev = fft_ks_keys_new(key, s2, 1, t, base_bit, "trlwe_new_RL_key");
   free(s2);
-  free(flat);
   return trlwe_ks_header(dev, 0, 1, t, base_bit);
 }
 

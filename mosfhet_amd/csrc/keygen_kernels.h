@@ -108,6 +108,47 @@ __global__ __launch_bounds__(256) void trgsw_bk_keygen_kernel(uint64_t *__restri
   }
 }
 
+// FFT-based TRLWE key-switch keys in the torus domain (trlwe_new_KS_key, src/keyswitch.c:12-37; the automorphism key set, :500-511; the private
+// pair, :39-50; the relinearisation key, :3-10 -- they differ only in the polynomial being switched from): entry e, row r < t is
+// TRLWE_{s_out}(msg_e(X) * 2^(64 - (r+1) bb)).  One workgroup per row; the caller transforms the rows afterwards.
+__global__ __launch_bounds__(256) void trlwe_poly_keygen_kernel(uint64_t *__restrict__ rows, const uint64_t *__restrict__ s_out, const uint64_t *__restrict__ msgs,
+                                                              int N, int t, int base_bit, double sigma, uint64_t seed) {
+  extern __shared__ uint64_t sh[];
+  uint64_t *a = sh;
+  uint16_t *ones = reinterpret_cast<uint16_t *>(sh + N);
+  __shared__ int n_ones;
+  const int tid = threadIdx.x;
+  const size_t r = blockIdx.x;
+  const int j = (int)(r % t);
+  const size_t e = r / t;
+  uint64_t *dst = rows + r * 2 * (size_t)N;
+  if (tid == 0) {
+    int cnt = 0;
+    for (int x = 0; x < N; x++)
+      if (s_out[x] & 1) ones[cnt++] = (uint16_t)x;
+    n_ones = cnt;
+  }
+  for (int x = tid; x < N; x += 256) {
+    const uint64_t ax = keygen_mix(seed, r, x, 0);
+    a[x] = ax;
+    dst[x] = ax;
+  }
+  __syncthreads();
+  const int shift = 64 - (j + 1) * base_bit, cnt = n_ones;
+  for (int x = tid; x < N; x += 256) {
+    uint64_t acc = 0;
+    for (int k = 0; k < cnt; k++) {
+      const int p = ones[k], src = x - p;
+      const uint64_t w = a[src & (N - 1)];
+      acc += src < 0 ? (uint64_t)0 - w : w;
+    }
+    const double u1 = ((double)(keygen_mix(seed, r, x, 1) >> 11) + 0.5) * 0x1p-53, u2 = ((double)(keygen_mix(seed, r, x, 2) >> 11) + 0.5) * 0x1p-53;
+    const double z = cos(6.283185307179586 * u1) * sqrt(-2.0 * log(u2)) * sigma;
+    acc += (uint64_t)(int64_t)(18446744073709551616.0 * z);
+    dst[N + x] = acc + (msgs[e * (size_t)N + x] << shift);
+  }
+}
+
 // rows [first_row, first_row + gridDim.x) of a seed-compressed table key in full (`row` words each): the first mask_words regenerated, the
 // rest copied from the stored b part ([rows][row - mask_words])
 __global__ __launch_bounds__(256) void table_expand_kernel(uint64_t *__restrict__ out, const uint64_t *__restrict__ b_rows, int row, int mask_words,

@@ -195,6 +195,15 @@ class Engine:
         _check(lib().mosfhet_hip_trlwe_ksk_create(self.h, C.byref(h), rows.ctypes.data_as(C.c_void_p), entries, N, t, base_bit))
         return AutomorphismKeys(self, h, N, t, base_bit)
 
+    def generate_trlwe_ks_keys(self, s_out, msgs, t, base_bit, sigma, seed):
+        """On-device FFT key-switch key set: entry e switches from the polynomial msgs[e] to the binary key s_out."""
+        s_out = np.ascontiguousarray(s_out, dtype=np.uint64)
+        msgs = np.ascontiguousarray(msgs, dtype=np.uint64).reshape(-1, s_out.size)
+        h = C.c_void_p()
+        _check(lib().mosfhet_hip_trlwe_ksk_generate(self.h, C.byref(h), s_out.ctypes.data_as(C.c_void_p), s_out.size, msgs.ctypes.data_as(C.c_void_p),
+                                                    msgs.shape[0], t, base_bit, C.c_double(sigma), C.c_uint64(seed)))
+        return AutomorphismKeys(self, h, s_out.size, t, base_bit)
+
     def load_packing1_key(self, rows, base_bit):
         """rows: numpy uint64 [n][t][2^bb-1][2][N] -> device LWE -> TRLWE packing key."""
         rows = np.ascontiguousarray(rows, dtype=np.uint64)
