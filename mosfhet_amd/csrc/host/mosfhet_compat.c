@@ -19,6 +19,8 @@
 extern int hipMalloc(void **ptr, size_t size);
 extern int hipFree(void *ptr);
 extern int hipMemcpy(void *dst, const void *src, size_t size, int kind);
+extern int hipHostMalloc(void **ptr, size_t size, unsigned int flags);
+extern int hipHostFree(void *ptr);
 #define HIP_H2D 1
 #define HIP_D2H 2
 
@@ -507,6 +509,7 @@ static void trlwe_from_flat(TRLWE c, const Torus *flat) {
 }
 
 static void tlwe_array_to_flat(Torus *flat, TLWE *c, int count, int n) {
+  if (n < 0) return;
   for (int i = 0; i < count; i++) {
     memcpy(flat + (size_t)i * (n + 1), c[i]->a, sizeof(Torus) * (size_t)n);
     flat[(size_t)i * (n + 1) + n] = c[i]->b;
@@ -514,6 +517,7 @@ static void tlwe_array_to_flat(Torus *flat, TLWE *c, int count, int n) {
 }
 
 static void tlwe_array_from_flat(TLWE *c, const Torus *flat, int count, int n) {
+  if (n < 0) return;
   for (int i = 0; i < count; i++) {
     memcpy(c[i]->a, flat + (size_t)i * (n + 1), sizeof(Torus) * (size_t)n);
     c[i]->b = flat[(size_t)i * (n + 1) + n];
@@ -548,6 +552,44 @@ static void *stage_alloc(size_t bytes) {
   return g_stage;
 }
 static void stage_free(void *p) { (void)p; }
+
+/* Host staging of the wrappers (the flat batches copied to / from the device) is PINNED memory, a few cached buffers per thread: copies of
+ * page-locked memory run at PCIe speed, pageable ones at a fraction of it (the batch entry points move 13 KB per bootstrap).  The wrappers
+ * nest at most two deep; anything beyond the cached slots falls back to ordinary memory. */
+#define HSTAGE_SLOTS 4
+static __thread struct { void *p; size_t bytes; int used; } g_hstage[HSTAGE_SLOTS];
+static pthread_key_t g_hstage_key;
+static pthread_once_t g_hstage_once = PTHREAD_ONCE_INIT;
+static void hstage_release(void *unused) {
+  (void)unused;
+  for (int i = 0; i < HSTAGE_SLOTS; i++)
+    if (g_hstage[i].p) { hipHostFree(g_hstage[i].p); g_hstage[i].p = NULL; }
+}
+static void hstage_key_init(void) { pthread_key_create(&g_hstage_key, hstage_release); }
+static void *hstage_alloc(size_t bytes) {
+  if (!bytes) bytes = 64;
+  for (int i = 0; i < HSTAGE_SLOTS; i++) {
+    if (g_hstage[i].used) continue;
+    if (g_hstage[i].bytes < bytes) {
+      if (g_hstage[i].p) hipHostFree(g_hstage[i].p);
+      g_hstage[i].p = NULL;
+      g_hstage[i].bytes = 0;
+      const size_t want = bytes < 65536 ? 65536 : bytes + bytes / 2;
+      if (hipHostMalloc(&g_hstage[i].p, want, 0) || !g_hstage[i].p) { g_hstage[i].p = NULL; break; }   /* cannot pin: ordinary memory below */
+      g_hstage[i].bytes = want;
+      pthread_once(&g_hstage_once, hstage_key_init);
+      pthread_setspecific(g_hstage_key, g_hstage);      /* non-NULL: the destructor runs at thread exit */
+    }
+    g_hstage[i].used = 1;
+    return g_hstage[i].p;
+  }
+  return xmalloc(bytes);
+}
+static void hstage_free(void *p) {
+  for (int i = 0; i < HSTAGE_SLOTS; i++)
+    if (g_hstage[i].p == p && g_hstage[i].used) { g_hstage[i].used = 0; return; }
+  free(p);
+}
 
 static void dev_copy(void *dst, const void *src, size_t bytes, int kind) {
   if (bytes && hipMemcpy(dst, src, bytes, kind)) {
@@ -655,7 +697,7 @@ static void bootstrap_many(int mode, TLWE *out, TRLWE out_trlwe, TRLWE tv, TLWE 
   const int n = key->n, N = key->N, k = key->k;
   const size_t in_w = (size_t)count * (n + 1), tv_w = (size_t)(k + 1) * N;
   const size_t out_w = (mode == MODE_WO_EXTRACT) ? (size_t)count * tv_w : (size_t)count * (k * N + 1);
-  Torus *h = (Torus *)xmalloc(sizeof(Torus) * (in_w + tv_w + out_w));
+  Torus *h = (Torus *)hstage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
   tlwe_array_to_flat(h, in, count, n);
   trlwe_to_flat(h + in_w, tv);
   Torus *d = (Torus *)stage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
@@ -672,7 +714,7 @@ static void bootstrap_many(int mode, TLWE *out, TRLWE out_trlwe, TRLWE tv, TLWE 
   if (mode == MODE_WO_EXTRACT) trlwe_from_flat(out_trlwe, h + in_w + tv_w);
   else tlwe_array_from_flat(out, h + in_w + tv_w, count, k * N);
   stage_free(d);
-  free(h);
+  hstage_free(h);
 }
 
 void functional_bootstrap_batch(TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_Key key, int torus_base) {
@@ -707,7 +749,7 @@ void full_domain_functional_bootstrap_batch(TLWE *out, TRLWE tv, TLWE *in, int c
   mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
   const int n = key->n, N = key->N, k = key->k;
   const size_t in_w = (size_t)count * (n + 1), tv_w = (size_t)(k + 1) * N, out_w = (size_t)count * (k * N + 1);
-  Torus *h = (Torus *)xmalloc(sizeof(Torus) * (in_w + tv_w + out_w));
+  Torus *h = (Torus *)hstage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
   tlwe_array_to_flat(h, in, count, n);
   trlwe_to_flat(h + in_w, tv);
   Torus *d = (Torus *)stage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
@@ -719,7 +761,7 @@ void full_domain_functional_bootstrap_batch(TLWE *out, TRLWE tv, TLWE *in, int c
   dev_copy(h + in_w + tv_w, d + in_w + tv_w, sizeof(Torus) * out_w, HIP_D2H);
   tlwe_array_from_flat(out, h + in_w + tv_w, count, k * N);
   stage_free(d);
-  free(h);
+  hstage_free(h);
 }
 
 void full_domain_functional_bootstrap(TLWE out, TRLWE tv, TLWE in, Bootstrap_Key key, TLWE_KS_Key ksk, int precision) {
@@ -730,7 +772,7 @@ void multivalue_bootstrap_CLOT21(TLWE *out, TRLWE tv, TLWE in, Bootstrap_Key key
   mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
   const int n = key->n, N = key->N, k = key->k;
   const size_t in_w = (size_t)(n + 1), tv_w = (size_t)(k + 1) * N, out_w = (size_t)n_luts * (k * N + 1);
-  Torus *h = (Torus *)xmalloc(sizeof(Torus) * (in_w + tv_w + out_w));
+  Torus *h = (Torus *)hstage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
   tlwe_array_to_flat(h, &in, 1, n);
   trlwe_to_flat(h + in_w, tv);
   Torus *d = (Torus *)stage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
@@ -742,7 +784,7 @@ void multivalue_bootstrap_CLOT21(TLWE *out, TRLWE tv, TLWE in, Bootstrap_Key key
   dev_copy(h + in_w + tv_w, d + in_w + tv_w, sizeof(Torus) * out_w, HIP_D2H);
   tlwe_array_from_flat(out, h + in_w + tv_w, n_luts, k * N);
   stage_free(d);
-  free(h);
+  hstage_free(h);
 }
 
 void blind_rotate(TRLWE tv, Torus *a, TRGSW_DFT *s, int size) {
@@ -759,7 +801,7 @@ void blind_rotate(TRLWE tv, Torus *a, TRGSW_DFT *s, int size) {
   mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
   const int n = key->n, N = key->N, k = key->k;
   const size_t acc_w = (size_t)(k + 1) * N;
-  Torus *h = (Torus *)xmalloc(sizeof(Torus) * (acc_w + n + 1));
+  Torus *h = (Torus *)hstage_alloc(sizeof(Torus) * (acc_w + n + 1));
   trlwe_to_flat(h, tv);
   memcpy(h + acc_w, a, sizeof(Torus) * (size_t)n);
   h[acc_w + n] = 0;
@@ -771,7 +813,7 @@ void blind_rotate(TRLWE tv, Torus *a, TRGSW_DFT *s, int size) {
   dev_copy(h, d, sizeof(Torus) * acc_w, HIP_D2H);
   trlwe_from_flat(tv, h);
   stage_free(d);
-  free(h);
+  hstage_free(h);
 }
 
 /* ------------------------------------------------------------------ Galois-automorphism bootstrap */
@@ -856,7 +898,7 @@ static void bootstrap_ga_many(TLWE *out, TRLWE out_trlwe, TRLWE tv, TLWE *in, in
   const int n = key->n, N = key->N, extract = out != NULL;
   const size_t in_w = (size_t)count * (n + 1), tv_w = (size_t)2 * N;
   const size_t out_w = extract ? (size_t)count * (N + 1) : (size_t)count * tv_w;
-  Torus *h = (Torus *)xmalloc(sizeof(Torus) * (in_w + tv_w + out_w));
+  Torus *h = (Torus *)hstage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
   tlwe_array_to_flat(h, in, count, n);
   trlwe_to_flat(h + in_w, tv);
   Torus *d = (Torus *)stage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
@@ -869,7 +911,7 @@ static void bootstrap_ga_many(TLWE *out, TRLWE out_trlwe, TRLWE tv, TLWE *in, in
   if (extract) tlwe_array_from_flat(out, h + in_w + tv_w, count, N);
   else trlwe_from_flat(out_trlwe, h + in_w + tv_w);
   stage_free(d);
-  free(h);
+  hstage_free(h);
 }
 
 void functional_bootstrap_ga_batch(TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_GA_Key key, int torus_base) {
@@ -952,7 +994,7 @@ void tlwe_keyswitch_batch(TLWE *out, TLWE *in, int count, TLWE_KS_Key ks) {
   mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
   const int n_in = ks->n, n_out = out[0]->n;
   const size_t in_w = (size_t)count * (n_in + 1), out_w = (size_t)count * (n_out + 1);
-  Torus *h = (Torus *)xmalloc(sizeof(Torus) * (in_w + out_w));
+  Torus *h = (Torus *)hstage_alloc(sizeof(Torus) * (in_w + out_w));
   tlwe_array_to_flat(h, in, count, n_in);
   Torus *d = (Torus *)stage_alloc(sizeof(Torus) * (in_w + out_w));
   dev_copy(d, h, sizeof(Torus) * in_w, HIP_H2D);
@@ -961,7 +1003,7 @@ void tlwe_keyswitch_batch(TLWE *out, TLWE *in, int count, TLWE_KS_Key ks) {
   dev_copy(h + in_w, d + in_w, sizeof(Torus) * out_w, HIP_D2H);
   tlwe_array_from_flat(out, h + in_w, count, n_out);
   stage_free(d);
-  free(h);
+  hstage_free(h);
 }
 
 void tlwe_keyswitch(TLWE out, TLWE in, TLWE_KS_Key ks_key) { tlwe_keyswitch_batch(&out, &in, 1, ks_key); }
@@ -1055,7 +1097,7 @@ static void trlwe_ks_run(int mode, TRLWE out, TRLWE in, TRLWE_KS_Key key) {
   mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
   const int N = in->b->N;
   const size_t w = (size_t)2 * N;
-  Torus *h = (Torus *)xmalloc(sizeof(Torus) * w);
+  Torus *h = (Torus *)hstage_alloc(sizeof(Torus) * w);
   trlwe_to_flat(h, in);
   Torus *d = (Torus *)stage_alloc(sizeof(Torus) * 2 * w);
   dev_copy(d, h, sizeof(Torus) * w, HIP_H2D);
@@ -1065,7 +1107,7 @@ static void trlwe_ks_run(int mode, TRLWE out, TRLWE in, TRLWE_KS_Key key) {
   dev_copy(h, d + w, sizeof(Torus) * w, HIP_D2H);
   trlwe_from_flat(out, h);
   stage_free(d);
-  free(h);
+  hstage_free(h);
 }
 
 void trlwe_keyswitch(TRLWE out, TRLWE in, TRLWE_KS_Key ks_key) { trlwe_ks_run(0, out, in, ks_key); }
@@ -1106,7 +1148,7 @@ void trlwe_packing1_keyswitch(TRLWE out, TLWE in, Generic_KS_Key ks) {
   mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
   const int N = out->b->N, n = ks->n;
   const size_t in_w = (size_t)n + 1, out_w = (size_t)2 * N;
-  Torus *h = (Torus *)xmalloc(sizeof(Torus) * (in_w + out_w));
+  Torus *h = (Torus *)hstage_alloc(sizeof(Torus) * (in_w + out_w));
   tlwe_array_to_flat(h, &in, 1, n);
   Torus *d = (Torus *)stage_alloc(sizeof(Torus) * (in_w + out_w));
   dev_copy(d, h, sizeof(Torus) * in_w, HIP_H2D);
@@ -1115,14 +1157,14 @@ void trlwe_packing1_keyswitch(TRLWE out, TLWE in, Generic_KS_Key ks) {
   dev_copy(h + in_w, d + in_w, sizeof(Torus) * out_w, HIP_D2H);
   trlwe_from_flat(out, h + in_w);
   stage_free(d);
-  free(h);
+  hstage_free(h);
 }
 
 void circuit_bootstrap_3_batch(TRGSW *out, TLWE *in, int count, Bootstrap_Key key, TRLWE_KS_Key *kska, Generic_KS_Key kskb) {
   mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
   const int n = key->n, N = key->N, l = key->l;
   const size_t in_w = (size_t)count * (n + 1), row = (size_t)2 * N, out_w = (size_t)count * 2 * l * row;
-  Torus *h = (Torus *)xmalloc(sizeof(Torus) * (in_w + out_w));
+  Torus *h = (Torus *)hstage_alloc(sizeof(Torus) * (in_w + out_w));
   tlwe_array_to_flat(h, in, count, n);
   Torus *d = (Torus *)stage_alloc(sizeof(Torus) * (in_w + out_w));
   dev_copy(d, h, sizeof(Torus) * in_w, HIP_H2D);
@@ -1134,7 +1176,7 @@ void circuit_bootstrap_3_batch(TRGSW *out, TLWE *in, int count, Bootstrap_Key ke
   for (int b = 0; b < count; b++)
     for (int q = 0; q < 2 * l; q++) trlwe_from_flat(out[b]->samples[q], h + in_w + ((size_t)b * 2 * l + q) * row);
   stage_free(d);
-  free(h);
+  hstage_free(h);
 }
 
 void circuit_bootstrap_3(TRGSW out, TLWE in, Bootstrap_Key key, TRLWE_KS_Key *kska, Generic_KS_Key kskb) {
@@ -1146,13 +1188,13 @@ typedef struct { Torus *h, *d; size_t words; } Buf;
 static Buf buf_new(size_t words) {
   Buf b;
   b.words = words;
-  b.h = (Torus *)xmalloc(sizeof(Torus) * (words ? words : 1));
+  b.h = (Torus *)hstage_alloc(sizeof(Torus) * (words ? words : 1));
   b.d = (Torus *)stage_alloc(sizeof(Torus) * (words ? words : 1));
   return b;
 }
 static void buf_up(Buf *b, size_t off, size_t words) { dev_copy(b->d + off, b->h + off, sizeof(Torus) * words, HIP_H2D); }
 static void buf_down(Buf *b, size_t off, size_t words) { dev_copy(b->h + off, b->d + off, sizeof(Torus) * words, HIP_D2H); }
-static void buf_free(Buf *b) { stage_free(b->d); free(b->h); }
+static void buf_free(Buf *b) { stage_free(b->d); hstage_free(b->h); }
 static mosfhet_hip_ctx_t ectx(void) { return (mosfhet_hip_ctx_t)mosfhet_engine_ctx(); }
 static void check_rc(int rc, const char *what) { if (rc || mosfhet_hip_ctx_sync(ectx(), NULL)) die(what); }
 

@@ -17,5 +17,14 @@ int main(void) {
   const double t0 = now();
   for (int i = 0; i < 50; i++) programmable_bootstrap(out, tv, in, bk, 3, 0, 0);
   printf("programmable_bootstrap(out, tv, in, bk, 3, 0, 0): %.3f ms per call (single sample, host structs in and out)\n", (now() - t0) / 50);
+  /* the batch entry with host structs: marshalling + copies + kernel */
+  enum { B = 4096 };
+  TLWE *ins = tlwe_alloc_sample_array(B, 585), *outs = tlwe_alloc_sample_array(B, 1024);
+  for (int i = 0; i < B; i++) tlwe_sample(ins[i], double2torus((i % 4) / 8.), lk);
+  programmable_bootstrap_batch(outs, tv, ins, B, bk, 3, 0, 0);
+  const double t1 = now();
+  for (int i = 0; i < 5; i++) programmable_bootstrap_batch(outs, tv, ins, B, bk, 3, 0, 0);
+  const double ms = (now() - t1) / 5;
+  printf("programmable_bootstrap_batch, %d samples: %.2f ms per call = %.1f k bootstraps/s (host structs in and out)\n", B, ms, B / ms);
   return 0;
 }
