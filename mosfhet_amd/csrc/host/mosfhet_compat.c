@@ -20,6 +20,9 @@ extern int hipMalloc(void **ptr, size_t size);
 extern int hipFree(void *ptr);
 extern int hipMemcpy(void *dst, const void *src, size_t size, int kind);
 extern int hipHostMalloc(void **ptr, size_t size, unsigned int flags);
+extern int hipStreamCreate(void **stream);
+extern int hipStreamSynchronize(void *stream);
+extern int hipMemcpyAsync(void *dst, const void *src, size_t size, int kind, void *stream);
 extern int hipHostFree(void *ptr);
 #define HIP_H2D 1
 #define HIP_D2H 2
@@ -690,8 +693,54 @@ void free_bootstrap_key(Bootstrap_Key key) {
 /* ------------------------------------------------------------------ bootstraps (GPU) */
 enum { MODE_FUNCTIONAL, MODE_PROGRAMMABLE, MODE_WO_EXTRACT };
 
+/* Large batches are pipelined in chunks over two streams of the calling thread: while the GPU bootstraps chunk c, the host packs chunk c + 1 into
+ * the pinned staging buffer and unpacks the results of chunk c - 1 (the pointer-chasing TLWE arrays cost about as much host time as the PCIe
+ * copies).  Chunks of 2048 keep every launch at full occupancy. */
+#define PIPE_CHUNK 2048
+static __thread void *g_pipe_streams[2];
+static void bootstrap_pipelined(int mode, TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_Key key, int a0, int kappa, int theta) {
+  mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
+  mosfhet_hip_bsk_t bsk = (mosfhet_hip_bsk_t)mosfhet_bootstrap_key_device(key);
+  const int n = key->n, N = key->N, k = key->k;
+  const size_t in_row = (size_t)n + 1, out_row = (size_t)k * N + 1, tv_w = (size_t)(k + 1) * N;
+  const size_t in_w = (size_t)count * in_row, out_w = (size_t)count * out_row;
+  for (int i = 0; i < 2; i++)
+    if (!g_pipe_streams[i] && hipStreamCreate(&g_pipe_streams[i])) die("bootstrap (stream)");
+  Torus *h = (Torus *)hstage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
+  Torus *d = (Torus *)stage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
+  Torus *h_tv = h + in_w, *h_out = h + in_w + tv_w, *d_tv = d + in_w, *d_out = d + in_w + tv_w;
+  trlwe_to_flat(h_tv, tv);
+  dev_copy(d_tv, h_tv, sizeof(Torus) * tv_w, HIP_H2D);
+  int prev_lo = -1, prev_c = 0;
+  for (int lo = 0, c = 0; lo < count; lo += PIPE_CHUNK, c++) {
+    const int cnt = count - lo < PIPE_CHUNK ? count - lo : PIPE_CHUNK;
+    void *st = g_pipe_streams[c & 1];
+    tlwe_array_to_flat(h + (size_t)lo * in_row, in + lo, cnt, n);
+    if (hipMemcpyAsync(d + (size_t)lo * in_row, h + (size_t)lo * in_row, sizeof(Torus) * (size_t)cnt * in_row, HIP_H2D, st)) die("bootstrap (copy in)");
+    const int rc = mode == MODE_PROGRAMMABLE
+                       ? mosfhet_hip_programmable_bootstrap_batch(ctx, bsk, d_out + (size_t)lo * out_row, d_tv, 1, d + (size_t)lo * in_row, cnt, a0, kappa, theta, st)
+                       : mosfhet_hip_functional_bootstrap_batch(ctx, bsk, d_out + (size_t)lo * out_row, d_tv, 1, d + (size_t)lo * in_row, cnt, a0, st);
+    if (rc) die("bootstrap");
+    if (hipMemcpyAsync(h_out + (size_t)lo * out_row, d_out + (size_t)lo * out_row, sizeof(Torus) * (size_t)cnt * out_row, HIP_D2H, st)) die("bootstrap (copy out)");
+    if (prev_lo >= 0) {   /* the previous chunk's results: wait for its stream, unpack while this chunk runs */
+      if (hipStreamSynchronize(g_pipe_streams[prev_c & 1])) die("bootstrap");
+      tlwe_array_from_flat(out + prev_lo, h_out + (size_t)prev_lo * out_row, lo - prev_lo, k * N);
+    }
+    prev_lo = lo;
+    prev_c = c;
+  }
+  if (hipStreamSynchronize(g_pipe_streams[prev_c & 1])) die("bootstrap");
+  tlwe_array_from_flat(out + prev_lo, h_out + (size_t)prev_lo * out_row, count - prev_lo, k * N);
+  stage_free(d);
+  hstage_free(h);
+}
+
 static void bootstrap_many(int mode, TLWE *out, TRLWE out_trlwe, TRLWE tv, TLWE *in, int count, Bootstrap_Key key,
                            int a0, int kappa, int theta) {
+  if (mode != MODE_WO_EXTRACT && count >= 2 * PIPE_CHUNK) {
+    bootstrap_pipelined(mode, out, tv, in, count, key, a0, kappa, theta);
+    return;
+  }
   mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
   mosfhet_hip_bsk_t bsk = (mosfhet_hip_bsk_t)mosfhet_bootstrap_key_device(key);
   const int n = key->n, N = key->N, k = key->k;

@@ -578,6 +578,31 @@ static void case_other_rings(void) {
   }
 }
 
+/* batches past two pipeline chunks (the layer overlaps host packing / unpacking and the copies with the kernels, csrc/host/mosfhet_compat.c:
+ * bootstrap_pipelined): every output decrypts, and the outputs equal those of the same samples bootstrapped one by one */
+static void case_big_batch(void) {
+  enum { COUNT = 2 * 2048 + 37 };
+  Torus lut[4] = {int2torus(3, 4), int2torus(7, 4), int2torus(11, 4), int2torus(15, 4)};
+  TRLWE tv = trlwe_alloc_new_sample(k, N);
+  trlwe_torus_packing(tv, lut, 4);
+  TLWE *in = tlwe_alloc_sample_array(COUNT, n), *out = tlwe_alloc_sample_array(COUNT, N);
+  for (int i = 0; i < COUNT; i++) tlwe_sample(in[i], double2torus((i % 4) / 8.), lwe_key);
+  programmable_bootstrap_batch(out, tv, in, COUNT, bk, 3, 0, 0);
+  int bad = 0;
+  for (int i = 0; i < COUNT; i++) bad += tdist(lut[i % 4], tlwe_phase(out[i], extracted_key)) >= (1ULL << 58);
+  CHECK(bad == 0, "%d of %d outputs of the pipelined batch do not decrypt", bad, COUNT);
+  const int probe[6] = {0, 2047, 2048, 4095, 4096, COUNT - 1};
+  TLWE one = tlwe_alloc_sample(N);
+  for (int q = 0; q < 6; q++) {
+    programmable_bootstrap(one, tv, in[probe[q]], bk, 3, 0, 0);
+    CHECK(same_tlwe(one, out[probe[q]]), "sample %d of the pipelined batch differs from its single call", probe[q]);
+  }
+  functional_bootstrap_batch(out, tv, in, COUNT, bk, 4);
+  functional_bootstrap(one, tv, in[2049], bk, 4);
+  CHECK(same_tlwe(one, out[2049]), "functional_bootstrap_batch (pipelined) differs from the single call");
+  free_tlwe(one); free_tlwe_array(in, COUNT); free_tlwe_array(out, COUNT); free_trlwe(tv);
+}
+
 int main(int argc, char **argv) {
   setvbuf(stdout, NULL, _IOLBF, 0);
   mosfhet_seed(0x4D4F5346);
@@ -595,7 +620,7 @@ int main(int argc, char **argv) {
     {"fdfb_variants", case_fdfb_variants},               {"multivalue_phases", case_multivalue_phases},
     {"circuit_2+mux+trgsw", case_circuit_2_mux_trgsw},   {"radix_integer_add", case_radix_integer_add},
     {"key_files", case_key_files},                       {"threads", case_threads},
-    {"other_rings", case_other_rings},
+    {"other_rings", case_other_rings},                   {"big_batch", case_big_batch},
   };
   for (unsigned i = 0; i < sizeof(cases) / sizeof(cases[0]); i++) {
     if (argc > 1 && strcmp(argv[1], cases[i].name)) continue;
