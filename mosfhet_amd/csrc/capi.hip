@@ -194,6 +194,12 @@ extern "C" int mosfhet_hip_ctx_create(mosfhet_hip_ctx_t *out, int device) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(MOSFHET_HIP_ENODEV, "no HIP device visible (this library has no CPU fallback)");
   if (device < 0 || device >= ndev) return fail(MOSFHET_HIP_EINVAL, "ctx_create: device %d of %d", device, ndev);
+  {
+    // the library carries gfx950 code objects only: say so instead of failing at the first launch
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+      return fail(MOSFHET_HIP_ENODEV, "device %d is %s: this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+  }
   HIP_TRY(hipSetDevice(device));
   std::unique_ptr<mosfhet_hip_ctx> c(new mosfhet_hip_ctx());
   c->device = device;
