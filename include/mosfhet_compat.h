@@ -7,9 +7,9 @@
  * reference's names, argument order and error behaviour (void; abort with a message on failure, as the
  * reference's assert / safe_malloc do, src/misc.c:104-128), so a program written against mosfhet.h for this
  * path re-links against libmosfhet_hip.so unchanged.  What differs, by design:
- *   - DFT-domain objects are device resident: Bootstrap_Key.s is an opaque token for the engine's key
- *     (reference: array of host TRGSW_DFT, include/mosfhet.h:129-133), and TLWE_KS_Key additionally owns a
- *     device copy of its table;
+ *   - DFT-domain objects (DFT_Polynomial, TRLWE_DFT, TRGSW_DFT, the entries of Bootstrap_Key.s) keep the reference's struct shapes, but
+ *     their `coeffs` point to DEVICE memory in the engine's own element order -- as in the reference, where DFT contents are private to the FFT
+ *     back-end (src/polynomial.c:336-357), host code must not read them; TLWE_KS_Key additionally owns a device copy of its table;
  *   - every bootstrap / key switch runs on the GPU through include/mosfhet_hip.h; there is no CPU path;
  *   - new *_batch entry points take arrays of samples (the reference has no batching API; its callers loop,
  *     e.g. applications/multi-ciphertext-arith/src/lut.c:12-17);
@@ -19,6 +19,7 @@
  */
 #ifndef MOSFHET_COMPAT_H
 #define MOSFHET_COMPAT_H
+#include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
 #ifdef __cplusplus
@@ -40,11 +41,14 @@ typedef struct _TLWE_KS_Key { TLWE ***s; int base_bit, t, n;                    
 typedef struct _TRLWE { TorusPolynomial *a, b; int k; } *TRLWE;                      /* mosfhet.h:73-76 */
 typedef struct _TRLWE_Key { IntPolynomial *s; DFT_Polynomial *s_dft; int k; double sigma; } *TRLWE_Key; /* mosfhet.h:83-88 */
 
+typedef struct _TRLWE_DFT { DFT_Polynomial *a, b; int k; } *TRLWE_DFT;               /* mosfhet.h:78-81; coefficients in device memory */
 typedef struct _TRGSW { TRLWE *samples; int l, Bg_bit; } *TRGSW;                     /* mosfhet.h:106-109 */
-typedef struct _TRGSW_DFT *TRGSW_DFT;                                                /* opaque: device resident */
+typedef struct _TRGSW_DFT { TRLWE_DFT *samples; int l, Bg_bit; } *TRGSW_DFT;         /* mosfhet.h:111-114; one device block per sample (or array) */
 typedef struct _TRGSW_Key { TRLWE_Key trlwe_key; int l, Bg_bit; } *TRGSW_Key;        /* mosfhet.h:116-119 */
 
-typedef struct _Bootstrap_Key { TRGSW_DFT *s; TRGSW *su; int n, k, N, Bg_bit, l, unfolding; } *Bootstrap_Key; /* mosfhet.h:129-133 */
+/* mosfhet.h:129-133.  s[i] (unfolding 1) are views of the device-resident key, usable wherever the reference takes a TRGSW_DFT; su is NULL (an
+ * unfolded key's samples live on the device as well).  `device` (appended) is the engine's key handle. */
+typedef struct _Bootstrap_Key { TRGSW_DFT *s; TRGSW *su; int n, k, N, Bg_bit, l, unfolding; void *device; } *Bootstrap_Key;
 
 /* ---- engine control (new) ---- */
 void mosfhet_seed(uint64_t seed);              /* reseed the host generator used by all *_sample / *_key functions */
@@ -60,7 +64,35 @@ Torus int2torus(uint64_t x, int log_scale);
 
 /* ---- polynomials (src/polynomial.c:3-53) ---- */
 TorusPolynomial polynomial_new_torus_polynomial(int N);
-void free_polynomial(void *p);
+void free_polynomial(void *p);                                     /* torus- and DFT-domain polynomials alike, as in the reference */
+void *safe_malloc(size_t size);                                    /* src/misc.c:104-113 */
+void *safe_aligned_malloc(size_t size);                            /* src/misc.c:115-128 */
+void generate_random_bytes(uint64_t amount, uint8_t *pointer);     /* src/misc.c:79-82 (here: the host layer's ChaCha20 stream) */
+double generate_normal_random(double sigma);                       /* src/misc.c:87-91 */
+void generate_torus_normal_random_array(Torus *out, double sigma, int N);   /* src/misc.c:93-97 */
+void generate_rnd_seed(uint64_t *p);                               /* src/misc.c:34-49 */
+
+/* ---- DFT-level functions (src/polynomial.c:336-426, src/trlwe.c:622-634, src/trgsw.c:345-357,385-423)  -> GPU.
+ * The legacy signatures of SURVEY 8(b): every object named *_DFT lives in device memory; each call copies its torus-domain arguments in or out
+ * and waits for its result, like the single-sample bootstrap entry points.  Batched work belongs on include/mosfhet_hip.h. ---- */
+void init_fft(int N);                                                              /* polynomial.c:341-356: starts the engine; N in {1024, 2048, 4096} */
+DFT_Polynomial polynomial_new_DFT_polynomial(int N);                               /* polynomial.c:12-19 */
+DFT_Polynomial *polynomial_new_array_of_polynomials_DFT(int N, int size);          /* polynomial.c:21-27 */
+void free_DFT_polynomial(DFT_Polynomial p);                                        /* polynomial.c:47-53 */
+void free_array_of_polynomials(void *p, int size);                                 /* polynomial.c:27-33 */
+void polynomial_torus_to_DFT(DFT_Polynomial out, TorusPolynomial in);              /* polynomial.c:368-375 */
+void polynomial_DFT_to_torus(TorusPolynomial out, const DFT_Polynomial in);        /* polynomial.c:359-366 */
+void polynomial_mul_DFT(DFT_Polynomial out, DFT_Polynomial in1, DFT_Polynomial in2);        /* polynomial.c:379-400 */
+void polynomial_mul_addto_DFT(DFT_Polynomial out, DFT_Polynomial in1, DFT_Polynomial in2);  /* polynomial.c:404-426 */
+void polynomial_copy_DFT_polynomial(DFT_Polynomial out, DFT_Polynomial in);
+TRLWE_DFT trlwe_alloc_new_DFT_sample(int k, int N);                                /* trlwe.c:54-64 */
+TRLWE_DFT *trlwe_alloc_new_DFT_sample_array(int count, int k, int N);              /* trlwe.c:66-72 */
+void trlwe_to_DFT(TRLWE_DFT out, TRLWE in);                                        /* trlwe.c:622-627 */
+void trlwe_from_DFT(TRLWE out, TRLWE_DFT in);                                      /* trlwe.c:629-634 */
+TRGSW_DFT trgsw_alloc_new_DFT_sample(int l, int Bg_bit, int k, int N);             /* trgsw.c:61-72 */
+TRGSW_DFT *trgsw_alloc_new_DFT_sample_array(int count, int l, int Bg_bit, int k, int N);   /* trgsw.c:74-80: one contiguous device block */
+void trgsw_to_DFT(TRGSW_DFT out, TRGSW in);                                        /* trgsw.c:345-349 */
+void trgsw_mul_trlwe_DFT(TRLWE_DFT out, TRLWE in1, TRGSW_DFT in2);                 /* trgsw.c:385-423: the external product, result in the DFT domain */
 
 /* ---- TLWE (src/tlwe.c) ---- */
 TLWE_Key tlwe_alloc_key(int n, double sigma);                     /* :60-67 */
@@ -93,7 +125,10 @@ TRLWE_Key trlwe_alloc_key(int N, int k, double sigma);            /* :104-116 */
 TRLWE_Key trlwe_new_binary_key(int N, int k, double sigma);       /* :132-134 */
 void free_trlwe_key(TRLWE_Key key);
 TRLWE trlwe_alloc_new_sample(int k, int N);                       /* :3-13 */
-void free_trlwe(void *p);                                         /* :86-94 */
+TRLWE *trlwe_alloc_new_sample_array(int count, int k, int N);     /* :15-21 */
+void free_trlwe(void *p);                                         /* :86-94 (TRLWE and TRLWE_DFT) */
+void free_trlwe_array(void *p, int count);                        /* :96-102 */
+TRLWE trlwe_new_sample(TorusPolynomial m, TRLWE_Key key);         /* :318-322 */
 void trlwe_noiseless_trivial_sample(TRLWE out, TorusPolynomial m);/* :273-283 */
 TRLWE trlwe_new_noiseless_trivial_sample(TorusPolynomial m, int k, int N);
 void trlwe_sample(TRLWE out, TorusPolynomial m, TRLWE_Key key);   /* :296-316 */
@@ -119,7 +154,9 @@ void trlwe_mv_extract_tlwe_scaling_subto(TLWE out, TRLWE in, int scale);  /* :61
 TRGSW_Key trgsw_new_key(TRLWE_Key trlwe_key, int l, int Bg_bit);  /* :20-27 */
 void free_trgsw_key(TRGSW_Key key);
 TRGSW trgsw_alloc_new_sample(int l, int Bg_bit, int k, int N);    /* :48-59 */
-void free_trgsw(void *p);
+void free_trgsw(void *p);                                         /* TRGSW and TRGSW_DFT */
+void free_trgsw_array(void *p, int count);                        /* :137-143 */
+TRGSW *trgsw_alloc_new_sample_array(int count, int l, int Bg_bit, int k, int N);   /* :82-88 */
 void trgsw_monomial_sample(TRGSW out, int64_t m, int e, TRGSW_Key key);   /* :152-168 */
 
 /* ---- bootstrap (src/bootstrap.c)  -> GPU ---- */
@@ -135,11 +172,17 @@ void multivalue_bootstrap_CLOT21(TLWE *out, TRLWE tv, TLWE in, Bootstrap_Key key
 void trlwe_torus_packing_many_LUT(TRLWE out, Torus *in, int lut_size, int n_luts);   /* src/trlwe.c:677-687 (host) */
 
 /* ---- bootstrap with Galois automorphisms (src/bootstrap_ga.c)  -> GPU ---- */
-typedef struct _Bootstrap_GA_Key { TRGSW_DFT *s; TRGSW *su; void **ak; int n, k, N, Bg_bit, l, unfolding; } *Bootstrap_GA_Key; /* mosfhet.h:135-140; s, ak opaque */
+typedef struct _TRLWE_KS_Key { void **s; int base_bit, t, k;                          /* mosfhet.h:90-93 */
+                               void *device; int entry, owner; } *TRLWE_KS_Key;        /* + engine handle (appended) */
+/* mosfhet.h:135-140: s[i] views of the device key, ak[j] = key of generator 2j + 1 (N headers sharing one device key set) */
+typedef struct _Bootstrap_GA_Key { TRGSW_DFT *s; TRGSW *su; TRLWE_KS_Key *ak; int n, k, N, Bg_bit, l, unfolding; void *device, *ak_device; } *Bootstrap_GA_Key;
 Bootstrap_GA_Key new_bootstrap_key_ga(TRGSW_Key out_key, TLWE_Key in_key);                                   /* :5-24 */
 void free_bootstrap_key_ga(Bootstrap_GA_Key key);                                                            /* :26-33 */
 void functional_bootstrap_wo_extract_ga(TRLWE out, TRLWE tv, TLWE in, Bootstrap_GA_Key key, int torus_base); /* :62-68 */
 void functional_bootstrap_ga(TLWE out, TRLWE tv, TLWE in, Bootstrap_GA_Key key, int torus_base);             /* :70-76 */
+void blind_rotate_ga(TRLWE tv, Torus *a, TRGSW_DFT *s, TRLWE_KS_Key *ak, int size);                          /* :35-60; s and ak from one Bootstrap_GA_Key */
+void trlwe_eval_automorphism(TRLWE out, TRLWE in, uint64_t gen, TRLWE_KS_Key ks_key);                        /* src/trlwe.c:775-781 */
+uint16_t inverse_mod_2N(uint16_t x, uint16_t N);                                                             /* src/misc.c:142-159 (host) */
 void functional_bootstrap_ga_batch(TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_GA_Key key, int torus_base);  /* new */
 void polynomial_permute(TorusPolynomial out, TorusPolynomial in, uint64_t gen);                               /* src/polynomial.c:442-450 (host) */
 void mosfhet_gen_bootstrap_key_ga_flat(Torus *out /*[n][(k+1)l][k+1][N]*/, TRGSW_Key out_key, TLWE_Key in_key);       /* BK_i = TRGSW(X^{s_i}) */
@@ -149,8 +192,6 @@ void mosfhet_gen_automorphism_keyset_flat(Torus *out /*[N][t][2][N]*/, TRLWE_Key
  * Both key types are device resident: `s` is NULL (reference: host arrays of TRLWE_DFT / TRLWE, mosfhet.h:90-103) and
  * `device` holds the engine handle.  A TRLWE_KS_Key array returned by trlwe_new_priv_KS_key shares ONE device key set
  * (entry = index in the set), as the automorphism keys do. */
-typedef struct _TRLWE_KS_Key { void **s; int base_bit, t, k;                          /* mosfhet.h:90-93 */
-                               void *device; int entry, owner; } *TRLWE_KS_Key;        /* + engine handle (appended) */
 typedef struct _Generic_KS_Key { TRLWE ***s; int base_bit, t, n, include_b;            /* mosfhet.h:100-103 */
                                  void *device; } *Generic_KS_Key;                      /* + engine handle (appended) */
 TRLWE_KS_Key trlwe_new_KS_key(TRLWE_Key out_key, TRLWE_Key in_key, int t, int base_bit);         /* keyswitch.c:12-37 */
@@ -173,8 +214,7 @@ void trlwe_priv_keyswitch(TRLWE out, TLWE in, Generic_KS_Key ks_key);           
 void circuit_bootstrap(TRGSW out, TLWE in, Bootstrap_Key key, Generic_KS_Key kska, Generic_KS_Key kskb);   /* bootstrap.c:309-322 */
 void circuit_bootstrap_2(TRGSW out, TLWE in, Bootstrap_Key key, Generic_KS_Key kska, Generic_KS_Key kskb); /* bootstrap.c:324-344 */
 void circuit_bootstrap_2_batch(TRGSW *out, TLWE *in, int count, Bootstrap_Key key, Generic_KS_Key kska, Generic_KS_Key kskb); /* new */
-/* public_mux: `selector` is an array of l torus-domain TRLWEs (reference: TRLWE_DFT *, bootstrap.c:369; the transform is fused on the GPU) */
-void public_mux(TRLWE out, TorusPolynomial p0, TorusPolynomial p1, TRLWE *selector, int l, int Bg_bit);    /* bootstrap.c:369-389 */
+void public_mux(TRLWE out, TorusPolynomial p0, TorusPolynomial p1, TRLWE_DFT *selector, int l, int Bg_bit);   /* bootstrap.c:369-389 */
 void full_domain_functional_bootstrap_KS21(TLWE out, TorusPolynomial tv, TLWE in, Bootstrap_Key key, Generic_KS_Key ksk, int torus_base);   /* :391-432 */
 void full_domain_functional_bootstrap_KS21_2(TLWE out, TorusPolynomial tv, TLWE in, Bootstrap_Key key, Generic_KS_Key ksk, int torus_base); /* :434-463 */
 void full_domain_functional_bootstrap_KS21_batch(TLWE *out, TorusPolynomial tv, TLWE *in, int count, Bootstrap_Key key, Generic_KS_Key ksk, int torus_base); /* new */
@@ -187,8 +227,6 @@ void full_domain_functional_bootstrap_CLOT21_2_batch(TLWE *out, Torus *tv, TLWE 
                                                      int precision);                                       /* new */
 void multivalue_bootstrap_phase1(TRLWE *out, TLWE in, Bootstrap_Key key, int torus_base);                  /* bootstrap.c:232-243 */
 void multivalue_bootstrap_phase2(TLWE out, int *in, TRLWE *rotated_tv, int torus_base, int log_torus_base);/* bootstrap.c:245-265 */
-TRGSW_DFT trgsw_alloc_new_DFT_sample(int l, int Bg_bit, int k, int N);                                     /* trgsw.c:61-72; device resident */
-void free_trgsw_DFT(TRGSW_DFT p);                                                                          /* (reference: free_trgsw) */
 void functional_bootstrap_trgsw_phase1(TRGSW_DFT out, TLWE in, Bootstrap_Key key, int torus_base);         /* bootstrap.c:284-295 */
 void functional_bootstrap_trgsw_phase2(TLWE out, TRGSW_DFT in, TRLWE tv);                                  /* bootstrap.c:297-306 */
 void mosfhet_gen_priv_sk_ks_key_flat(Torus *out /*[n+1][t][2^bb-1][2][N]*/, TRLWE_Key out_key, TLWE_Key in_key, int t, int base_bit);

@@ -329,6 +329,24 @@ int mosfhet_hip_time_programmable_bootstrap(mosfhet_hip_ctx_t ctx, mosfhet_hip_b
                                             const uint64_t *d_tv, int tv_count, const uint64_t *d_in, int count,
                                             int precision, int reps, void *stream, float *ms_per_launch);
 
+/* ---- DFT-level entry points behind the reference's legacy signatures (mosfhet.h:179-182,263-264,342-344,454,296 of the reference; csrc/capi_dft.inc).
+ * DFT-domain objects are device arrays of doubles in the engine's slot order ([polynomial][N/2] complex). ---- */
+/* non-owning key handle over n consecutive TRGSW_DFT entries ([(k+1)l][k+1][N/2] complex each) already on the device; destroy with mosfhet_hip_bsk_destroy */
+int mosfhet_hip_bsk_view_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t *out, const double *d_dft, int n, int k, int N, int l, int Bg_bit);
+const double *mosfhet_hip_bsk_device_dft(mosfhet_hip_bsk_t bsk);          /* device address of entry 0 (NULL: unfolded key) */
+/* trgsw_mul_trlwe_DFT (src/trgsw.c:385-423), result left in the DFT domain: d_out_dft [count][k+1][N/2] complex; key_stride in doubles, 0 = shared TRGSW */
+int mosfhet_hip_external_product_dft_batch(mosfhet_hip_ctx_t ctx, const double *d_trgsw_dft, size_t key_stride, double *d_out_dft,
+                                           const uint64_t *d_in /*[count][k+1][N]*/, int N, int l, int Bg_bit, int count, void *stream);
+/* public_mux (src/bootstrap.c:369-389) with the selector rows in the DFT domain: d_sel_dft [count][l][2][N/2] complex */
+int mosfhet_hip_public_mux_dft_batch(mosfhet_hip_ctx_t ctx, uint64_t *d_out /*[count][2][N]*/, const uint64_t *d_p0 /*[N]*/, const uint64_t *d_p1,
+                                     const double *d_sel_dft, int N, int l, int Bg_bit, int count, void *stream);
+/* blind_rotate_ga (src/bootstrap_ga.c:35-60) in place on d_acc [count][2][N]; d_in [count][n+1] (mask words) */
+int mosfhet_hip_blind_rotate_ga_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, mosfhet_hip_gak_t gak, uint64_t *d_acc, const uint64_t *d_in, int count,
+                                      void *stream);
+/* trlwe_eval_automorphism (src/trlwe.c:775-781) with key-set entry `entry` (the batch entry point above uses entry (gen - 1) / 2) */
+int mosfhet_hip_trlwe_eval_automorphism_entry_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_gak_t gak, int entry, uint64_t *d_out, const uint64_t *d_in, int gen,
+                                                    int count, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,9 +13,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmosfhet_hip.so")
 
 HIP_SOURCES = ["capi.hip"]
-HOST_C_SOURCES = ["host/mosfhet_compat.c"]
-DEPS = ["negacyclic_fft.h", "bootstrap_kernels.h", "keyswitch_kernels.h", "ext_kernels.h", "keygen_kernels.h", "capi_ext.inc", "../../include/mosfhet_hip.h",
-        "../../include/mosfhet_compat.h", "../build.py"]
+HOST_C_SOURCES = ["host/mosfhet_compat.c", "host/mosfhet_compat_dft.c", "host/csprng.c"]
+DEPS = ["negacyclic_fft.h", "bootstrap_kernels.h", "keyswitch_kernels.h", "ext_kernels.h", "keygen_kernels.h", "capi_ext.inc", "capi_dft.inc", "../../include/mosfhet_hip.h",
+        "../../include/mosfhet_compat.h", "../../include/mosfhet.h", "host/compat_internal.h", "../build.py"]
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value",
                "-Wno-comment"]

@@ -549,8 +549,10 @@ __device__ __forceinline__ uint32_t inverse_mod_2n(uint32_t x, uint32_t mask) {
 struct GaParams {
   PbsParams p;
   const d2 *__restrict__ ak;  // [N][L][2][8][T] complex: automorphism key-switch keys, entry (gen - 1) / 2
-  int mode;                   // 0: functional_bootstrap(_wo_extract)_ga;  1: one trlwe_eval_automorphism with generator `gen`
+  int mode;                   // 0: functional_bootstrap(_wo_extract)_ga (p.skip_init: blind_rotate_ga on the accumulators in p.out);
+                              // 1: one trlwe_eval_automorphism with generator `gen`
   int gen;
+  int entry;                  // mode 1: key-set entry to switch with; < 0: (gen - 1) / 2 (trlwe_new_automorphism_KS_keyset's order)
 };
 
 template <class F, int L, int BG>
@@ -582,10 +584,20 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_ga_kernel(GaParams g) {
       acc1[M + m * T + t] = src[N + M + m * T + t];
     }
     F::sync();
-    ga_eval_automorphism<F, L, BG>(al, ah, acc1, xch, fft, g.ak + (size_t)((g.gen - 1) >> 1) * ak_sz, g.gen, off, Bg_bit, scale, t);
+    ga_eval_automorphism<F, L, BG>(al, ah, acc1, xch, fft, g.ak + (size_t)(g.entry >= 0 ? g.entry : (g.gen - 1) >> 1) * ak_sz, g.gen, off, Bg_bit, scale, t);
   } else {
     const uint64_t *__restrict__ ct = p.in + b * (size_t)(p.n + 1);
-    {
+    if (p.skip_init) {
+      // blind_rotate_ga (src/bootstrap_ga.c:35-60) on a caller-supplied accumulator
+      const uint64_t *src = p.out + b * (size_t)(2 * N);
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        al[m] = src[m * T + t];
+        ah[m] = src[M + m * T + t];
+        acc1[m * T + t] = src[N + m * T + t];
+        acc1[M + m * T + t] = src[N + M + m * T + t];
+      }
+    } else {
       // src/bootstrap_ga.c:64-65: acc = tv * X^(2N - bbar)
       const uint64_t *__restrict__ tv = p.tv + b * (size_t)p.tv_stride;
       const uint32_t bbar = modswitch<LOG2N2>(ct[p.n] + p.prec_offset);
@@ -817,10 +829,12 @@ template <class F, int L>
 __global__ __launch_bounds__(F::THREADS) void external_product_kernel(const d2 *__restrict__ bkrow, const d2 *__restrict__ tw,
                                                                     const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
                                                                     int Bg_bit, size_t key_stride = 0, size_t in_stride = 2 * F::N,
-                                                                    const uint64_t *__restrict__ in0 = nullptr) {
+                                                                    const uint64_t *__restrict__ in0 = nullptr, d2 *__restrict__ out_dft = nullptr) {
   // key_stride (in d2): 0 = one TRGSW for the whole batch, else TRGSW b starts at bkrow + b * key_stride (per-ciphertext
   // selectors, functional_bootstrap_trgsw_phase2); in_stride (words): 0 = one shared TRLWE input.
   // in0 != nullptr: CMUX (applications/leveled_lut/vertical_packing.c:24-33): out[b] = in0[b] + TRGSW (.) (in[b] - in0[b])
+  // out_dft != nullptr: trgsw_mul_trlwe_DFT as the reference declares it (include/mosfhet.h:344): the result stays in the DFT domain,
+  // out_dft[b][c][slot] in slot order; trlwe_from_DFT (dft_to_torus_kernel) finishes it with the same inverse transform and rounding.
   constexpr int N = F::N, M = F::M, T = F::THREADS;
   __shared__ __attribute__((aligned(16))) d2 xch[F::XCH_SLOTS];
   const int t = threadIdx.x;
@@ -847,6 +861,14 @@ __global__ __launch_bounds__(F::THREADS) void external_product_kernel(const d2 *
       Digits<L, 0>::pack(w_lo[m], w_hi[m], ext[m], ct[q * N + m * T + t] - s_lo + off, ct[q * N + M + m * T + t] - s_hi + off);
     }
     cmux_rows<F, L, 0>(w_lo, w_hi, ext, q, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
+  }
+  if (out_dft) {
+    d2 *dd = out_dft + (size_t)blockIdx.x * 2 * M;
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int m = 0; m < 8; m++) dd[c * M + m * T + t] = d2{o_re[c][m], o_im[c][m]};
+    return;
   }
   const RoundCtx scale(0x1p-64 / (double)M);
   uint64_t *dst = out + (size_t)blockIdx.x * 2 * N;

@@ -112,9 +112,10 @@ struct mosfhet_hip_bsk {
   int unfolding = 1;          // > 1: d_bk is null and d_su holds the torus-domain samples of new_bootstrap_key (src/bootstrap.c:23-48)
   uint64_t *d_su = nullptr;   // [n 2^u / u][2l][2][N]
   size_t bytes = 0;
+  bool owns = true;           // false: d_bk belongs to the caller (mosfhet_hip_bsk_view_create)
   ~mosfhet_hip_bsk() {
     if (ctx) (void)hipSetDevice(ctx->device);
-    if (d_bk) (void)hipFree(d_bk);
+    if (d_bk && owns) (void)hipFree(d_bk);
     if (d_su) (void)hipFree(d_su);
   }
 };
@@ -378,7 +379,7 @@ extern "C" int mosfhet_hip_set_team_max_batch(int max_batch) {
 }
 
 static int bootstrap_unfolded(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_out, const uint64_t *d_tv, int tv_count,
-                              const uint64_t *d_in, int count, int pre, int torus_base, int extract, int skip_init, void *stream, int rows);
+                              const uint64_t *d_in, int count, int pre, int kappa, int theta, int torus_base, int extract, int skip_init, void *stream, int rows);
 
 static int bootstrap_common(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_out,
                             const uint64_t *d_tv, int tv_count, const uint64_t *d_in, int count, int pre, int kappa,
@@ -392,7 +393,7 @@ static int bootstrap_common(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hip_
   if (pre && (kappa < 0 || kappa > 63 || theta < 0 || theta > 52)) return fail(MOSFHET_HIP_EINVAL, "%s: kappa/theta out of range", who);
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
-  if (bsk->unfolding > 1) return bootstrap_unfolded(who, ctx, bsk, d_out, d_tv, tv_count, d_in, count, pre, torus_base, extract, skip_init, stream, rows);
+  if (bsk->unfolding > 1) return bootstrap_unfolded(who, ctx, bsk, d_out, d_tv, tv_count, d_in, count, pre, kappa, theta, torus_base, extract, skip_init, stream, rows);
   PbsParams p;
   p.bk = bsk->d_bk;
   p.tw = bsk->N == 1024 ? ctx->tw1024 : (bsk->N == 2048 ? ctx->tw2048 : ctx->tw4096);
@@ -684,6 +685,7 @@ extern "C" int mosfhet_hip_trlwe_eval_automorphism_batch(mosfhet_hip_ctx_t ctx, 
   g.ak = gak->d_ak;
   g.mode = 1;
   g.gen = gen;
+  g.entry = -1;
   int rc_ga = MOSFHET_HIP_OK;
   RING_DISPATCH(ctx, gak->N, rc_ga = launch_ga_f<F>(gak->t, gak->base_bit, g, count, pick(ctx, stream)));
   return rc_ga;
@@ -830,3 +832,4 @@ extern "C" int mosfhet_hip_time_programmable_bootstrap(mosfhet_hip_ctx_t ctx, mo
 }
 
 #include "capi_ext.inc"
+#include "capi_dft.inc"

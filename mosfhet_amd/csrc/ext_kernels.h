@@ -22,7 +22,8 @@ __global__ void public_mux_digits_kernel(const uint64_t *__restrict__ p0, const 
 template <class F>
 __global__ __launch_bounds__(F::THREADS, 2) void public_mux_kernel(const uint64_t *__restrict__ sel, size_t sel_stride, const d2 *__restrict__ pdec,
                                                                  const uint64_t *__restrict__ p0, const d2 *__restrict__ tw,
-                                                                 uint64_t *__restrict__ out, size_t out_stride, int l) {
+                                                                 uint64_t *__restrict__ out, size_t out_stride, int l,
+                                                                 const d2 *__restrict__ sel_dft = nullptr) {
   constexpr int N = F::N, M = F::M, T = F::THREADS;
   __shared__ __attribute__((aligned(16))) d2 xch[F::XCH_SLOTS];
   const int tid = threadIdx.x;
@@ -42,14 +43,21 @@ __global__ __launch_bounds__(F::THREADS, 2) void public_mux_kernel(const uint64_
     for (int m = 0; m < 8; m++) k[m] = pdec[(size_t)i * M + m * T + tid];
 #pragma unroll
     for (int c = 0; c < 2; c++) {
-      const uint64_t *src = s + ((size_t)i * 2 + c) * N;
       double re[8], im[8];
+      if (sel_dft) {
+        // the selector arrives as TRLWE_DFT rows (the reference's signature, include/mosfhet.h public_mux): [b][l][2][M] complex, slot order
+        const d2 *src = sel_dft + ((size_t)blockIdx.x * l * 2 + (size_t)i * 2 + c) * M;
 #pragma unroll
-      for (int m = 0; m < 8; m++) {
-        re[m] = torus_to_double(src[m * T + tid]);
-        im[m] = torus_to_double(src[M + m * T + tid]);
+        for (int m = 0; m < 8; m++) { const d2 v = src[m * T + tid]; re[m] = v.x; im[m] = v.y; }
+      } else {
+        const uint64_t *src = s + ((size_t)i * 2 + c) * N;
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          re[m] = torus_to_double(src[m * T + tid]);
+          im[m] = torus_to_double(src[M + m * T + tid]);
+        }
+        fft.forward(re, im, xch, tid);
       }
-      fft.forward(re, im, xch, tid);
 #pragma unroll
       for (int m = 0; m < 8; m++) {
         o_re[c][m] = __builtin_fma(-im[m], k[m].y, __builtin_fma(re[m], k[m].x, o_re[c][m]));

@@ -7,34 +7,22 @@
  * of those in this library.  Reference file:line citations are in the header next to each prototype.
  */
 #define _GNU_SOURCE
-#include "mosfhet_compat.h"
-#include "mosfhet_hip.h"
+#include "compat_internal.h"
 
 #include <math.h>
 #include <pthread.h>
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 
-/* HIP runtime entry points used for staging buffers (declared here to keep this file plain C) */
-extern int hipMalloc(void **ptr, size_t size);
-extern int hipFree(void *ptr);
-extern int hipMemcpy(void *dst, const void *src, size_t size, int kind);
-extern int hipHostMalloc(void **ptr, size_t size, unsigned int flags);
-extern int hipStreamCreate(void **stream);
-extern int hipStreamSynchronize(void *stream);
-extern int hipMemcpyAsync(void *dst, const void *src, size_t size, int kind, void *stream);
-extern int hipHostFree(void *ptr);
-#define HIP_H2D 1
-#define HIP_D2H 2
-
 #define W 64
 
-static void die(const char *what) {
+void mc_die(const char *what) {
   fprintf(stderr, "mosfhet_amd: %s: %s\n", what, mosfhet_hip_last_error());
   abort();
 }
 
-static void *xmalloc(size_t sz) {
+void *mc_xmalloc(size_t sz) {
   void *p = NULL;
   if (posix_memalign(&p, 64, sz ? sz : 64)) {
     perror("mosfhet_amd: allocation failed");
@@ -42,6 +30,8 @@ static void *xmalloc(size_t sz) {
   }
   return p;
 }
+void *safe_malloc(size_t size) { return mc_xmalloc(size); }           /* src/misc.c:104-113 */
+void *safe_aligned_malloc(size_t size) { return mc_xmalloc(size); }   /* src/misc.c:115-128 */
 
 /* ------------------------------------------------------------------ engine singleton */
 static mosfhet_hip_ctx_t g_ctx = NULL;
@@ -57,7 +47,7 @@ void mosfhet_set_device(int device) {
 
 /* The layer is re-entrant like the reference (thread-local FFT state there, src/polynomial.c:269-352): the engine is created once under a lock,
  * keys are read-only after creation and may be shared by any number of host threads (device temporaries belong to the calling thread,
- * csrc/capi.hip), every thread has its own staging buffer and its own random stream. */
+ * csrc/capi.hip), every thread has its own staging buffer and its own random stream (csprng.c). */
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 
 void *mosfhet_engine_ctx(void) {
@@ -70,70 +60,24 @@ void *mosfhet_engine_ctx(void) {
       g_device = e ? atoi(e) : 0;
     }
     mosfhet_hip_ctx_t fresh = NULL;
-    if (mosfhet_hip_ctx_create(&fresh, g_device)) die("engine start-up");
+    if (mosfhet_hip_ctx_create(&fresh, g_device)) mc_die("engine start-up");
     __atomic_store_n(&g_ctx, fresh, __ATOMIC_RELEASE);
   }
   pthread_mutex_unlock(&g_lock);
   return g_ctx;
 }
 
-/* ------------------------------------------------------------------ randomness: xoshiro256** */
-/* One stream per host thread.  mosfhet_seed seeds the CALLING thread's stream (a single-threaded program is reproducible exactly as before) and
- * becomes the base from which threads that never seeded derive theirs (base, then a per-thread ticket): no shared generator state. */
-static __thread uint64_t g_rng[4];
-static __thread int g_rng_ready = 0;
-static uint64_t g_base_seed = 0;
-static int g_base_seed_set = 0;
-static uint64_t g_thread_ticket = 0;
-
-static uint64_t splitmix(uint64_t *x) {
-  uint64_t z = (*x += 0x9E3779B97F4A7C15ull);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-
-static void seed_this_thread(uint64_t seed) {
-  for (int i = 0; i < 4; i++) g_rng[i] = splitmix(&seed);
-  g_rng_ready = 1;
-}
-
-void mosfhet_seed(uint64_t seed) {
-  pthread_mutex_lock(&g_lock);
-  g_base_seed = seed;
-  g_base_seed_set = 1;
-  pthread_mutex_unlock(&g_lock);
-  seed_this_thread(seed);
-}
-
-static inline uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
-
-static uint64_t rnd64(void) {
-  if (!g_rng_ready) {
-    pthread_mutex_lock(&g_lock);
-    if (!g_base_seed_set) {
-      FILE *f = fopen("/dev/urandom", "rb");
-      if (!f || fread(&g_base_seed, sizeof(g_base_seed), 1, f) != 1) g_base_seed = 0x4D4F5346ull;
-      if (f) fclose(f);
-      g_base_seed_set = 1;
-    }
-    uint64_t seed = g_base_seed ^ (0xA24BAED4963EE407ull * ++g_thread_ticket);
-    pthread_mutex_unlock(&g_lock);
-    seed_this_thread(splitmix(&seed));
+/* HIP's current device is per host thread and starts at 0: every thread that allocates staging memory or creates streams for the engine first makes
+ * the ENGINE's device current (the C ABI does the same at the top of every call). */
+void mc_use_device(void) {
+  static __thread int t_done = 0;
+  if (t_done) return;
+  (void)mosfhet_engine_ctx();
+  if (hipSetDevice(g_device)) {
+    fprintf(stderr, "mosfhet_amd: hipSetDevice(%d) failed\n", g_device);
+    abort();
   }
-  const uint64_t r = rotl(g_rng[1] * 5, 7) * 9, t = g_rng[1] << 17;
-  g_rng[2] ^= g_rng[0];
-  g_rng[3] ^= g_rng[1];
-  g_rng[1] ^= g_rng[2];
-  g_rng[0] ^= g_rng[3];
-  g_rng[2] ^= t;
-  g_rng[3] = rotl(g_rng[3], 45);
-  return r;
-}
-
-static double rnd_normal(double sigma) { /* Box-Muller, as src/misc.c:87-91 */
-  const double u1 = ((double)(rnd64() >> 11) + 0.5) * 0x1p-53, u2 = ((double)(rnd64() >> 11) + 0.5) * 0x1p-53;
-  return cos(2. * M_PI * u1) * sqrt(-2. * log(u2)) * sigma;
+  t_done = 1;
 }
 
 /* ------------------------------------------------------------------ torus scalars */
@@ -143,18 +87,41 @@ uint64_t torus2int(Torus x, int log_scale) { return (x + ((Torus)1 << (W - log_s
 Torus int2torus(uint64_t x, int log_scale) { return x << (W - log_scale); }
 
 /* ------------------------------------------------------------------ polynomials */
+/* Every polynomial shell this library hands out -- torus domain (host coefficients) or DFT domain (device coefficients) -- sits behind a hidden tag:
+ * the reference frees both kinds through the same void * functions (free_polynomial, free_trlwe, free_trgsw: src/polynomial.c:40-53, src/trlwe.c:86-94). */
+typedef struct { uint64_t kind, pad; struct _TorusPolynomial p; } PolyBox;
+#define POLY_BOX(ptr) ((PolyBox *)((char *)(ptr) - offsetof(PolyBox, p)))
+
+void *mc_poly_shell(int kind, void *coeffs, int N) {
+  PolyBox *b = (PolyBox *)mc_xmalloc(sizeof(*b));
+  b->kind = (uint64_t)kind;
+  b->pad = 0;
+  b->p.coeffs = (Torus *)coeffs;
+  b->p.N = N;
+  return &b->p;
+}
+
+int mc_poly_kind(const void *poly) { return (int)POLY_BOX(poly)->kind; }
+
 TorusPolynomial polynomial_new_torus_polynomial(int N) {
-  TorusPolynomial p = (TorusPolynomial)xmalloc(sizeof(*p));
-  p->coeffs = (Torus *)xmalloc(sizeof(Torus) * (size_t)N);
-  p->N = N;
-  return p;
+  return (TorusPolynomial)mc_poly_shell(MC_POLY_TORUS, mc_xmalloc(sizeof(Torus) * (size_t)N), N);
 }
 
 void free_polynomial(void *p) {
   if (!p) return;
-  free(((TorusPolynomial)p)->coeffs);
-  free(p);
+  PolyBox *b = POLY_BOX(p);
+  switch ((int)b->kind) {
+    case MC_POLY_TORUS: free(b->p.coeffs); break;
+    case MC_POLY_DFT_OWNER: mc_use_device(); hipFree(b->p.coeffs); break;   /* the device block of a DFT-domain object hangs off its first polynomial */
+    case MC_POLY_DFT_VIEW: break;
+    default:
+      fprintf(stderr, "mosfhet_amd: free_polynomial: %p was not allocated by this library\n", p);
+      abort();
+  }
+  b->kind = 0;
+  free(b);
 }
+void free_DFT_polynomial(DFT_Polynomial p) { free_polynomial(p); }   /* src/polynomial.c:47-53 */
 
 /* exact negacyclic out += a * s; fast path for 0/1 coefficients of s */
 static void negacyclic_mul_addto(Torus *out, const Torus *a, const Torus *s, int N) {
@@ -173,16 +140,16 @@ static void negacyclic_mul_addto(Torus *out, const Torus *a, const Torus *s, int
 
 /* ------------------------------------------------------------------ TLWE */
 TLWE_Key tlwe_alloc_key(int n, double sigma) {
-  TLWE_Key k = (TLWE_Key)xmalloc(sizeof(*k));
+  TLWE_Key k = (TLWE_Key)mc_xmalloc(sizeof(*k));
   k->n = n;
   k->sigma = sigma;
-  k->s = (Integer *)xmalloc(sizeof(Integer) * (size_t)n);
+  k->s = (Integer *)mc_xmalloc(sizeof(Integer) * (size_t)n);
   return k;
 }
 
 TLWE_Key tlwe_new_binary_key(int n, double sigma) {
   TLWE_Key k = tlwe_alloc_key(n, sigma);
-  for (int i = 0; i < n; i++) k->s[i] = rnd64() & 1;
+  for (int i = 0; i < n; i++) k->s[i] = mc_rnd64() & 1;
   return k;
 }
 
@@ -193,15 +160,15 @@ void free_tlwe_key(TLWE_Key key) {
 }
 
 TLWE tlwe_alloc_sample(int n) {
-  TLWE c = (TLWE)xmalloc(sizeof(*c));
-  c->a = (Torus *)xmalloc(sizeof(Torus) * (size_t)n);
+  TLWE c = (TLWE)mc_xmalloc(sizeof(*c));
+  c->a = (Torus *)mc_xmalloc(sizeof(Torus) * (size_t)n);
   c->n = n;
   c->b = 0;
   return c;
 }
 
 TLWE *tlwe_alloc_sample_array(int count, int n) {
-  TLWE *r = (TLWE *)xmalloc(sizeof(TLWE) * (size_t)count);
+  TLWE *r = (TLWE *)mc_xmalloc(sizeof(TLWE) * (size_t)count);
   for (int i = 0; i < count; i++) r[i] = tlwe_alloc_sample(n);
   return r;
 }
@@ -225,19 +192,19 @@ void tlwe_noiseless_trivial_sample(TLWE out, Torus m) {
 void mosfhet_tlwe_sample_flat(Torus *out, Torus m, TLWE_Key key) {
   Torus b = m;
   for (int i = 0; i < key->n; i++) {
-    out[i] = rnd64();
+    out[i] = mc_rnd64();
     b += key->s[i] * out[i];
   }
-  out[key->n] = b + double2torus(rnd_normal(key->sigma));
+  out[key->n] = b + double2torus(mc_rnd_normal(key->sigma));
 }
 
 void tlwe_sample(TLWE out, Torus m, TLWE_Key key) {
   Torus b = m;
   for (int i = 0; i < key->n; i++) {
-    out->a[i] = rnd64();
+    out->a[i] = mc_rnd64();
     b += key->s[i] * out->a[i];
   }
-  out->b = b + double2torus(rnd_normal(key->sigma));
+  out->b = b + double2torus(mc_rnd_normal(key->sigma));
 }
 
 TLWE tlwe_new_sample(Torus m, TLWE_Key key) {
@@ -290,10 +257,10 @@ void tlwe_scale_subto(TLWE out, TLWE in1, Torus in2) {
 
 /* ------------------------------------------------------------------ TRLWE */
 TRLWE_Key trlwe_alloc_key(int N, int k, double sigma) {
-  TRLWE_Key key = (TRLWE_Key)xmalloc(sizeof(*key));
+  TRLWE_Key key = (TRLWE_Key)mc_xmalloc(sizeof(*key));
   key->k = k;
   key->sigma = sigma;
-  key->s = (IntPolynomial *)xmalloc(sizeof(IntPolynomial) * (size_t)k);
+  key->s = (IntPolynomial *)mc_xmalloc(sizeof(IntPolynomial) * (size_t)k);
   key->s_dft = NULL; /* DFT-domain data is device resident in this engine */
   for (int i = 0; i < k; i++) key->s[i] = polynomial_new_torus_polynomial(N);
   return key;
@@ -302,7 +269,7 @@ TRLWE_Key trlwe_alloc_key(int N, int k, double sigma) {
 TRLWE_Key trlwe_new_binary_key(int N, int k, double sigma) {
   TRLWE_Key key = trlwe_alloc_key(N, k, sigma);
   for (int i = 0; i < k; i++)
-    for (int j = 0; j < N; j++) key->s[i]->coeffs[j] = rnd64() & 1;
+    for (int j = 0; j < N; j++) key->s[i]->coeffs[j] = mc_rnd64() & 1;
   return key;
 }
 
@@ -314,8 +281,8 @@ void free_trlwe_key(TRLWE_Key key) {
 }
 
 TRLWE trlwe_alloc_new_sample(int k, int N) {
-  TRLWE c = (TRLWE)xmalloc(sizeof(*c));
-  c->a = (TorusPolynomial *)xmalloc(sizeof(TorusPolynomial) * (size_t)k);
+  TRLWE c = (TRLWE)mc_xmalloc(sizeof(*c));
+  c->a = (TorusPolynomial *)mc_xmalloc(sizeof(TorusPolynomial) * (size_t)k);
   for (int i = 0; i < k; i++) c->a[i] = polynomial_new_torus_polynomial(N);
   c->b = polynomial_new_torus_polynomial(N);
   c->k = k;
@@ -347,8 +314,8 @@ TRLWE trlwe_new_noiseless_trivial_sample(TorusPolynomial m, int k, int N) {
 void trlwe_sample(TRLWE out, TorusPolynomial m, TRLWE_Key key) {
   const int N = key->s[0]->N;
   for (int i = 0; i < key->k; i++)
-    for (int j = 0; j < N; j++) out->a[i]->coeffs[j] = rnd64();
-  for (int j = 0; j < N; j++) out->b->coeffs[j] = double2torus(rnd_normal(key->sigma));
+    for (int j = 0; j < N; j++) out->a[i]->coeffs[j] = mc_rnd64();
+  for (int j = 0; j < N; j++) out->b->coeffs[j] = double2torus(mc_rnd_normal(key->sigma));
   for (int i = 0; i < key->k; i++) negacyclic_mul_addto(out->b->coeffs, out->a[i]->coeffs, key->s[i]->coeffs, N);
   if (m)
     for (int j = 0; j < N; j++) out->b->coeffs[j] += m->coeffs[j];
@@ -459,7 +426,7 @@ void trlwe_mv_extract_tlwe_scaling_subto(TLWE out, TRLWE in, int scale) {
 
 /* ------------------------------------------------------------------ TRGSW */
 TRGSW_Key trgsw_new_key(TRLWE_Key trlwe_key, int l, int Bg_bit) {
-  TRGSW_Key k = (TRGSW_Key)xmalloc(sizeof(*k));
+  TRGSW_Key k = (TRGSW_Key)mc_xmalloc(sizeof(*k));
   k->trlwe_key = trlwe_key;
   k->l = l;
   k->Bg_bit = Bg_bit;
@@ -469,8 +436,8 @@ TRGSW_Key trgsw_new_key(TRLWE_Key trlwe_key, int l, int Bg_bit) {
 void free_trgsw_key(TRGSW_Key key) { free(key); }
 
 TRGSW trgsw_alloc_new_sample(int l, int Bg_bit, int k, int N) {
-  TRGSW g = (TRGSW)xmalloc(sizeof(*g));
-  g->samples = (TRLWE *)xmalloc(sizeof(TRLWE) * (size_t)l * (k + 1));
+  TRGSW g = (TRGSW)mc_xmalloc(sizeof(*g));
+  g->samples = (TRLWE *)mc_xmalloc(sizeof(TRLWE) * (size_t)l * (k + 1));
   for (int i = 0; i < l * (k + 1); i++) g->samples[i] = trlwe_alloc_new_sample(k, N);
   g->l = l;
   g->Bg_bit = Bg_bit;
@@ -499,13 +466,13 @@ void trgsw_monomial_sample(TRGSW out, int64_t m, int e, TRGSW_Key key) {
 }
 
 /* ------------------------------------------------------------------ flat marshalling */
-static void trlwe_to_flat(Torus *flat, TRLWE c) {
+void mc_trlwe_to_flat(Torus *flat, TRLWE c) {
   const int N = c->b->N;
   for (int p = 0; p < c->k; p++) memcpy(flat + (size_t)p * N, c->a[p]->coeffs, sizeof(Torus) * (size_t)N);
   memcpy(flat + (size_t)c->k * N, c->b->coeffs, sizeof(Torus) * (size_t)N);
 }
 
-static void trlwe_from_flat(TRLWE c, const Torus *flat) {
+void mc_trlwe_from_flat(TRLWE c, const Torus *flat) {
   const int N = c->b->N;
   for (int p = 0; p < c->k; p++) memcpy(c->a[p]->coeffs, flat + (size_t)p * N, sizeof(Torus) * (size_t)N);
   memcpy(c->b->coeffs, flat + (size_t)c->k * N, sizeof(Torus) * (size_t)N);
@@ -527,8 +494,9 @@ static void tlwe_array_from_flat(TLWE *c, const Torus *flat, int count, int n) {
   }
 }
 
-static void *dev_alloc(size_t bytes) {
+void *mc_dev_alloc(size_t bytes) {
   void *p = NULL;
+  mc_use_device();
   if (hipMalloc(&p, bytes ? bytes : 8)) {
     fprintf(stderr, "mosfhet_amd: hipMalloc(%zu) failed\n", bytes);
     abort();
@@ -544,11 +512,11 @@ static pthread_key_t g_stage_key;                      /* its destructor release
 static pthread_once_t g_stage_once = PTHREAD_ONCE_INIT;
 static void stage_release(void *p) { if (p) hipFree(p); }
 static void stage_key_init(void) { pthread_key_create(&g_stage_key, stage_release); }
-static void *stage_alloc(size_t bytes) {
+void *mc_stage_alloc(size_t bytes) {
   if (bytes > g_stage_bytes) {
     if (g_stage) hipFree(g_stage);
     g_stage_bytes = bytes < 65536 ? 65536 : bytes + bytes / 2;
-    g_stage = dev_alloc(g_stage_bytes);
+    g_stage = mc_dev_alloc(g_stage_bytes);
     pthread_once(&g_stage_once, stage_key_init);
     pthread_setspecific(g_stage_key, g_stage);
   }
@@ -569,8 +537,9 @@ static void hstage_release(void *unused) {
     if (g_hstage[i].p) { hipHostFree(g_hstage[i].p); g_hstage[i].p = NULL; }
 }
 static void hstage_key_init(void) { pthread_key_create(&g_hstage_key, hstage_release); }
-static void *hstage_alloc(size_t bytes) {
+void *mc_hstage_alloc(size_t bytes) {
   if (!bytes) bytes = 64;
+  mc_use_device();
   for (int i = 0; i < HSTAGE_SLOTS; i++) {
     if (g_hstage[i].used) continue;
     if (g_hstage[i].bytes < bytes) {
@@ -586,15 +555,15 @@ static void *hstage_alloc(size_t bytes) {
     g_hstage[i].used = 1;
     return g_hstage[i].p;
   }
-  return xmalloc(bytes);
+  return mc_xmalloc(bytes);
 }
-static void hstage_free(void *p) {
+void mc_hstage_free(void *p) {
   for (int i = 0; i < HSTAGE_SLOTS; i++)
     if (g_hstage[i].p == p && g_hstage[i].used) { g_hstage[i].used = 0; return; }
   free(p);
 }
 
-static void dev_copy(void *dst, const void *src, size_t bytes, int kind) {
+void mc_dev_copy(void *dst, const void *src, size_t bytes, int kind) {
   if (bytes && hipMemcpy(dst, src, bytes, kind)) {
     fprintf(stderr, "mosfhet_amd: hipMemcpy failed\n");
     abort();
@@ -608,12 +577,12 @@ void mosfhet_gen_bootstrap_key_flat(Torus *out, TRGSW_Key out_key, TLWE_Key in_k
   TRGSW tmp = trgsw_alloc_new_sample(l, out_key->Bg_bit, k, N);
   for (int i = 0; i < in_key->n; i++) {
     trgsw_monomial_sample(tmp, (int64_t)in_key->s[i], 0, out_key);
-    for (int q = 0; q < (k + 1) * l; q++) trlwe_to_flat(out + (size_t)i * sz + q * row, tmp->samples[q]);
+    for (int q = 0; q < (k + 1) * l; q++) mc_trlwe_to_flat(out + (size_t)i * sz + q * row, tmp->samples[q]);
   }
   free_trgsw(tmp);
 }
 
-/* registry so that blind_rotate(tv, a, key->s, n) can find the key behind the `s` token */
+/* Keys alive in this process, for the one reference signature that names no key (functional_bootstrap_trgsw_phase2, src/bootstrap.c:297). */
 #define MAX_KEYS 64
 static Bootstrap_Key g_keys[MAX_KEYS];
 
@@ -634,8 +603,13 @@ static void forget_key(Bootstrap_Key key) {
   pthread_mutex_unlock(&g_lock);
 }
 
-/* Bootstrap_Key.s is an opaque token: a one-element array holding the device key handle. */
-void *mosfhet_bootstrap_key_device(Bootstrap_Key key) { return key && key->s ? (void *)key->s[0] : NULL; }
+void *mosfhet_bootstrap_key_device(Bootstrap_Key key) { return key ? key->device : NULL; }
+
+/* Bootstrap_Key.s: the reference's array of n TRGSW_DFT (src/bootstrap.c:7-19), here n views of the device-resident key */
+static TRGSW_DFT *key_views(void *dev, int n, int l, int Bg_bit, int N) {
+  const double *base = mosfhet_hip_bsk_device_dft((mosfhet_hip_bsk_t)dev);
+  return base ? mc_trgsw_dft_views((double *)base, n, l, Bg_bit, N) : NULL;
+}
 
 /* src/bootstrap.c:23-48: 2^u torus-domain TRGSW samples per group of u key bits, su[i 2^u/u + j] = TRGSW(indicator of bit pattern j) */
 void mosfhet_gen_bootstrap_key_unfolded_flat(Torus *out, TRGSW_Key out_key, TLWE_Key in_key, int unfolding) {
@@ -647,7 +621,7 @@ void mosfhet_gen_bootstrap_key_unfolded_flat(Torus *out, TRGSW_Key out_key, TLWE
       Torus key = 1;
       for (int u = 0, j_ = j; u < unfolding; u++, j_ >>= 1) key *= (j_ & 1) ? in_key->s[i + u] : 1 - in_key->s[i + u];
       trgsw_monomial_sample(tmp, (int64_t)key, 0, out_key);
-      for (int q = 0; q < 2 * l; q++) trlwe_to_flat(out + ((size_t)i * final_exp + j) * sz + q * row, tmp->samples[q]);
+      for (int q = 0; q < 2 * l; q++) mc_trlwe_to_flat(out + ((size_t)i * final_exp + j) * sz + q * row, tmp->samples[q]);
     }
   free_trgsw(tmp);
 }
@@ -659,7 +633,7 @@ Bootstrap_Key new_bootstrap_key(TRGSW_Key out_key, TLWE_Key in_key, int unfoldin
                     "reference's key layout (src/bootstrap.c:34-45: group stride 2^u / u as an integer) is only consistent for powers of two\n", unfolding);
     abort();
   }
-  Bootstrap_Key res = (Bootstrap_Key)xmalloc(sizeof(*res));
+  Bootstrap_Key res = (Bootstrap_Key)mc_xmalloc(sizeof(*res));
   res->n = n; res->k = k; res->l = l; res->N = N; res->Bg_bit = out_key->Bg_bit; res->unfolding = unfolding;
   res->su = NULL;   /* device resident as well (reference: host TRGSW array, src/bootstrap.c:35) */
   mosfhet_hip_bsk_t dev = NULL;
@@ -667,17 +641,17 @@ Bootstrap_Key new_bootstrap_key(TRGSW_Key out_key, TLWE_Key in_key, int unfoldin
   if (unfolding == 1) {
     /* encrypted on the device (counter-based generator seeded from this thread's stream), transformed there: no host copy of the key */
     if (mosfhet_hip_bsk_generate((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, out_key->trlwe_key->s[0]->coeffs, N, in_key->s, n, l, out_key->Bg_bit,
-                                 out_key->trlwe_key->sigma, rnd64(), 0))
-      die("new_bootstrap_key");
+                                 out_key->trlwe_key->sigma, mc_rnd64(), 0))
+      mc_die("new_bootstrap_key");
   } else {
     const size_t words = (size_t)n * ((size_t)1 << unfolding) / unfolding * 2 * l * 2 * N;
-    Torus *flat = (Torus *)xmalloc(sizeof(Torus) * words);
+    Torus *flat = (Torus *)mc_xmalloc(sizeof(Torus) * words);
     mosfhet_gen_bootstrap_key_unfolded_flat(flat, out_key, in_key, unfolding);
-    if (mosfhet_hip_bsk_unfolded_create((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, flat, n, N, l, out_key->Bg_bit, unfolding)) die("new_bootstrap_key (unfolded)");
+    if (mosfhet_hip_bsk_unfolded_create((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, flat, n, N, l, out_key->Bg_bit, unfolding)) mc_die("new_bootstrap_key (unfolded)");
     free(flat);
   }
-  res->s = (TRGSW_DFT *)xmalloc(sizeof(TRGSW_DFT));
-  res->s[0] = (TRGSW_DFT)dev;
+  res->device = dev;
+  res->s = key_views(dev, n, l, out_key->Bg_bit, N);
   remember_key(res);
   return res;
 }
@@ -685,8 +659,8 @@ Bootstrap_Key new_bootstrap_key(TRGSW_Key out_key, TLWE_Key in_key, int unfoldin
 void free_bootstrap_key(Bootstrap_Key key) {
   if (!key) return;
   forget_key(key);
-  mosfhet_hip_bsk_destroy((mosfhet_hip_bsk_t)mosfhet_bootstrap_key_device(key));
-  free(key->s);
+  if (key->s) mc_trgsw_dft_views_free(key->s, key->n);
+  mosfhet_hip_bsk_destroy((mosfhet_hip_bsk_t)key->device);
   free(key);
 }
 
@@ -704,40 +678,43 @@ static void bootstrap_pipelined(int mode, TLWE *out, TRLWE tv, TLWE *in, int cou
   const int n = key->n, N = key->N, k = key->k;
   const size_t in_row = (size_t)n + 1, out_row = (size_t)k * N + 1, tv_w = (size_t)(k + 1) * N;
   const size_t in_w = (size_t)count * in_row, out_w = (size_t)count * out_row;
+  mc_use_device();
   for (int i = 0; i < 2; i++)
-    if (!g_pipe_streams[i] && hipStreamCreate(&g_pipe_streams[i])) die("bootstrap (stream)");
-  Torus *h = (Torus *)hstage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
-  Torus *d = (Torus *)stage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
+    if (!g_pipe_streams[i] && hipStreamCreate(&g_pipe_streams[i])) mc_die("bootstrap (stream)");
+  Torus *h = (Torus *)mc_hstage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
+  Torus *d = (Torus *)mc_stage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
   Torus *h_tv = h + in_w, *h_out = h + in_w + tv_w, *d_tv = d + in_w, *d_out = d + in_w + tv_w;
-  trlwe_to_flat(h_tv, tv);
-  dev_copy(d_tv, h_tv, sizeof(Torus) * tv_w, HIP_H2D);
+  mc_trlwe_to_flat(h_tv, tv);
+  mc_dev_copy(d_tv, h_tv, sizeof(Torus) * tv_w, HIP_H2D);
   int prev_lo = -1, prev_c = 0;
   for (int lo = 0, c = 0; lo < count; lo += PIPE_CHUNK, c++) {
     const int cnt = count - lo < PIPE_CHUNK ? count - lo : PIPE_CHUNK;
     void *st = g_pipe_streams[c & 1];
     tlwe_array_to_flat(h + (size_t)lo * in_row, in + lo, cnt, n);
-    if (hipMemcpyAsync(d + (size_t)lo * in_row, h + (size_t)lo * in_row, sizeof(Torus) * (size_t)cnt * in_row, HIP_H2D, st)) die("bootstrap (copy in)");
+    if (hipMemcpyAsync(d + (size_t)lo * in_row, h + (size_t)lo * in_row, sizeof(Torus) * (size_t)cnt * in_row, HIP_H2D, st)) mc_die("bootstrap (copy in)");
     const int rc = mode == MODE_PROGRAMMABLE
                        ? mosfhet_hip_programmable_bootstrap_batch(ctx, bsk, d_out + (size_t)lo * out_row, d_tv, 1, d + (size_t)lo * in_row, cnt, a0, kappa, theta, st)
                        : mosfhet_hip_functional_bootstrap_batch(ctx, bsk, d_out + (size_t)lo * out_row, d_tv, 1, d + (size_t)lo * in_row, cnt, a0, st);
-    if (rc) die("bootstrap");
-    if (hipMemcpyAsync(h_out + (size_t)lo * out_row, d_out + (size_t)lo * out_row, sizeof(Torus) * (size_t)cnt * out_row, HIP_D2H, st)) die("bootstrap (copy out)");
+    if (rc) mc_die("bootstrap");
+    if (hipMemcpyAsync(h_out + (size_t)lo * out_row, d_out + (size_t)lo * out_row, sizeof(Torus) * (size_t)cnt * out_row, HIP_D2H, st)) mc_die("bootstrap (copy out)");
     if (prev_lo >= 0) {   /* the previous chunk's results: wait for its stream, unpack while this chunk runs */
-      if (hipStreamSynchronize(g_pipe_streams[prev_c & 1])) die("bootstrap");
+      if (hipStreamSynchronize(g_pipe_streams[prev_c & 1])) mc_die("bootstrap");
       tlwe_array_from_flat(out + prev_lo, h_out + (size_t)prev_lo * out_row, lo - prev_lo, k * N);
     }
     prev_lo = lo;
     prev_c = c;
   }
-  if (hipStreamSynchronize(g_pipe_streams[prev_c & 1])) die("bootstrap");
+  if (hipStreamSynchronize(g_pipe_streams[prev_c & 1])) mc_die("bootstrap");
   tlwe_array_from_flat(out + prev_lo, h_out + (size_t)prev_lo * out_row, count - prev_lo, k * N);
   stage_free(d);
-  hstage_free(h);
+  mc_hstage_free(h);
 }
 
 static void bootstrap_many(int mode, TLWE *out, TRLWE out_trlwe, TRLWE tv, TLWE *in, int count, Bootstrap_Key key,
                            int a0, int kappa, int theta) {
-  if (mode != MODE_WO_EXTRACT && count >= 2 * PIPE_CHUNK) {
+  /* unfolded keys keep the single-stream path: their accumulators live in the calling thread's device pool, one set per thread, so chunks on two
+   * streams would share it (mosfhet_hip.h: compositions on several streams must be ordered by the caller) */
+  if (mode != MODE_WO_EXTRACT && count >= 2 * PIPE_CHUNK && key->unfolding == 1) {
     bootstrap_pipelined(mode, out, tv, in, count, key, a0, kappa, theta);
     return;
   }
@@ -746,11 +723,11 @@ static void bootstrap_many(int mode, TLWE *out, TRLWE out_trlwe, TRLWE tv, TLWE 
   const int n = key->n, N = key->N, k = key->k;
   const size_t in_w = (size_t)count * (n + 1), tv_w = (size_t)(k + 1) * N;
   const size_t out_w = (mode == MODE_WO_EXTRACT) ? (size_t)count * tv_w : (size_t)count * (k * N + 1);
-  Torus *h = (Torus *)hstage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
+  Torus *h = (Torus *)mc_hstage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
   tlwe_array_to_flat(h, in, count, n);
-  trlwe_to_flat(h + in_w, tv);
-  Torus *d = (Torus *)stage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
-  dev_copy(d, h, sizeof(Torus) * (in_w + tv_w), HIP_H2D);
+  mc_trlwe_to_flat(h + in_w, tv);
+  Torus *d = (Torus *)mc_stage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
+  mc_dev_copy(d, h, sizeof(Torus) * (in_w + tv_w), HIP_H2D);
   int rc;
   if (mode == MODE_PROGRAMMABLE)
     rc = mosfhet_hip_programmable_bootstrap_batch(ctx, bsk, d + in_w + tv_w, d + in_w, 1, d, count, a0, kappa, theta, NULL);
@@ -758,12 +735,12 @@ static void bootstrap_many(int mode, TLWE *out, TRLWE out_trlwe, TRLWE tv, TLWE 
     rc = mosfhet_hip_functional_bootstrap_batch(ctx, bsk, d + in_w + tv_w, d + in_w, 1, d, count, a0, NULL);
   else
     rc = mosfhet_hip_functional_bootstrap_wo_extract_batch(ctx, bsk, d + in_w + tv_w, d + in_w, 1, d, count, a0, NULL);
-  if (rc || mosfhet_hip_ctx_sync(ctx, NULL)) die("bootstrap");
-  dev_copy(h + in_w + tv_w, d + in_w + tv_w, sizeof(Torus) * out_w, HIP_D2H);
-  if (mode == MODE_WO_EXTRACT) trlwe_from_flat(out_trlwe, h + in_w + tv_w);
+  if (rc || mosfhet_hip_ctx_sync(ctx, NULL)) mc_die("bootstrap");
+  mc_dev_copy(h + in_w + tv_w, d + in_w + tv_w, sizeof(Torus) * out_w, HIP_D2H);
+  if (mode == MODE_WO_EXTRACT) mc_trlwe_from_flat(out_trlwe, h + in_w + tv_w);
   else tlwe_array_from_flat(out, h + in_w + tv_w, count, k * N);
   stage_free(d);
-  hstage_free(h);
+  mc_hstage_free(h);
 }
 
 void functional_bootstrap_batch(TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_Key key, int torus_base) {
@@ -798,19 +775,19 @@ void full_domain_functional_bootstrap_batch(TLWE *out, TRLWE tv, TLWE *in, int c
   mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
   const int n = key->n, N = key->N, k = key->k;
   const size_t in_w = (size_t)count * (n + 1), tv_w = (size_t)(k + 1) * N, out_w = (size_t)count * (k * N + 1);
-  Torus *h = (Torus *)hstage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
+  Torus *h = (Torus *)mc_hstage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
   tlwe_array_to_flat(h, in, count, n);
-  trlwe_to_flat(h + in_w, tv);
-  Torus *d = (Torus *)stage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
-  dev_copy(d, h, sizeof(Torus) * (in_w + tv_w), HIP_H2D);
+  mc_trlwe_to_flat(h + in_w, tv);
+  Torus *d = (Torus *)mc_stage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
+  mc_dev_copy(d, h, sizeof(Torus) * (in_w + tv_w), HIP_H2D);
   if (mosfhet_hip_full_domain_functional_bootstrap_batch(ctx, (mosfhet_hip_bsk_t)mosfhet_bootstrap_key_device(key),
                                                          (mosfhet_hip_ksk_t)ksk->device, d + in_w + tv_w, d + in_w, 1, d, count, precision, NULL) ||
       mosfhet_hip_ctx_sync(ctx, NULL))
-    die("full_domain_functional_bootstrap");
-  dev_copy(h + in_w + tv_w, d + in_w + tv_w, sizeof(Torus) * out_w, HIP_D2H);
+    mc_die("full_domain_functional_bootstrap");
+  mc_dev_copy(h + in_w + tv_w, d + in_w + tv_w, sizeof(Torus) * out_w, HIP_D2H);
   tlwe_array_from_flat(out, h + in_w + tv_w, count, k * N);
   stage_free(d);
-  hstage_free(h);
+  mc_hstage_free(h);
 }
 
 void full_domain_functional_bootstrap(TLWE out, TRLWE tv, TLWE in, Bootstrap_Key key, TLWE_KS_Key ksk, int precision) {
@@ -821,48 +798,19 @@ void multivalue_bootstrap_CLOT21(TLWE *out, TRLWE tv, TLWE in, Bootstrap_Key key
   mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
   const int n = key->n, N = key->N, k = key->k;
   const size_t in_w = (size_t)(n + 1), tv_w = (size_t)(k + 1) * N, out_w = (size_t)n_luts * (k * N + 1);
-  Torus *h = (Torus *)hstage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
+  Torus *h = (Torus *)mc_hstage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
   tlwe_array_to_flat(h, &in, 1, n);
-  trlwe_to_flat(h + in_w, tv);
-  Torus *d = (Torus *)stage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
-  dev_copy(d, h, sizeof(Torus) * (in_w + tv_w), HIP_H2D);
+  mc_trlwe_to_flat(h + in_w, tv);
+  Torus *d = (Torus *)mc_stage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
+  mc_dev_copy(d, h, sizeof(Torus) * (in_w + tv_w), HIP_H2D);
   if (mosfhet_hip_multivalue_bootstrap_CLOT21_batch(ctx, (mosfhet_hip_bsk_t)mosfhet_bootstrap_key_device(key), d + in_w + tv_w, d + in_w, 1, d,
                                                     1, torus_base, n_luts, NULL) ||
       mosfhet_hip_ctx_sync(ctx, NULL))
-    die("multivalue_bootstrap_CLOT21");
-  dev_copy(h + in_w + tv_w, d + in_w + tv_w, sizeof(Torus) * out_w, HIP_D2H);
+    mc_die("multivalue_bootstrap_CLOT21");
+  mc_dev_copy(h + in_w + tv_w, d + in_w + tv_w, sizeof(Torus) * out_w, HIP_D2H);
   tlwe_array_from_flat(out, h + in_w + tv_w, n_luts, k * N);
   stage_free(d);
-  hstage_free(h);
-}
-
-void blind_rotate(TRLWE tv, Torus *a, TRGSW_DFT *s, int size) {
-  Bootstrap_Key key = NULL;
-  pthread_mutex_lock(&g_lock);
-  for (int i = 0; i < MAX_KEYS; i++)
-    if (g_keys[i] && g_keys[i]->s == s) key = g_keys[i];
-  pthread_mutex_unlock(&g_lock);
-  if (!key || size != key->n) {
-    fprintf(stderr, "mosfhet_amd: blind_rotate: `s` must be the .s member of a Bootstrap_Key made by new_bootstrap_key "
-                    "and size its n (device-resident key)\n");
-    abort();
-  }
-  mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
-  const int n = key->n, N = key->N, k = key->k;
-  const size_t acc_w = (size_t)(k + 1) * N;
-  Torus *h = (Torus *)hstage_alloc(sizeof(Torus) * (acc_w + n + 1));
-  trlwe_to_flat(h, tv);
-  memcpy(h + acc_w, a, sizeof(Torus) * (size_t)n);
-  h[acc_w + n] = 0;
-  Torus *d = (Torus *)stage_alloc(sizeof(Torus) * (acc_w + n + 1));
-  dev_copy(d, h, sizeof(Torus) * (acc_w + n + 1), HIP_H2D);
-  if (mosfhet_hip_blind_rotate_batch(ctx, (mosfhet_hip_bsk_t)mosfhet_bootstrap_key_device(key), d, d + acc_w, 1, NULL) ||
-      mosfhet_hip_ctx_sync(ctx, NULL))
-    die("blind_rotate");
-  dev_copy(h, d, sizeof(Torus) * acc_w, HIP_D2H);
-  trlwe_from_flat(tv, h);
-  stage_free(d);
-  hstage_free(h);
+  mc_hstage_free(h);
 }
 
 /* ------------------------------------------------------------------ Galois-automorphism bootstrap */
@@ -880,7 +828,7 @@ void mosfhet_gen_bootstrap_key_ga_flat(Torus *out, TRGSW_Key out_key, TLWE_Key i
   TRGSW tmp = trgsw_alloc_new_sample(l, out_key->Bg_bit, k, N);
   for (int i = 0; i < in_key->n; i++) {
     trgsw_monomial_sample(tmp, 1, (int)in_key->s[i], out_key);   /* src/bootstrap_ga.c:19 */
-    for (int q = 0; q < (k + 1) * l; q++) trlwe_to_flat(out + (size_t)i * sz + q * row, tmp->samples[q]);
+    for (int q = 0; q < (k + 1) * l; q++) mc_trlwe_to_flat(out + (size_t)i * sz + q * row, tmp->samples[q]);
   }
   free_trgsw(tmp);
 }
@@ -895,7 +843,7 @@ void mosfhet_gen_automorphism_keyset_flat(Torus *out, TRLWE_Key key, int t, int 
     for (int r = 0; r < t; r++) {
       for (int i = 0; i < N; i++) msg->coeffs[i] = s2->coeffs[i] * ((Torus)1 << (W - (r + 1) * base_bit));
       trlwe_sample(tmp, msg, key);
-      trlwe_to_flat(out + (((size_t)j * t + r) * 2) * N, tmp);
+      mc_trlwe_to_flat(out + (((size_t)j * t + r) * 2) * N, tmp);
     }
   }
   free_polynomial(s2);
@@ -904,20 +852,21 @@ void mosfhet_gen_automorphism_keyset_flat(Torus *out, TRLWE_Key key, int t, int 
 }
 
 static mosfhet_hip_gak_t fft_ks_keys_new(TRLWE_Key out_key, const Torus *msgs, int entries, int t, int base_bit, const char *who);
+static TRLWE_KS_Key trlwe_ks_header(void *dev, int entry, int owner, int t, int base_bit);
 
 Bootstrap_GA_Key new_bootstrap_key_ga(TRGSW_Key out_key, TLWE_Key in_key) {
   const int l = out_key->l, k = out_key->trlwe_key->k, N = out_key->trlwe_key->s[0]->N, n = in_key->n;
   if (k != 1) { fprintf(stderr, "mosfhet_amd: new_bootstrap_key_ga: k = 1 only\n"); abort(); }
   mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
-  Bootstrap_GA_Key res = (Bootstrap_GA_Key)xmalloc(sizeof(*res));
+  Bootstrap_GA_Key res = (Bootstrap_GA_Key)mc_xmalloc(sizeof(*res));
   res->n = n; res->k = k; res->l = l; res->N = N; res->Bg_bit = out_key->Bg_bit; res->unfolding = 1;
   res->su = NULL;
   /* the TRGSW(X^{s_i}) samples are encrypted on the device (mosfhet_hip_bsk_generate, ga = 1) */
   mosfhet_hip_bsk_t dev = NULL;
-  if (mosfhet_hip_bsk_generate(ctx, &dev, out_key->trlwe_key->s[0]->coeffs, N, in_key->s, n, l, out_key->Bg_bit, out_key->trlwe_key->sigma, rnd64(), 1))
-    die("new_bootstrap_key_ga");
+  if (mosfhet_hip_bsk_generate(ctx, &dev, out_key->trlwe_key->s[0]->coeffs, N, in_key->s, n, l, out_key->Bg_bit, out_key->trlwe_key->sigma, mc_rnd64(), 1))
+    mc_die("new_bootstrap_key_ga");
   /* automorphism key set (src/bootstrap_ga.c:10: t = l, base_bit = Bg_bit): entry j switches from s(X^(2j+1)), encrypted on the device too */
-  Torus *msgs = (Torus *)xmalloc(sizeof(Torus) * (size_t)N * N);
+  Torus *msgs = (Torus *)mc_xmalloc(sizeof(Torus) * (size_t)N * N);
   TorusPolynomial perm = polynomial_new_torus_polynomial(N);
   for (int j = 0; j < N; j++) {
     polynomial_permute(perm, out_key->trlwe_key->s[0], (uint64_t)(2 * j + 1));
@@ -926,17 +875,17 @@ Bootstrap_GA_Key new_bootstrap_key_ga(TRGSW_Key out_key, TLWE_Key in_key) {
   free_polynomial(perm);
   mosfhet_hip_gak_t gak = fft_ks_keys_new(out_key->trlwe_key, msgs, N, l, out_key->Bg_bit, "new_bootstrap_key_ga (automorphism keys)");
   free(msgs);
-  res->s = (TRGSW_DFT *)xmalloc(sizeof(TRGSW_DFT));
+  res->s = (TRGSW_DFT *)mc_xmalloc(sizeof(TRGSW_DFT));
   res->s[0] = (TRGSW_DFT)dev;
-  res->ak = (void **)xmalloc(sizeof(void *));
+  res->ak = (void **)mc_xmalloc(sizeof(void *));
   res->ak[0] = gak;
   return res;
 }
 
 void free_bootstrap_key_ga(Bootstrap_GA_Key key) {
   if (!key) return;
-  mosfhet_hip_bsk_destroy((mosfhet_hip_bsk_t)key->s[0]);
-  mosfhet_hip_gak_destroy((mosfhet_hip_gak_t)key->ak[0]);
+  mosfhet_hip_bsk_destroy((mosfhet_hip_bsk_t)key->device);
+  mosfhet_hip_gak_destroy((mosfhet_hip_gak_t)key->ak_device);
   free(key->s);
   free(key->ak);
   free(key);
@@ -947,20 +896,20 @@ static void bootstrap_ga_many(TLWE *out, TRLWE out_trlwe, TRLWE tv, TLWE *in, in
   const int n = key->n, N = key->N, extract = out != NULL;
   const size_t in_w = (size_t)count * (n + 1), tv_w = (size_t)2 * N;
   const size_t out_w = extract ? (size_t)count * (N + 1) : (size_t)count * tv_w;
-  Torus *h = (Torus *)hstage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
+  Torus *h = (Torus *)mc_hstage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
   tlwe_array_to_flat(h, in, count, n);
-  trlwe_to_flat(h + in_w, tv);
-  Torus *d = (Torus *)stage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
-  dev_copy(d, h, sizeof(Torus) * (in_w + tv_w), HIP_H2D);
-  if (mosfhet_hip_functional_bootstrap_ga_batch(ctx, (mosfhet_hip_bsk_t)key->s[0], (mosfhet_hip_gak_t)key->ak[0], d + in_w + tv_w, d + in_w, 1, d,
+  mc_trlwe_to_flat(h + in_w, tv);
+  Torus *d = (Torus *)mc_stage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
+  mc_dev_copy(d, h, sizeof(Torus) * (in_w + tv_w), HIP_H2D);
+  if (mosfhet_hip_functional_bootstrap_ga_batch(ctx, (mosfhet_hip_bsk_t)key->device, (mosfhet_hip_gak_t)key->ak_device, d + in_w + tv_w, d + in_w, 1, d,
                                                 count, torus_base, extract, NULL) ||
       mosfhet_hip_ctx_sync(ctx, NULL))
-    die("functional_bootstrap_ga");
-  dev_copy(h + in_w + tv_w, d + in_w + tv_w, sizeof(Torus) * out_w, HIP_D2H);
+    mc_die("functional_bootstrap_ga");
+  mc_dev_copy(h + in_w + tv_w, d + in_w + tv_w, sizeof(Torus) * out_w, HIP_D2H);
   if (extract) tlwe_array_from_flat(out, h + in_w + tv_w, count, N);
-  else trlwe_from_flat(out_trlwe, h + in_w + tv_w);
+  else mc_trlwe_from_flat(out_trlwe, h + in_w + tv_w);
   stage_free(d);
-  hstage_free(h);
+  mc_hstage_free(h);
 }
 
 void functional_bootstrap_ga_batch(TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_GA_Key key, int torus_base) {
@@ -990,18 +939,18 @@ void mosfhet_gen_tlwe_ks_key_flat(Torus *out, TLWE_Key out_key, TLWE_Key in_key,
 static TLWE_KS_Key tlwe_ks_wrap(Torus *flat, int n_in, int n_out, int t, int base_bit, const char *who) {
   const int base = 1 << base_bit;
   const size_t row = (size_t)n_out + 1;
-  TLWE_KS_Key res = (TLWE_KS_Key)xmalloc(sizeof(*res));
+  TLWE_KS_Key res = (TLWE_KS_Key)mc_xmalloc(sizeof(*res));
   res->base_bit = base_bit;
   res->t = t;
   res->n = n_in;
-  res->s = (TLWE ***)xmalloc(sizeof(TLWE **) * (size_t)n_in);
+  res->s = (TLWE ***)mc_xmalloc(sizeof(TLWE **) * (size_t)n_in);
   for (int i = 0; i < n_in; i++) {
-    res->s[i] = (TLWE **)xmalloc(sizeof(TLWE *) * (size_t)t);
+    res->s[i] = (TLWE **)mc_xmalloc(sizeof(TLWE *) * (size_t)t);
     for (int j = 0; j < t; j++) {
-      res->s[i][j] = (TLWE *)xmalloc(sizeof(TLWE) * (size_t)(base - 1));
+      res->s[i][j] = (TLWE *)mc_xmalloc(sizeof(TLWE) * (size_t)(base - 1));
       for (int v = 0; v < base - 1; v++) {
         Torus *r = flat + (((size_t)i * t + j) * (base - 1) + v) * row;
-        TLWE c = (TLWE)xmalloc(sizeof(*c));
+        TLWE c = (TLWE)mc_xmalloc(sizeof(*c));
         c->a = r;
         c->b = r[n_out];
         c->n = n_out;
@@ -1010,14 +959,14 @@ static TLWE_KS_Key tlwe_ks_wrap(Torus *flat, int n_in, int n_out, int t, int bas
     }
   }
   mosfhet_hip_ksk_t dev = NULL;
-  if (mosfhet_hip_ksk_create((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, flat, n_in, n_out, t, base_bit)) die(who);
+  if (mosfhet_hip_ksk_create((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, flat, n_in, n_out, t, base_bit)) mc_die(who);
   res->device = dev;
   return res;
 }
 
 TLWE_KS_Key tlwe_new_KS_key(TLWE_Key out_key, TLWE_Key in_key, int t, int base_bit) {
   const size_t words = (size_t)in_key->n * t * ((1 << base_bit) - 1) * ((size_t)out_key->n + 1);
-  Torus *flat = (Torus *)xmalloc(sizeof(Torus) * words);
+  Torus *flat = (Torus *)mc_xmalloc(sizeof(Torus) * words);
   mosfhet_gen_tlwe_ks_key_flat(flat, out_key, in_key, t, base_bit);
   return tlwe_ks_wrap(flat, in_key->n, out_key->n, t, base_bit, "tlwe_new_KS_key");
 }
@@ -1043,16 +992,16 @@ void tlwe_keyswitch_batch(TLWE *out, TLWE *in, int count, TLWE_KS_Key ks) {
   mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
   const int n_in = ks->n, n_out = out[0]->n;
   const size_t in_w = (size_t)count * (n_in + 1), out_w = (size_t)count * (n_out + 1);
-  Torus *h = (Torus *)hstage_alloc(sizeof(Torus) * (in_w + out_w));
+  Torus *h = (Torus *)mc_hstage_alloc(sizeof(Torus) * (in_w + out_w));
   tlwe_array_to_flat(h, in, count, n_in);
-  Torus *d = (Torus *)stage_alloc(sizeof(Torus) * (in_w + out_w));
-  dev_copy(d, h, sizeof(Torus) * in_w, HIP_H2D);
+  Torus *d = (Torus *)mc_stage_alloc(sizeof(Torus) * (in_w + out_w));
+  mc_dev_copy(d, h, sizeof(Torus) * in_w, HIP_H2D);
   if (mosfhet_hip_tlwe_keyswitch_batch(ctx, (mosfhet_hip_ksk_t)ks->device, d + in_w, d, count, NULL) || mosfhet_hip_ctx_sync(ctx, NULL))
-    die("tlwe_keyswitch");
-  dev_copy(h + in_w, d + in_w, sizeof(Torus) * out_w, HIP_D2H);
+    mc_die("tlwe_keyswitch");
+  mc_dev_copy(h + in_w, d + in_w, sizeof(Torus) * out_w, HIP_D2H);
   tlwe_array_from_flat(out, h + in_w, count, n_out);
   stage_free(d);
-  hstage_free(h);
+  mc_hstage_free(h);
 }
 
 void tlwe_keyswitch(TLWE out, TLWE in, TLWE_KS_Key ks_key) { tlwe_keyswitch_batch(&out, &in, 1, ks_key); }
@@ -1066,7 +1015,7 @@ void mosfhet_gen_trlwe_ks_key_flat(Torus *out, const Torus *s_in, TRLWE_Key out_
   for (int r = 0; r < t; r++) {
     for (int i = 0; i < N; i++) msg->coeffs[i] = s_in[i] * ((Torus)1 << (W - (r + 1) * base_bit));
     trlwe_sample(tmp, msg, out_key);
-    trlwe_to_flat(out + (size_t)r * 2 * N, tmp);
+    mc_trlwe_to_flat(out + (size_t)r * 2 * N, tmp);
   }
   free_polynomial(msg);
   free_trlwe(tmp);
@@ -1075,7 +1024,7 @@ void mosfhet_gen_trlwe_ks_key_flat(Torus *out, const Torus *s_in, TRLWE_Key out_
 /* entry 0 switches from -s_out * s_in, entry 1 from -s_out   [src/keyswitch.c:39-50] */
 void mosfhet_gen_priv_ks_key_flat(Torus *out, TRLWE_Key out_key, TRLWE_Key in_key, int t, int base_bit) {
   const int N = out_key->s[0]->N;
-  Torus *neg = (Torus *)xmalloc(sizeof(Torus) * (size_t)N), *prod = (Torus *)xmalloc(sizeof(Torus) * (size_t)N);
+  Torus *neg = (Torus *)mc_xmalloc(sizeof(Torus) * (size_t)N), *prod = (Torus *)mc_xmalloc(sizeof(Torus) * (size_t)N);
   for (int i = 0; i < N; i++) neg[i] = (Torus)0 - out_key->s[0]->coeffs[i];
   memset(prod, 0, sizeof(Torus) * (size_t)N);
   negacyclic_mul_addto(prod, neg, in_key->s[0]->coeffs, N);
@@ -1094,13 +1043,13 @@ void mosfhet_gen_packing1_ks_key_flat(Torus *out, TRLWE_Key out_key, TLWE_Key in
       for (int v = 1; v < base; v++) {
         trlwe_sample(tmp, NULL, out_key);
         tmp->b->coeffs[0] += in_key->s[i] * (Torus)v * ((Torus)1 << (W - (j + 1) * base_bit));
-        trlwe_to_flat(out + ((((size_t)i * t + j) * (base - 1)) + (v - 1)) * 2 * N, tmp);
+        mc_trlwe_to_flat(out + ((((size_t)i * t + j) * (base - 1)) + (v - 1)) * 2 * N, tmp);
       }
   free_trlwe(tmp);
 }
 
 static TRLWE_KS_Key trlwe_ks_header(void *dev, int entry, int owner, int t, int base_bit) {
-  TRLWE_KS_Key res = (TRLWE_KS_Key)xmalloc(sizeof(*res));
+  TRLWE_KS_Key res = (TRLWE_KS_Key)mc_xmalloc(sizeof(*res));
   res->s = NULL; res->base_bit = base_bit; res->t = t; res->k = 1;
   res->device = dev; res->entry = entry; res->owner = owner;
   return res;
@@ -1110,8 +1059,8 @@ static TRLWE_KS_Key trlwe_ks_header(void *dev, int entry, int owner, int t, int 
 static mosfhet_hip_gak_t fft_ks_keys_new(TRLWE_Key out_key, const Torus *msgs, int entries, int t, int base_bit, const char *who) {
   mosfhet_hip_gak_t dev = NULL;
   if (mosfhet_hip_trlwe_ksk_generate((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, out_key->s[0]->coeffs, out_key->s[0]->N, msgs, entries, t, base_bit,
-                                     out_key->sigma, rnd64()))
-    die(who);
+                                     out_key->sigma, mc_rnd64()))
+    mc_die(who);
   return dev;
 }
 
@@ -1124,13 +1073,13 @@ TRLWE_KS_Key *trlwe_new_priv_KS_key(TRLWE_Key out_key, TRLWE_Key in_key, int t, 
   const int N = out_key->s[0]->N;
   if (out_key->k != 1 || in_key->k != 1) { fprintf(stderr, "mosfhet_amd: trlwe_new_priv_KS_key: k = 1 only\n"); abort(); }
   /* entry 0 switches from -s_out * s_in, entry 1 from -s_out (src/keyswitch.c:39-50) */
-  Torus *msgs = (Torus *)xmalloc(sizeof(Torus) * (size_t)2 * N);
+  Torus *msgs = (Torus *)mc_xmalloc(sizeof(Torus) * (size_t)2 * N);
   memset(msgs, 0, sizeof(Torus) * (size_t)N);
   for (int i = 0; i < N; i++) msgs[N + i] = (Torus)0 - out_key->s[0]->coeffs[i];
   negacyclic_mul_addto(msgs, msgs + N, in_key->s[0]->coeffs, N);
   mosfhet_hip_gak_t dev = fft_ks_keys_new(out_key, msgs, 2, t, base_bit, "trlwe_new_priv_KS_key");
   free(msgs);
-  TRLWE_KS_Key *res = (TRLWE_KS_Key *)xmalloc(sizeof(TRLWE_KS_Key) * 2);
+  TRLWE_KS_Key *res = (TRLWE_KS_Key *)mc_xmalloc(sizeof(TRLWE_KS_Key) * 2);
   res[0] = trlwe_ks_header(dev, 0, 1, t, base_bit);   /* entry 0 owns the shared device key set */
   res[1] = trlwe_ks_header(dev, 1, 0, t, base_bit);
   return res;
@@ -1146,17 +1095,17 @@ static void trlwe_ks_run(int mode, TRLWE out, TRLWE in, TRLWE_KS_Key key) {
   mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
   const int N = in->b->N;
   const size_t w = (size_t)2 * N;
-  Torus *h = (Torus *)hstage_alloc(sizeof(Torus) * w);
-  trlwe_to_flat(h, in);
-  Torus *d = (Torus *)stage_alloc(sizeof(Torus) * 2 * w);
-  dev_copy(d, h, sizeof(Torus) * w, HIP_H2D);
+  Torus *h = (Torus *)mc_hstage_alloc(sizeof(Torus) * w);
+  mc_trlwe_to_flat(h, in);
+  Torus *d = (Torus *)mc_stage_alloc(sizeof(Torus) * 2 * w);
+  mc_dev_copy(d, h, sizeof(Torus) * w, HIP_H2D);
   int rc = mode ? mosfhet_hip_trlwe_priv_keyswitch_2_batch(ctx, (mosfhet_hip_gak_t)key->device, d + w, d, 1, NULL)
                 : mosfhet_hip_trlwe_keyswitch_batch(ctx, (mosfhet_hip_gak_t)key->device, key->entry, d + w, d, 1, NULL);
-  if (rc || mosfhet_hip_ctx_sync(ctx, NULL)) die(mode ? "trlwe_priv_keyswitch_2" : "trlwe_keyswitch");
-  dev_copy(h, d + w, sizeof(Torus) * w, HIP_D2H);
-  trlwe_from_flat(out, h);
+  if (rc || mosfhet_hip_ctx_sync(ctx, NULL)) mc_die(mode ? "trlwe_priv_keyswitch_2" : "trlwe_keyswitch");
+  mc_dev_copy(h, d + w, sizeof(Torus) * w, HIP_D2H);
+  mc_trlwe_from_flat(out, h);
   stage_free(d);
-  hstage_free(h);
+  mc_hstage_free(h);
 }
 
 void trlwe_keyswitch(TRLWE out, TRLWE in, TRLWE_KS_Key ks_key) { trlwe_ks_run(0, out, in, ks_key); }
@@ -1167,7 +1116,7 @@ void trlwe_priv_keyswitch_2(TRLWE out, TRLWE in, TRLWE_KS_Key *ks_key) { trlwe_k
 static Generic_KS_Key table_key_new(int kind, TRLWE_Key out_key, TLWE_Key in_key, int t, int base_bit, const char *who) {
   const int N = out_key->s[0]->N;
   if (out_key->k != 1) { fprintf(stderr, "mosfhet_amd: %s: k = 1 only\n", who); abort(); }
-  Generic_KS_Key res = (Generic_KS_Key)xmalloc(sizeof(*res));
+  Generic_KS_Key res = (Generic_KS_Key)mc_xmalloc(sizeof(*res));
   res->s = NULL; res->base_bit = base_bit; res->t = t; res->n = in_key->n; res->include_b = kind;
   mosfhet_hip_ksk_t dev = NULL;
   /* seed-compressed, like the reference's default build (USE_COMPRESSED_TRLWE, src/keyswitch.c:231-241): half the bytes in HBM, the key switches
@@ -1175,10 +1124,10 @@ static Generic_KS_Key table_key_new(int kind, TRLWE_Key out_key, TLWE_Key in_key
   const char *full = getenv("MOSFHET_HIP_FULL_TABLE_KEYS");
   int rc = (full && full[0] == '1')
                ? mosfhet_hip_trlwe_table_ksk_generate((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, kind, out_key->s[0]->coeffs, N, in_key->s, in_key->n, t,
-                                                      base_bit, out_key->sigma, rnd64())
+                                                      base_bit, out_key->sigma, mc_rnd64())
                : mosfhet_hip_trlwe_table_ksk_generate_compressed((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, kind, out_key->s[0]->coeffs, N, in_key->s,
-                                                                 in_key->n, t, base_bit, out_key->sigma, rnd64());
-  if (rc) die(who);
+                                                                 in_key->n, t, base_bit, out_key->sigma, mc_rnd64());
+  if (rc) mc_die(who);
   res->device = dev;
   return res;
 }
@@ -1197,35 +1146,35 @@ void trlwe_packing1_keyswitch(TRLWE out, TLWE in, Generic_KS_Key ks) {
   mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
   const int N = out->b->N, n = ks->n;
   const size_t in_w = (size_t)n + 1, out_w = (size_t)2 * N;
-  Torus *h = (Torus *)hstage_alloc(sizeof(Torus) * (in_w + out_w));
+  Torus *h = (Torus *)mc_hstage_alloc(sizeof(Torus) * (in_w + out_w));
   tlwe_array_to_flat(h, &in, 1, n);
-  Torus *d = (Torus *)stage_alloc(sizeof(Torus) * (in_w + out_w));
-  dev_copy(d, h, sizeof(Torus) * in_w, HIP_H2D);
+  Torus *d = (Torus *)mc_stage_alloc(sizeof(Torus) * (in_w + out_w));
+  mc_dev_copy(d, h, sizeof(Torus) * in_w, HIP_H2D);
   if (mosfhet_hip_trlwe_packing1_keyswitch_batch(ctx, (mosfhet_hip_ksk_t)ks->device, d + in_w, d, 1, NULL) || mosfhet_hip_ctx_sync(ctx, NULL))
-    die("trlwe_packing1_keyswitch");
-  dev_copy(h + in_w, d + in_w, sizeof(Torus) * out_w, HIP_D2H);
-  trlwe_from_flat(out, h + in_w);
+    mc_die("trlwe_packing1_keyswitch");
+  mc_dev_copy(h + in_w, d + in_w, sizeof(Torus) * out_w, HIP_D2H);
+  mc_trlwe_from_flat(out, h + in_w);
   stage_free(d);
-  hstage_free(h);
+  mc_hstage_free(h);
 }
 
 void circuit_bootstrap_3_batch(TRGSW *out, TLWE *in, int count, Bootstrap_Key key, TRLWE_KS_Key *kska, Generic_KS_Key kskb) {
   mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
   const int n = key->n, N = key->N, l = key->l;
   const size_t in_w = (size_t)count * (n + 1), row = (size_t)2 * N, out_w = (size_t)count * 2 * l * row;
-  Torus *h = (Torus *)hstage_alloc(sizeof(Torus) * (in_w + out_w));
+  Torus *h = (Torus *)mc_hstage_alloc(sizeof(Torus) * (in_w + out_w));
   tlwe_array_to_flat(h, in, count, n);
-  Torus *d = (Torus *)stage_alloc(sizeof(Torus) * (in_w + out_w));
-  dev_copy(d, h, sizeof(Torus) * in_w, HIP_H2D);
-  if (mosfhet_hip_circuit_bootstrap_3_batch(ctx, (mosfhet_hip_bsk_t)key->s[0], (mosfhet_hip_gak_t)kska[0]->device, (mosfhet_hip_ksk_t)kskb->device,
+  Torus *d = (Torus *)mc_stage_alloc(sizeof(Torus) * (in_w + out_w));
+  mc_dev_copy(d, h, sizeof(Torus) * in_w, HIP_H2D);
+  if (mosfhet_hip_circuit_bootstrap_3_batch(ctx, (mosfhet_hip_bsk_t)key->device, (mosfhet_hip_gak_t)kska[0]->device, (mosfhet_hip_ksk_t)kskb->device,
                                             d + in_w, d, count, NULL) ||
       mosfhet_hip_ctx_sync(ctx, NULL))
-    die("circuit_bootstrap_3");
-  dev_copy(h + in_w, d + in_w, sizeof(Torus) * out_w, HIP_D2H);
+    mc_die("circuit_bootstrap_3");
+  mc_dev_copy(h + in_w, d + in_w, sizeof(Torus) * out_w, HIP_D2H);
   for (int b = 0; b < count; b++)
-    for (int q = 0; q < 2 * l; q++) trlwe_from_flat(out[b]->samples[q], h + in_w + ((size_t)b * 2 * l + q) * row);
+    for (int q = 0; q < 2 * l; q++) mc_trlwe_from_flat(out[b]->samples[q], h + in_w + ((size_t)b * 2 * l + q) * row);
   stage_free(d);
-  hstage_free(h);
+  mc_hstage_free(h);
 }
 
 void circuit_bootstrap_3(TRGSW out, TLWE in, Bootstrap_Key key, TRLWE_KS_Key *kska, Generic_KS_Key kskb) {
@@ -1237,15 +1186,15 @@ typedef struct { Torus *h, *d; size_t words; } Buf;
 static Buf buf_new(size_t words) {
   Buf b;
   b.words = words;
-  b.h = (Torus *)hstage_alloc(sizeof(Torus) * (words ? words : 1));
-  b.d = (Torus *)stage_alloc(sizeof(Torus) * (words ? words : 1));
+  b.h = (Torus *)mc_hstage_alloc(sizeof(Torus) * (words ? words : 1));
+  b.d = (Torus *)mc_stage_alloc(sizeof(Torus) * (words ? words : 1));
   return b;
 }
-static void buf_up(Buf *b, size_t off, size_t words) { dev_copy(b->d + off, b->h + off, sizeof(Torus) * words, HIP_H2D); }
-static void buf_down(Buf *b, size_t off, size_t words) { dev_copy(b->h + off, b->d + off, sizeof(Torus) * words, HIP_D2H); }
-static void buf_free(Buf *b) { stage_free(b->d); hstage_free(b->h); }
+static void buf_up(Buf *b, size_t off, size_t words) { mc_dev_copy(b->d + off, b->h + off, sizeof(Torus) * words, HIP_H2D); }
+static void buf_down(Buf *b, size_t off, size_t words) { mc_dev_copy(b->h + off, b->d + off, sizeof(Torus) * words, HIP_D2H); }
+static void buf_free(Buf *b) { stage_free(b->d); mc_hstage_free(b->h); }
 static mosfhet_hip_ctx_t ectx(void) { return (mosfhet_hip_ctx_t)mosfhet_engine_ctx(); }
-static void check_rc(int rc, const char *what) { if (rc || mosfhet_hip_ctx_sync(ectx(), NULL)) die(what); }
+static void check_rc(int rc, const char *what) { if (rc || mosfhet_hip_ctx_sync(ectx(), NULL)) mc_die(what); }
 
 /* s[i][j][v-1] = TRLWE_out( -s_out * s_i v 2^(64-(j+1)bb) ), i <= n, s_n = -1 for the b word   [src/keyswitch.c:611-637] */
 void mosfhet_gen_priv_sk_ks_key_flat(Torus *out, TRLWE_Key out_key, TLWE_Key in_key, int t, int base_bit) {
@@ -1258,7 +1207,7 @@ void mosfhet_gen_priv_sk_ks_key_flat(Torus *out, TRLWE_Key out_key, TLWE_Key in_
         const Torus dec_key = s_i * (Torus)v * ((Torus)1 << (W - (j + 1) * base_bit));
         trlwe_sample(tmp, NULL, out_key);
         for (int e = 0; e < N; e++) tmp->b->coeffs[e] += ((Torus)0 - out_key->s[0]->coeffs[e]) * dec_key;
-        trlwe_to_flat(out + ((((size_t)i * t + j) * (base - 1)) + (v - 1)) * 2 * N, tmp);
+        mc_trlwe_to_flat(out + ((((size_t)i * t + j) * (base - 1)) + (v - 1)) * 2 * N, tmp);
       }
   }
   free_trlwe(tmp);
@@ -1275,7 +1224,7 @@ void trlwe_priv_keyswitch(TRLWE out, TLWE in, Generic_KS_Key ks) {
   buf_up(&b, 0, (size_t)n + 1);
   check_rc(mosfhet_hip_trlwe_priv_keyswitch_batch(ectx(), (mosfhet_hip_ksk_t)ks->device, b.d + n + 1, b.d, 1, NULL), "trlwe_priv_keyswitch");
   buf_down(&b, (size_t)n + 1, (size_t)2 * N);
-  trlwe_from_flat(out, b.h + n + 1);
+  mc_trlwe_from_flat(out, b.h + n + 1);
   buf_free(&b);
 }
 
@@ -1285,11 +1234,11 @@ static void circuit_bootstrap_many(TRGSW *out, TLWE *in, int count, Bootstrap_Ke
   Buf b = buf_new(in_w + out_w);
   tlwe_array_to_flat(b.h, in, count, n);
   buf_up(&b, 0, in_w);
-  check_rc(mosfhet_hip_circuit_bootstrap_batch(ectx(), (mosfhet_hip_bsk_t)key->s[0], (mosfhet_hip_ksk_t)kska->device, (mosfhet_hip_ksk_t)kskb->device, b.d + in_w,
+  check_rc(mosfhet_hip_circuit_bootstrap_batch(ectx(), (mosfhet_hip_bsk_t)key->device, (mosfhet_hip_ksk_t)kska->device, (mosfhet_hip_ksk_t)kskb->device, b.d + in_w,
                                                b.d, count, variant, NULL), "circuit_bootstrap");
   buf_down(&b, in_w, out_w);
   for (int c = 0; c < count; c++)
-    for (int q = 0; q < 2 * l; q++) trlwe_from_flat(out[c]->samples[q], b.h + in_w + ((size_t)c * 2 * l + q) * row);
+    for (int q = 0; q < 2 * l; q++) mc_trlwe_from_flat(out[c]->samples[q], b.h + in_w + ((size_t)c * 2 * l + q) * row);
   buf_free(&b);
 }
 
@@ -1297,20 +1246,6 @@ void circuit_bootstrap(TRGSW out, TLWE in, Bootstrap_Key key, Generic_KS_Key ksk
 void circuit_bootstrap_2(TRGSW out, TLWE in, Bootstrap_Key key, Generic_KS_Key kska, Generic_KS_Key kskb) { circuit_bootstrap_many(&out, &in, 1, key, kska, kskb, 1); }
 void circuit_bootstrap_2_batch(TRGSW *out, TLWE *in, int count, Bootstrap_Key key, Generic_KS_Key kska, Generic_KS_Key kskb) {
   circuit_bootstrap_many(out, in, count, key, kska, kskb, 1);
-}
-
-void public_mux(TRLWE out, TorusPolynomial p0, TorusPolynomial p1, TRLWE *selector, int l, int Bg_bit) {
-  const int N = out->b->N;
-  const size_t row = (size_t)2 * N;
-  Buf b = buf_new(2 * (size_t)N + l * row + row);
-  memcpy(b.h, p0->coeffs, sizeof(Torus) * N);
-  memcpy(b.h + N, p1->coeffs, sizeof(Torus) * N);
-  for (int i = 0; i < l; i++) trlwe_to_flat(b.h + 2 * N + i * row, selector[i]);
-  buf_up(&b, 0, 2 * (size_t)N + l * row);
-  check_rc(mosfhet_hip_public_mux_batch(ectx(), b.d + 2 * N + l * row, b.d, b.d + N, b.d + 2 * N, N, l, Bg_bit, 1, NULL), "public_mux");
-  buf_down(&b, 2 * (size_t)N + l * row, row);
-  trlwe_from_flat(out, b.h + 2 * N + l * row);
-  buf_free(&b);
 }
 
 static void fdfb_ks21_many(TLWE *out, TorusPolynomial tv, TLWE *in, int count, Bootstrap_Key key, Generic_KS_Key ksk, int torus_base, int variant) {
@@ -1321,7 +1256,7 @@ static void fdfb_ks21_many(TLWE *out, TorusPolynomial tv, TLWE *in, int count, B
   tlwe_array_to_flat(b.h, in, count, n);
   memcpy(b.h + in_w, tv->coeffs, sizeof(Torus) * tv_w);
   buf_up(&b, 0, in_w + tv_w);
-  check_rc(mosfhet_hip_full_domain_functional_bootstrap_KS21_batch(ectx(), (mosfhet_hip_bsk_t)key->s[0], (mosfhet_hip_ksk_t)ksk->device, b.d + in_w + tv_w, b.d + in_w,
+  check_rc(mosfhet_hip_full_domain_functional_bootstrap_KS21_batch(ectx(), (mosfhet_hip_bsk_t)key->device, (mosfhet_hip_ksk_t)ksk->device, b.d + in_w + tv_w, b.d + in_w,
                                                                    b.d, count, torus_base, variant, NULL), "full_domain_functional_bootstrap_KS21");
   buf_down(&b, in_w + tv_w, out_w);
   tlwe_array_from_flat(out, b.h + in_w + tv_w, count, N);
@@ -1341,7 +1276,7 @@ void full_domain_functional_bootstrap_KS21_batch(TLWE *out, TorusPolynomial tv, 
 TRLWE_KS_Key trlwe_new_RL_key(TRLWE_Key key, int t, int base_bit) {
   const int N = key->s[0]->N;
   if (key->k != 1) { fprintf(stderr, "mosfhet_amd: trlwe_new_RL_key: k = 1 only\n"); abort(); }
-  Torus *s2 = (Torus *)xmalloc(sizeof(Torus) * (size_t)N);
+  Torus *s2 = (Torus *)mc_xmalloc(sizeof(Torus) * (size_t)N);
   memset(s2, 0, sizeof(Torus) * (size_t)N);
   negacyclic_mul_addto(s2, key->s[0]->coeffs, key->s[0]->coeffs, N);   /* s^2 (src/keyswitch.c:6) */
   mosfhet_hip_gak_t dev = fft_ks_keys_new(key, s2, 1, t, base_bit, "trlwe_new_RL_key");
@@ -1353,12 +1288,12 @@ void trlwe_tensor_prod_FFT(TRLWE out, TRLWE in1, TRLWE in2, int precision, TRLWE
   const int N = in1->b->N;
   const size_t row = (size_t)2 * N;
   Buf b = buf_new(3 * row);
-  trlwe_to_flat(b.h, in1);
-  trlwe_to_flat(b.h + row, in2);
+  mc_trlwe_to_flat(b.h, in1);
+  mc_trlwe_to_flat(b.h + row, in2);
   buf_up(&b, 0, 2 * row);
   check_rc(mosfhet_hip_trlwe_tensor_prod_FFT_batch(ectx(), (mosfhet_hip_gak_t)rl_key->device, b.d + 2 * row, b.d, b.d + row, precision, 1, NULL), "trlwe_tensor_prod_FFT");
   buf_down(&b, 2 * row, row);
-  trlwe_from_flat(out, b.h + 2 * row);
+  mc_trlwe_from_flat(out, b.h + 2 * row);
   buf_free(&b);
 }
 
@@ -1383,7 +1318,7 @@ static void fdfb_clot21_many(TLWE *out, const Torus *tv_flat, size_t tv_w, TLWE 
   tlwe_array_to_flat(b.h, in, count, n);
   memcpy(b.h + in_w, tv_flat, sizeof(Torus) * tv_w);
   buf_up(&b, 0, in_w + tv_w);
-  check_rc(mosfhet_hip_full_domain_functional_bootstrap_CLOT21_batch(ectx(), (mosfhet_hip_bsk_t)key->s[0], (mosfhet_hip_ksk_t)ksk->device, (mosfhet_hip_gak_t)rlk->device,
+  check_rc(mosfhet_hip_full_domain_functional_bootstrap_CLOT21_batch(ectx(), (mosfhet_hip_bsk_t)key->device, (mosfhet_hip_ksk_t)ksk->device, (mosfhet_hip_gak_t)rlk->device,
                                                                      b.d + in_w + tv_w, b.d + in_w, b.d, count, precision, variant, NULL),
            "full_domain_functional_bootstrap_CLOT21");
   buf_down(&b, in_w + tv_w, out_w);
@@ -1393,9 +1328,9 @@ static void fdfb_clot21_many(TLWE *out, const Torus *tv_flat, size_t tv_w, TLWE 
 
 void full_domain_functional_bootstrap_CLOT21(TLWE out, TRLWE tv[2], TLWE in, Bootstrap_Key key, Generic_KS_Key ksk, TRLWE_KS_Key rlk, int precision) {
   const size_t row = (size_t)2 * key->N;
-  Torus *flat = (Torus *)xmalloc(sizeof(Torus) * 2 * row);
-  trlwe_to_flat(flat, tv[0]);
-  trlwe_to_flat(flat + row, tv[1]);
+  Torus *flat = (Torus *)mc_xmalloc(sizeof(Torus) * 2 * row);
+  mc_trlwe_to_flat(flat, tv[0]);
+  mc_trlwe_to_flat(flat + row, tv[1]);
   fdfb_clot21_many(&out, flat, 2 * row, &in, 1, key, ksk, rlk, precision, 0);
   free(flat);
 }
@@ -1414,9 +1349,9 @@ void multivalue_bootstrap_phase1(TRLWE *out, TLWE in, Bootstrap_Key key, int tor
   Buf b = buf_new((size_t)n + 1 + out_w);
   tlwe_array_to_flat(b.h, &in, 1, n);
   buf_up(&b, 0, (size_t)n + 1);
-  check_rc(mosfhet_hip_multivalue_bootstrap_phase1_batch(ectx(), (mosfhet_hip_bsk_t)key->s[0], b.d + n + 1, b.d, 1, torus_base, NULL), "multivalue_bootstrap_phase1");
+  check_rc(mosfhet_hip_multivalue_bootstrap_phase1_batch(ectx(), (mosfhet_hip_bsk_t)key->device, b.d + n + 1, b.d, 1, torus_base, NULL), "multivalue_bootstrap_phase1");
   buf_down(&b, (size_t)n + 1, out_w);
-  for (int i = 0; i <= torus_base; i++) trlwe_from_flat(out[i], b.h + n + 1 + i * row);
+  for (int i = 0; i <= torus_base; i++) mc_trlwe_from_flat(out[i], b.h + n + 1 + i * row);
   buf_free(&b);
 }
 
@@ -1424,66 +1359,12 @@ void multivalue_bootstrap_phase2(TLWE out, int *in, TRLWE *rotated_tv, int torus
   const int N = rotated_tv[0]->b->N;
   const size_t row = (size_t)2 * N, in_w = (size_t)(torus_base + 1) * row;
   Buf b = buf_new(in_w + N + 1);
-  for (int i = 0; i <= torus_base; i++) trlwe_to_flat(b.h + i * row, rotated_tv[i]);
+  for (int i = 0; i <= torus_base; i++) mc_trlwe_to_flat(b.h + i * row, rotated_tv[i]);
   buf_up(&b, 0, in_w);
   check_rc(mosfhet_hip_multivalue_bootstrap_phase2_batch(ectx(), b.d + in_w, in, b.d, N, torus_base, log_torus_base, 1, NULL), "multivalue_bootstrap_phase2");
   buf_down(&b, in_w, (size_t)N + 1);
   tlwe_array_from_flat(&out, b.h + in_w, 1, N);
   buf_free(&b);
-}
-
-/* TRGSW_DFT: device-resident [2l][2][N/2] complex (reference: host struct, mosfhet.h:111-114) */
-struct _TRGSW_DFT { double *device; int l, Bg_bit, N; };
-
-TRGSW_DFT trgsw_alloc_new_DFT_sample(int l, int Bg_bit, int k, int N) {
-  if (k != 1) { fprintf(stderr, "mosfhet_amd: trgsw_alloc_new_DFT_sample: k = 1 only\n"); abort(); }
-  TRGSW_DFT res = (TRGSW_DFT)xmalloc(sizeof(*res));
-  res->l = l; res->Bg_bit = Bg_bit; res->N = N;
-  res->device = (double *)dev_alloc(sizeof(double) * (size_t)2 * l * 2 * N);
-  return res;
-}
-
-void free_trgsw_DFT(TRGSW_DFT p) {
-  if (!p) return;
-  hipFree(p->device);
-  free(p);
-}
-
-void functional_bootstrap_trgsw_phase1(TRGSW_DFT out, TLWE in, Bootstrap_Key key, int torus_base) {
-  const int n = key->n;
-  Buf b = buf_new((size_t)n + 1);
-  tlwe_array_to_flat(b.h, &in, 1, n);
-  buf_up(&b, 0, (size_t)n + 1);
-  check_rc(mosfhet_hip_functional_bootstrap_trgsw_phase1_batch(ectx(), (mosfhet_hip_bsk_t)key->s[0], out->device, b.d, 1, torus_base, NULL), "functional_bootstrap_trgsw_phase1");
-  buf_free(&b);
-}
-
-void functional_bootstrap_trgsw_phase2_key(TLWE out, TRGSW_DFT in, TRLWE tv, Bootstrap_Key key) {
-  const int N = tv->b->N;
-  const size_t row = (size_t)2 * N;
-  Buf b = buf_new(row + N + 1);
-  trlwe_to_flat(b.h, tv);
-  buf_up(&b, 0, row);
-  check_rc(mosfhet_hip_functional_bootstrap_trgsw_phase2_batch(ectx(), (mosfhet_hip_bsk_t)key->s[0], b.d + row, in->device, b.d, 1, 1, NULL), "functional_bootstrap_trgsw_phase2");
-  buf_down(&b, row, (size_t)N + 1);
-  tlwe_array_from_flat(&out, b.h + row, 1, N);
-  buf_free(&b);
-}
-
-/* the reference's signature has no key argument (src/bootstrap.c:297); the gadget comes from the TRGSW_DFT, the engine handle from
- * any registered bootstrap key of that ring and gadget */
-void functional_bootstrap_trgsw_phase2(TLWE out, TRGSW_DFT in, TRLWE tv) {
-  Bootstrap_Key key = NULL;
-  pthread_mutex_lock(&g_lock);
-  for (int i = 0; i < MAX_KEYS && !key; i++)
-    if (g_keys[i] && g_keys[i]->unfolding == 1 && g_keys[i]->N == in->N && g_keys[i]->l == in->l && g_keys[i]->Bg_bit == in->Bg_bit) key = g_keys[i];
-  pthread_mutex_unlock(&g_lock);
-  if (key) {
-    functional_bootstrap_trgsw_phase2_key(out, in, tv, key);
-    return;
-  }
-  fprintf(stderr, "mosfhet_amd: functional_bootstrap_trgsw_phase2: no bootstrap key with this ring / gadget is alive\n");
-  abort();
 }
 
 /* ------------------------------------------------------------------ on-disk formats
@@ -1589,7 +1470,7 @@ TLWE_KS_Key tlwe_load_new_KS_key(FILE *fd) {
   read_ints(fd, v, 4);
   if (v[0] < 1 || v[1] < 1 || v[2] < 1 || v[2] > 8 || v[3] < 1) { fprintf(stderr, "mosfhet_amd: tlwe_load_new_KS_key: bad header\n"); abort(); }
   const size_t words = (size_t)v[0] * v[1] * ((1 << v[2]) - 1) * ((size_t)v[3] + 1);
-  Torus *flat = (Torus *)xmalloc(sizeof(Torus) * words);
+  Torus *flat = (Torus *)mc_xmalloc(sizeof(Torus) * words);
   xread(flat, sizeof(Torus), words, fd);
   return tlwe_ks_wrap(flat, v[0], v[3], v[1], v[2], "tlwe_load_new_KS_key");
 }
@@ -1599,7 +1480,7 @@ TLWE_KS_Key tlwe_load_new_KS_key(FILE *fd) {
 #define KS_IO_CHUNK_BYTES ((size_t)64 << 20)
 void trlwe_save_generic_ks_key(FILE *fd, Generic_KS_Key key) {
   int info[6];
-  if (mosfhet_hip_ksk_info((mosfhet_hip_ksk_t)key->device, info)) die("trlwe_save_generic_ks_key");
+  if (mosfhet_hip_ksk_info((mosfhet_hip_ksk_t)key->device, info)) mc_die("trlwe_save_generic_ks_key");
   const int N = info[1] / 2, k = 1;
   xwrite(&key->base_bit, sizeof(int), 1, fd);
   xwrite(&key->t, sizeof(int), 1, fd);
@@ -1610,10 +1491,10 @@ void trlwe_save_generic_ks_key(FILE *fd, Generic_KS_Key key) {
   const size_t rows = (size_t)info[0] * key->t * ((1 << key->base_bit) - 1), row_bytes = (size_t)info[1] * sizeof(Torus);
   size_t chunk = KS_IO_CHUNK_BYTES / row_bytes;
   if (chunk < 1) chunk = 1;
-  Torus *buf = (Torus *)xmalloc(chunk * row_bytes);
+  Torus *buf = (Torus *)mc_xmalloc(chunk * row_bytes);
   for (size_t r = 0; r < rows; r += chunk) {
     const size_t c = rows - r < chunk ? rows - r : chunk;
-    if (mosfhet_hip_ksk_export_rows((mosfhet_hip_ksk_t)key->device, r, c, buf)) die("trlwe_save_generic_ks_key");
+    if (mosfhet_hip_ksk_export_rows((mosfhet_hip_ksk_t)key->device, r, c, buf)) mc_die("trlwe_save_generic_ks_key");
     xwrite(buf, row_bytes, c, fd);
   }
   free(buf);
@@ -1622,18 +1503,18 @@ Generic_KS_Key trlwe_load_new_generic_ks_key(FILE *fd) {
   int v[6];  /* base_bit, t, n, k, N, include_b */
   read_ints(fd, v, 6);
   if (v[3] != 1 || v[5] < 0 || v[5] > 1) { fprintf(stderr, "mosfhet_amd: trlwe_load_new_generic_ks_key: k = 1 keys only\n"); abort(); }
-  Generic_KS_Key res = (Generic_KS_Key)xmalloc(sizeof(*res));
+  Generic_KS_Key res = (Generic_KS_Key)mc_xmalloc(sizeof(*res));
   res->s = NULL; res->base_bit = v[0]; res->t = v[1]; res->n = v[2]; res->include_b = v[5];
   mosfhet_hip_ksk_t dev = NULL;
-  if (mosfhet_hip_ksk_alloc((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, v[5] ? 2 : 1, v[2], v[4], v[1], v[0])) die("trlwe_load_new_generic_ks_key");
+  if (mosfhet_hip_ksk_alloc((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, v[5] ? 2 : 1, v[2], v[4], v[1], v[0])) mc_die("trlwe_load_new_generic_ks_key");
   const size_t rows = (size_t)(v[2] + v[5]) * v[1] * ((1 << v[0]) - 1), row_bytes = (size_t)2 * v[4] * sizeof(Torus);
   size_t chunk = KS_IO_CHUNK_BYTES / row_bytes;
   if (chunk < 1) chunk = 1;
-  Torus *buf = (Torus *)xmalloc(chunk * row_bytes);
+  Torus *buf = (Torus *)mc_xmalloc(chunk * row_bytes);
   for (size_t r = 0; r < rows; r += chunk) {
     const size_t c = rows - r < chunk ? rows - r : chunk;
     xread(buf, row_bytes, c, fd);
-    if (mosfhet_hip_ksk_import_rows(dev, r, c, buf)) die("trlwe_load_new_generic_ks_key");
+    if (mosfhet_hip_ksk_import_rows(dev, r, c, buf)) mc_die("trlwe_load_new_generic_ks_key");
   }
   free(buf);
   res->device = dev;
@@ -1643,7 +1524,7 @@ Generic_KS_Key trlwe_load_new_generic_ks_key(FILE *fd) {
 /* FFT-based TRLWE key-switch key: header base_bit, t, k_in, k, N (src/keyswitch.c:122-160), layout tag, image of this key's t rows */
 void trlwe_save_KS_key(FILE *fd, TRLWE_KS_Key key) {
   int info[4];
-  if (mosfhet_hip_trlwe_ksk_info((mosfhet_hip_gak_t)key->device, info)) die("trlwe_save_KS_key");
+  if (mosfhet_hip_trlwe_ksk_info((mosfhet_hip_gak_t)key->device, info)) mc_die("trlwe_save_KS_key");
   const int one = 1, N = info[1];
   const unsigned tag = mosfhet_hip_dft_layout_id();
   xwrite(&key->base_bit, sizeof(int), 1, fd);
@@ -1653,8 +1534,8 @@ void trlwe_save_KS_key(FILE *fd, TRLWE_KS_Key key) {
   xwrite(&N, sizeof(int), 1, fd);
   xwrite(&tag, sizeof(tag), 1, fd);
   const size_t bytes = mosfhet_hip_trlwe_ksk_bytes((mosfhet_hip_gak_t)key->device), entry_bytes = bytes / (size_t)info[0];
-  char *img = (char *)xmalloc(bytes);
-  if (mosfhet_hip_trlwe_ksk_export((mosfhet_hip_gak_t)key->device, img)) die("trlwe_save_KS_key");
+  char *img = (char *)mc_xmalloc(bytes);
+  if (mosfhet_hip_trlwe_ksk_export((mosfhet_hip_gak_t)key->device, img)) mc_die("trlwe_save_KS_key");
   xwrite(img + (size_t)key->entry * entry_bytes, 1, entry_bytes, fd);
   free(img);
 }
@@ -1664,10 +1545,10 @@ TRLWE_KS_Key trlwe_load_new_KS_key(FILE *fd) {
   if (v[2] != 1 || v[3] != 1) { fprintf(stderr, "mosfhet_amd: trlwe_load_new_KS_key: k = 1 keys only\n"); abort(); }
   check_layout_tag(fd, "trlwe_load_new_KS_key");
   const size_t bytes = (size_t)v[1] * 2 * v[4] * sizeof(double);
-  char *img = (char *)xmalloc(bytes);
+  char *img = (char *)mc_xmalloc(bytes);
   xread(img, 1, bytes, fd);
   mosfhet_hip_gak_t dev = NULL;
-  if (mosfhet_hip_trlwe_ksk_import((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, img, 1, v[4], v[1], v[0])) die("trlwe_load_new_KS_key");
+  if (mosfhet_hip_trlwe_ksk_import((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, img, 1, v[4], v[1], v[0])) mc_die("trlwe_load_new_KS_key");
   free(img);
   return trlwe_ks_header(dev, 0, 1, v[1], v[0]);
 }
@@ -1684,8 +1565,8 @@ void save_bootstrap_key(FILE *fd, Bootstrap_Key key) {
   xwrite(&key->unfolding, sizeof(int), 1, fd);
   xwrite(&tag, sizeof(tag), 1, fd);
   const size_t bytes = mosfhet_hip_bsk_bytes(dev);
-  char *img = (char *)xmalloc(bytes);
-  if (mosfhet_hip_bsk_export(dev, img)) die("save_bootstrap_key");
+  char *img = (char *)mc_xmalloc(bytes);
+  if (mosfhet_hip_bsk_export(dev, img)) mc_die("save_bootstrap_key");
   xwrite(img, 1, bytes, fd);
   free(img);
 }
@@ -1696,16 +1577,16 @@ Bootstrap_Key load_new_bootstrap_key(FILE *fd) {
   if (v[0] < 1 || v[1] < 1 || v[2] < 1 || v[3] < 2 || v[5] < 1 || v[5] > 8) { fprintf(stderr, "mosfhet_amd: load_new_bootstrap_key: bad header\n"); abort(); }
   const size_t bytes = v[5] == 1 ? (size_t)v[0] * (v[2] + 1) * v[1] * (v[2] + 1) * v[3] * sizeof(double)
                                  : (size_t)v[0] * ((size_t)1 << v[5]) / v[5] * 2 * v[1] * 2 * v[3] * sizeof(Torus);
-  char *img = (char *)xmalloc(bytes);
+  char *img = (char *)mc_xmalloc(bytes);
   xread(img, 1, bytes, fd);
-  Bootstrap_Key res = (Bootstrap_Key)xmalloc(sizeof(*res));
+  Bootstrap_Key res = (Bootstrap_Key)mc_xmalloc(sizeof(*res));
   res->n = v[0]; res->l = v[1]; res->k = v[2]; res->N = v[3]; res->Bg_bit = v[4]; res->unfolding = v[5];
   res->su = NULL;
   mosfhet_hip_bsk_t dev = NULL;
-  if (mosfhet_hip_bsk_import((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, img, v[0], v[2], v[3], v[1], v[4], v[5])) die("load_new_bootstrap_key");
+  if (mosfhet_hip_bsk_import((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, img, v[0], v[2], v[3], v[1], v[4], v[5])) mc_die("load_new_bootstrap_key");
   free(img);
-  res->s = (TRGSW_DFT *)xmalloc(sizeof(TRGSW_DFT));
-  res->s[0] = (TRGSW_DFT)dev;
+  res->device = dev;
+  res->s = key_views(dev, res->n, res->l, res->Bg_bit, res->N);
   remember_key(res);
   return res;
 }

@@ -37,6 +37,9 @@ def build():
     """(Re)build oracle/_ref from /root/reference when that tree is present (this container only)."""
     if os.path.isdir("/root/reference/src"):
         subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "ref")])
+        if os.path.exists(os.path.join(_HERE, "..", "mosfhet_amd", "libmosfhet_hip.so")):
+            # the reference's vertical_packing.c, unchanged, against include/mosfhet.h + the product library (drop-in check, run under -m gpu)
+            subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "ref"), "app"])
         return True
     return False
 

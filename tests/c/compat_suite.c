@@ -1,6 +1,6 @@
 /*
- * GPU test of the MOSFHET-compatible C API (include/mosfhet_compat.h): a plain C program written the way a
- * mosfhet.h caller is (cf. the reference's test/tests.c cases named per function below), linked against
+ * GPU test of the MOSFHET-compatible C API: a plain C program written against <mosfhet.h> (include/mosfhet.h forwards to
+ * include/mosfhet_compat.h) the way a mosfhet.h caller is (cf. the reference's test/tests.c cases named per function below), linked against
  * libmosfhet_hip.so only.  Every case decrypts with the secret keys and applies the reference test's own tolerance.
  * Run by tests/test_gpu_parity.py::test_compat_c_api_suite; exit status = number of failed cases.
  */
@@ -8,7 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include "mosfhet_compat.h"
+#include <mosfhet.h>
 
 static int failures = 0;
 static uint64_t tdist(Torus a, Torus b) {
@@ -238,7 +238,29 @@ static void case_unfolded(void) {
       TLWE in = tlwe_new_sample(double2torus(j / 8.), lwe_key);
       functional_bootstrap(out, tv, in, ubk, 4);
       WITHIN(1ULL << 58, lut[j], tlwe_phase(out, wkey_extracted), "functional_bootstrap (unfolded key)");
+      /* programmable_bootstrap scales its input and calls functional_bootstrap, which dispatches on key->unfolding (src/bootstrap.c:208-219,196-197) */
+      programmable_bootstrap(out, tv, in, ubk, 3, 0, 0);
+      WITHIN(1ULL << 58, lut[j], tlwe_phase(out, wkey_extracted), "programmable_bootstrap (unfolded key)");
       free_tlwe(in);
+    }
+    if (u == 2) {
+      /* a batch past two pipeline chunks with an unfolded key: must equal the single calls (the layer keeps such batches on one stream) */
+      enum { COUNT = 2 * 2048 + 5 };
+      TLWE *in = tlwe_alloc_sample_array(COUNT, n), *bo = tlwe_alloc_sample_array(COUNT, N);
+      for (int i = 0; i < COUNT; i++) tlwe_sample(in[i], double2torus((i % 4) / 8.), lwe_key);
+      functional_bootstrap_batch(bo, tv, in, COUNT, ubk, 4);
+      int bad = 0;
+      for (int i = 0; i < COUNT; i++) bad += tdist(lut[i % 4], tlwe_phase(bo[i], wkey_extracted)) >= (1ULL << 58);
+      CHECK(bad == 0, "%d of %d outputs of the unfolded batch do not decrypt", bad, COUNT);
+      const int probe[5] = {0, 2047, 2048, 4096, COUNT - 1};
+      for (int q = 0; q < 5; q++) {
+        functional_bootstrap(out, tv, in[probe[q]], ubk, 4);
+        CHECK(out->b == bo[probe[q]]->b && !memcmp(out->a, bo[probe[q]]->a, sizeof(Torus) * N), "sample %d of the unfolded batch differs from its single call", probe[q]);
+      }
+      programmable_bootstrap_batch(bo, tv, in, COUNT, ubk, 3, 0, 0);
+      programmable_bootstrap(out, tv, in[2049], ubk, 3, 0, 0);
+      CHECK(out->b == bo[2049]->b && !memcmp(out->a, bo[2049]->a, sizeof(Torus) * N), "programmable_bootstrap_batch (unfolded key) differs from the single call");
+      free_tlwe_array(in, COUNT); free_tlwe_array(bo, COUNT);
     }
     free_bootstrap_key(ubk);
   }
@@ -309,9 +331,11 @@ static void case_circuit_2_mux_trgsw(void) {
   circuit_bootstrap(one, in[0], wbk, wpriv, wpack);
   TorusPolynomial p0 = polynomial_new_torus_polynomial(N), p1 = polynomial_new_torus_polynomial(N);
   for (int i = 0; i < N; i++) { p0->coeffs[i] = int2torus((uint64_t)(i & 7), 3); p1->coeffs[i] = int2torus((uint64_t)((i >> 3) & 7), 3); }
+  TRLWE_DFT *sel_dft = trlwe_alloc_new_DFT_sample_array(wl, k, N);
   for (int b = 0; b < 3; b++) {
     TRGSW g = b < 2 ? sel[b] : one;
-    public_mux(c2, p0, p1, g->samples + wl, wl, wBg);      /* the b rows of TRGSW(m) are the gadget encryption of m */
+    for (int i = 0; i < wl; i++) trlwe_to_DFT(sel_dft[i], g->samples[wl + i]);   /* the b rows of TRGSW(m) are the gadget encryption of m (src/bootstrap.c:417-420) */
+    public_mux(c2, p0, p1, sel_dft, wl, wBg);
     trlwe_phase(ph, c2, wkey);
     const TorusPolynomial want = (b == 1) ? p0 : p1;       /* TRGSW(1) picks p1, TRGSW(0) picks p0 */
     for (int i = 0; i < N; i++) WITHIN(1ULL << 58, want->coeffs[i], ph->coeffs[i], "public_mux with circuit-bootstrapped selector");
@@ -329,7 +353,7 @@ static void case_circuit_2_mux_trgsw(void) {
     WITHIN(1ULL << 58, lut[j], tlwe_phase(out, wkey_extracted), "functional_bootstrap_trgsw");
     free_tlwe(c);
   }
-  free_trgsw_DFT(acc); free_trlwe(tv); free_tlwe(out); free_polynomial(p0); free_polynomial(p1); free_trgsw(one);
+  free_trgsw(acc); free_trlwe_array(sel_dft, wl); free_trlwe(tv); free_tlwe(out); free_polynomial(p0); free_polynomial(p1); free_trgsw(one);
   free_trgsw(sel[0]); free_trgsw(sel[1]); free_tlwe(in[0]); free_tlwe(in[1]); free_tlwe(lw); free_trlwe(c2); free_polynomial(ph);
 }
 
@@ -603,6 +627,147 @@ static void case_big_batch(void) {
   free_tlwe(one); free_tlwe_array(in, COUNT); free_tlwe_array(out, COUNT); free_trlwe(tv);
 }
 
+/* The reference's DFT-level API (SURVEY 8(b) must-keep signatures), used the way applications/leveled_lut/vertical_packing.c:9-52 uses it:
+ * selectors encrypted bit by bit as TRGSW samples and moved to the DFT domain (trgsw_to_DFT), a CMUX tree made of trlwe_sub + trgsw_mul_trlwe_DFT +
+ * trlwe_from_DFT + trlwe_add, then blind_rotate over the remaining selectors and a sample extract.  With MOSFHET_SUITE_DUMP set, inputs and the final
+ * accumulator are written to that file so that tests/test_gpu_parity.py can recompute them with the oracle (bit for bit). */
+static void vp_cmux(TRLWE out, TRLWE in1, TRLWE in2, TRGSW_DFT selector) {
+  TRLWE_DFT tmp = trlwe_alloc_new_DFT_sample(out->k, out->b->N);
+  TRLWE tmp2 = trlwe_alloc_new_sample(out->k, out->b->N);
+  trlwe_sub(tmp2, in2, in1);
+  trgsw_mul_trlwe_DFT(tmp, tmp2, selector);
+  trlwe_from_DFT(tmp2, tmp);
+  trlwe_add(out, tmp2, in1);
+  free_trlwe(tmp);
+  free_trlwe(tmp2);
+}
+
+static void dump_trlwe(FILE *f, TRLWE c) {
+  for (int p = 0; p < c->k; p++) fwrite(c->a[p]->coeffs, sizeof(Torus), (size_t)c->b->N, f);
+  fwrite(c->b->coeffs, sizeof(Torus), (size_t)c->b->N, f);
+}
+
+static void case_dft_level_api(void) {
+  enum { BITS = 13, OUT_PREC = 4, LUTS = (1 << BITS) / N, LOG_N = 10 };
+  init_fft(N);
+  const char *dump_path = getenv("MOSFHET_SUITE_DUMP");
+  FILE *dump = dump_path ? fopen(dump_path, "wb") : NULL;
+  /* --- polynomial level: DFT(a) * DFT(b) against the exact negacyclic product (test/tests.c:231-276: 2^40) */
+  TorusPolynomial pa = polynomial_new_torus_polynomial(N), pb = polynomial_new_torus_polynomial(N), pc = polynomial_new_torus_polynomial(N);
+  DFT_Polynomial *fd = polynomial_new_array_of_polynomials_DFT(N, 3);
+  generate_random_bytes(sizeof(Torus) * N, (uint8_t *)pa->coeffs);
+  for (int i = 0; i < N; i++) pb->coeffs[i] = (Torus)((int64_t)(i % 17) - 8);
+  polynomial_torus_to_DFT(fd[0], pa);
+  polynomial_torus_to_DFT(fd[1], pb);
+  polynomial_mul_DFT(fd[2], fd[0], fd[1]);
+  polynomial_mul_addto_DFT(fd[2], fd[0], fd[1]);          /* 2 a b */
+  polynomial_DFT_to_torus(pc, fd[2]);
+  for (int i = 0; i < N; i++) {
+    Torus want = 0;
+    for (int j = 0; j <= i; j++) want += pa->coeffs[j] * pb->coeffs[i - j];
+    for (int j = i + 1; j < N; j++) want -= pa->coeffs[j] * pb->coeffs[N + i - j];
+    WITHIN(1ULL << 40, 2 * want, pc->coeffs[i], "polynomial_mul_DFT + polynomial_mul_addto_DFT");
+  }
+  polynomial_DFT_to_torus(pc, fd[0]);
+  for (int i = 0; i < N; i++) WITHIN(1ULL << 14, pa->coeffs[i], pc->coeffs[i], "polynomial_torus_to_DFT / polynomial_DFT_to_torus round trip");
+  free_array_of_polynomials(fd, 3);
+  /* --- TRLWE level: trlwe_to_DFT / trlwe_from_DFT round trip */
+  TRLWE ct = trlwe_new_sample(pa, rlwe_key), back = trlwe_alloc_new_sample(k, N);
+  TRLWE_DFT ctd = trlwe_alloc_new_DFT_sample(k, N);
+  trlwe_to_DFT(ctd, ct);
+  trlwe_from_DFT(back, ctd);
+  for (int i = 0; i < N; i++) {
+    WITHIN(1ULL << 14, ct->a[0]->coeffs[i], back->a[0]->coeffs[i], "trlwe_to_DFT / trlwe_from_DFT (a)");
+    WITHIN(1ULL << 14, ct->b->coeffs[i], back->b->coeffs[i], "trlwe_to_DFT / trlwe_from_DFT (b)");
+  }
+  free_trlwe(ctd); free_trlwe(back); free_trlwe(ct);
+  /* --- vertical packing (encrypt_bits + eval_LUT of the reference application) */
+  uint32_t input;
+  generate_random_bytes(4, (uint8_t *)&input);
+  input &= (1u << BITS) - 1;
+  TRGSW bit = trgsw_alloc_new_sample(l, Bg_bit, k, N);
+  TRGSW_DFT *sel = trgsw_alloc_new_DFT_sample_array(BITS, l, Bg_bit, k, N);
+  if (dump) { int hdr[6] = {N, l, Bg_bit, BITS, LUTS, (int)input}; fwrite(hdr, sizeof(int), 6, dump); }
+  for (int i = 0; i < BITS; i++) {
+    trgsw_monomial_sample(bit, (input >> i) & 1, 0, trgsw_key);
+    trgsw_to_DFT(sel[i], bit);
+    if (dump) for (int r = 0; r < 2 * l; r++) dump_trlwe(dump, bit->samples[r]);
+  }
+  uint32_t *lut = (uint32_t *)safe_malloc(sizeof(uint32_t) << BITS);
+  generate_random_bytes(sizeof(uint32_t) << BITS, (uint8_t *)lut);
+  TRLWE *tab = trlwe_alloc_new_sample_array(LUTS, k, N);
+  for (int i = 0; i < LUTS; i++) {
+    trlwe_sample(tab[i], NULL, rlwe_key);
+    for (int j = 0; j < N; j++) tab[i]->b->coeffs[j] += int2torus((lut[i * N + j] &= (1u << OUT_PREC) - 1), OUT_PREC);
+    if (dump) dump_trlwe(dump, tab[i]);
+  }
+  for (int i = 0; i < BITS - LOG_N; i++) {
+    const int half = 1 << (BITS - LOG_N - i - 1);
+    for (int j = 0; j < half; j++) vp_cmux(tab[j], tab[j], tab[j + half], sel[BITS - i - 1]);
+  }
+  Torus a[32];
+  for (int i = 0; i < LOG_N; i++) a[i] = int2torus(2 * N - (1 << i), LOG_N + 1);
+  blind_rotate(tab[0], a, sel, LOG_N);
+  if (dump) { dump_trlwe(dump, tab[0]); fclose(dump); }
+  TLWE res = tlwe_alloc_sample(N);
+  trlwe_extract_tlwe(res, tab[0], 0);
+  const uint32_t got = (uint32_t)torus2int(tlwe_phase(res, extracted_key), OUT_PREC) & ((1u << OUT_PREC) - 1);
+  CHECK(got == lut[input], "vertical packing: LUT[%u] = %u, evaluated %u", input, lut[input], got);
+  /* the same blind rotation with selectors that are NOT one device block (gathered inside blind_rotate) */
+  {
+    TRGSW_DFT lone[2] = {trgsw_alloc_new_DFT_sample(l, Bg_bit, k, N), trgsw_alloc_new_DFT_sample(l, Bg_bit, k, N)};
+    TRLWE t1 = trlwe_new_sample(pa, rlwe_key), t2 = trlwe_alloc_new_sample(k, N);
+    trlwe_copy(t2, t1);
+    for (int i = 0; i < 2; i++) { trgsw_monomial_sample(bit, i, 0, trgsw_key); trgsw_to_DFT(lone[i], bit); trgsw_to_DFT(sel[i], bit); }
+    blind_rotate(t1, a, lone, 2);
+    blind_rotate(t2, a, sel, 2);
+    CHECK(!memcmp(t1->a[0]->coeffs, t2->a[0]->coeffs, sizeof(Torus) * N) && !memcmp(t1->b->coeffs, t2->b->coeffs, sizeof(Torus) * N),
+          "blind_rotate over scattered selectors differs from the contiguous array");
+    free_trgsw(lone[0]); free_trgsw(lone[1]); free_trlwe(t1); free_trlwe(t2);
+  }
+  /* blind_rotate over the bootstrap key's own entries = functional_bootstrap_wo_extract without the first rotation */
+  {
+    TLWE in = tlwe_new_sample(double2torus(3 / 8.), lwe_key);
+    Torus l4[4] = {int2torus(1, 4), int2torus(5, 4), int2torus(9, 4), int2torus(13, 4)};
+    TRLWE tv = trlwe_alloc_new_sample(k, N), r1 = trlwe_alloc_new_sample(k, N), r2 = trlwe_alloc_new_sample(k, N);
+    trlwe_torus_packing(tv, l4, 4);
+    functional_bootstrap_wo_extract(r1, tv, in, bk, 4);
+    trlwe_mul_by_xai(r2, tv, 2 * N - (int)torus2int(in->b + double2torus(1. / 16), LOG_N + 1));
+    blind_rotate(r2, in->a, bk->s, bk->n);
+    CHECK(!memcmp(r1->a[0]->coeffs, r2->a[0]->coeffs, sizeof(Torus) * N) && !memcmp(r1->b->coeffs, r2->b->coeffs, sizeof(Torus) * N),
+          "blind_rotate(tv, a, key->s, n) differs from functional_bootstrap_wo_extract");
+    free_tlwe(in); free_trlwe(tv); free_trlwe(r1); free_trlwe(r2);
+  }
+  /* Galois side: trlwe_eval_automorphism with a key of the set, blind_rotate_ga = functional_bootstrap_wo_extract_ga without the first rotation */
+  {
+    enum { NG = 24 };
+    TLWE_Key short_key = tlwe_new_binary_key(NG, lwe_sigma);
+    Bootstrap_GA_Key gk = new_bootstrap_key_ga(trgsw_key, short_key);
+    const uint64_t gen = 5;
+    TorusPolynomial msg = polynomial_new_torus_polynomial(N), want = polynomial_new_torus_polynomial(N), ph = polynomial_new_torus_polynomial(N);
+    for (int i = 0; i < N; i++) msg->coeffs[i] = int2torus((uint64_t)(i & 3), 3);
+    TRLWE c1 = trlwe_new_sample(msg, rlwe_key), c2 = trlwe_alloc_new_sample(k, N);
+    trlwe_eval_automorphism(c2, c1, gen, gk->ak[(gen - 1) >> 1]);
+    polynomial_permute(want, msg, gen);
+    trlwe_phase(ph, c2, rlwe_key);
+    for (int i = 0; i < N; i++) WITHIN(1ULL << 52, want->coeffs[i], ph->coeffs[i], "trlwe_eval_automorphism");
+    CHECK(inverse_mod_2N(5, N) * 5 % (2 * N) == 1, "inverse_mod_2N");
+    TLWE in = tlwe_new_sample(double2torus(1 / 8.), short_key);
+    Torus l4[4] = {int2torus(1, 4), int2torus(5, 4), int2torus(9, 4), int2torus(13, 4)};
+    TRLWE tv = trlwe_alloc_new_sample(k, N), r1 = trlwe_alloc_new_sample(k, N), r2 = trlwe_alloc_new_sample(k, N);
+    trlwe_torus_packing(tv, l4, 4);
+    functional_bootstrap_wo_extract_ga(r1, tv, in, gk, 4);
+    trlwe_mul_by_xai(r2, tv, 2 * N - (int)torus2int(in->b + double2torus(1. / 16), LOG_N + 1));
+    blind_rotate_ga(r2, in->a, gk->s, gk->ak, gk->n);
+    CHECK(!memcmp(r1->a[0]->coeffs, r2->a[0]->coeffs, sizeof(Torus) * N) && !memcmp(r1->b->coeffs, r2->b->coeffs, sizeof(Torus) * N),
+          "blind_rotate_ga differs from functional_bootstrap_wo_extract_ga");
+    free_tlwe(in); free_trlwe(tv); free_trlwe(r1); free_trlwe(r2); free_trlwe(c1); free_trlwe(c2);
+    free_polynomial(msg); free_polynomial(want); free_polynomial(ph); free_bootstrap_key_ga(gk); free_tlwe_key(short_key);
+  }
+  free_tlwe(res); free_trlwe_array(tab, LUTS); free(lut); free_trgsw_array(sel, BITS); free_trgsw(bit);
+  free_polynomial(pa); free_polynomial(pb); free_polynomial(pc);
+}
+
 int main(int argc, char **argv) {
   setvbuf(stdout, NULL, _IOLBF, 0);
   mosfhet_seed(0x4D4F5346);
@@ -621,6 +786,7 @@ int main(int argc, char **argv) {
     {"circuit_2+mux+trgsw", case_circuit_2_mux_trgsw},   {"radix_integer_add", case_radix_integer_add},
     {"key_files", case_key_files},                       {"threads", case_threads},
     {"other_rings", case_other_rings},                   {"big_batch", case_big_batch},
+    {"dft_level_api", case_dft_level_api},
   };
   for (unsigned i = 0; i < sizeof(cases) / sizeof(cases[0]); i++) {
     if (argc > 1 && strcmp(argv[1], cases[i].name)) continue;

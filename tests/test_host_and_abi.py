@@ -25,6 +25,50 @@ def test_library_exports_every_declared_symbol(native_lib, header):
     assert not missing, "declared in include/%s but not exported by libmosfhet_hip.so: %s" % (header, missing)
 
 
+# the signatures a program written against the reference's mosfhet.h for this path links to (reference include/mosfhet.h lines
+# 179-182, 190, 263-264, 296, 342-344, 374-457), plus what the reference's own leveled-LUT application needs around them
+MUST_KEEP = """new_bootstrap_key free_bootstrap_key blind_rotate functional_bootstrap_wo_extract functional_bootstrap programmable_bootstrap
+trgsw_mul_trlwe_DFT polynomial_torus_to_DFT polynomial_DFT_to_torus polynomial_mul_DFT polynomial_mul_addto_DFT trlwe_from_DFT trlwe_to_DFT trgsw_to_DFT
+trlwe_extract_tlwe tlwe_new_KS_key tlwe_keyswitch init_fft blind_rotate_ga trlwe_eval_automorphism public_mux
+multivalue_bootstrap_CLOT21 multivalue_bootstrap_phase1 multivalue_bootstrap_phase2 circuit_bootstrap circuit_bootstrap_2 circuit_bootstrap_3
+full_domain_functional_bootstrap full_domain_functional_bootstrap_KS21 full_domain_functional_bootstrap_KS21_2 full_domain_functional_bootstrap_CLOT21
+full_domain_functional_bootstrap_CLOT21_2 functional_bootstrap_trgsw_phase1 functional_bootstrap_trgsw_phase2 new_bootstrap_key_ga
+functional_bootstrap_ga functional_bootstrap_wo_extract_ga free_bootstrap_key_ga trlwe_keyswitch trlwe_priv_keyswitch trlwe_priv_keyswitch_2
+trlwe_packing1_keyswitch trlwe_tensor_prod_FFT tlwe_mul trlwe_new_RL_key polynomial_permute inverse_mod_2N
+tlwe_alloc_sample trlwe_alloc_new_sample trgsw_alloc_new_sample trlwe_alloc_new_DFT_sample trgsw_alloc_new_DFT_sample trgsw_alloc_new_DFT_sample_array
+polynomial_new_DFT_polynomial tlwe_new_binary_key trlwe_new_binary_key trgsw_new_key tlwe_sample trlwe_sample trgsw_monomial_sample tlwe_phase trlwe_phase
+trlwe_torus_packing free_tlwe free_trlwe free_trgsw free_polynomial safe_malloc generate_random_bytes""".split()
+
+
+def test_must_keep_symbols_are_exported(native_lib):
+    """nm-level check of SURVEY 8(b)'s must-keep signatures: every name is a defined dynamic symbol of libmosfhet_hip.so and is declared by
+    include/mosfhet.h (through mosfhet_compat.h)."""
+    import subprocess
+    from mosfhet_amd import engine
+    out = subprocess.run(["nm", "-D", "--defined-only", engine.lib_path()], capture_output=True, text=True, check=True).stdout
+    exported = set(line.split()[-1] for line in out.splitlines() if line.strip())
+    missing = [n for n in MUST_KEEP if n not in exported]
+    assert not missing, "not exported: %s" % missing
+    declared = set(declared_functions("mosfhet_compat.h"))
+    undeclared = [n for n in MUST_KEEP if n not in declared]
+    assert not undeclared, "exported but not declared in include/mosfhet_compat.h: %s" % undeclared
+    assert '#include "mosfhet_compat.h"' in open(os.path.join(ROOT, "include", "mosfhet.h")).read()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/applications"), reason="the reference tree exists in the build container only")
+def test_reference_application_relinks_unchanged(native_lib):
+    """The reference's own applications/leveled_lut/vertical_packing.c compiles UNCHANGED against include/mosfhet.h and links to the product library
+    (oracle/ref/Makefile target `app`; the binary runs under -m gpu: test_reference_application_runs_on_the_gpu)."""
+    import subprocess
+    subprocess.check_call(["make", "-s", "-B", "-C", os.path.join(ROOT, "oracle", "ref"), "app"])
+    exe = os.path.join(ROOT, "oracle", "_ref", "vertical_packing_hip")
+    ldd = subprocess.run(["ldd", exe], capture_output=True, text=True, check=True).stdout
+    assert "libmosfhet_hip.so" in ldd and "not found" not in ldd, ldd
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True, check=True).stdout
+    for name in ("trgsw_mul_trlwe_DFT", "trlwe_from_DFT", "trgsw_to_DFT", "blind_rotate", "trgsw_alloc_new_DFT_sample_array"):
+        assert name in undefined, "the application does not import %s?" % name
+
+
 def test_no_cpu_fallback(native_lib):
     import torch
     import mosfhet_amd as ma
