@@ -9,10 +9,15 @@ key -- no collective on the data path (weak scaling); the only collectives are t
 max-over-ranks of the timed region.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     : algorithmic bytes per launch (38,367,832 B per bootstrap at SET_1) over the
-                 kernel's average launch duration measured with hipEvents on the launch stream;
+  roofline     : the dominant kernel (pbs_kernel) against the roof that binds it, FP64 vector issue: SURVEY.md 8(d)'s FLOP model
+                 (171,008 FLOP per CMUX step x n steps x B) over the kernel's average launch duration, measured live with hipEvents on
+                 the launch stream, against the 78.6 TFLOP/s FP64 vector peak.  SURVEY 8(d)'s byte model (bootstrap key streamed once
+                 per ciphertext) is kept as `hbm_algorithmic`, labelled: it is NOT a bound, the key is shared by the batch through L2;
+                 `traffic` = PMC-measured memory-side bytes per launch, only when profiles/latest_traffic.json was taken from THIS build;
+  roofline_external_product : the kernel BASELINE.json's target names (trgsw_mul_trlwe_DFT + trlwe_from_DFT over a large batch against one
+                 key entry, 32 KiB of ciphertext I/O per unit) against HBM bandwidth, timed live the same way;
   cpu_baseline : the reference's own programmable_bootstrap (oracle/_ref, built from /root/reference) timed on
-                 this box's host cores on a bounded sample (N=1 only).
+                 this box's host cores on a bounded sample (N=1 only), plus config 1 (one FFNT pure-C bootstrap).
 """
 import argparse
 import json
@@ -27,12 +32,36 @@ sys.path.insert(0, ROOT)
 
 SEED = 0x4D4F5346
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak: 256 CUs x 4 SIMDs x 16 FMA lanes x 2 FLOP x 2.4 GHz (one v_fma_f64 per 4 cycles per SIMD,
+                                # tools/ubench: 4.2 cycles measured; the FP64 MFMA runs on the same units at the same rate)
 
 
 def algorithmic_bytes_per_bootstrap(P):
     """bootstrap key streamed once per ciphertext + LWE in + test vector + LWE out."""
     k, N, n, l = P["k"], P["N"], P["n"], P["l"]
     return n * (k + 1) ** 2 * l * N * 8 + (n + 1) * 8 + (k + 1) * N * 8 + (k * N + 1) * 8
+
+
+def flops_per_cmux(P):
+    """5 M log2 M per M-point complex FFT ((k+1) l forward + (k+1) inverse) + 8 per complex multiply-add."""
+    k, N, l = P["k"], P["N"], P["l"]
+    M = N // 2
+    fft = 5 * M * (M.bit_length() - 1)
+    return ((k + 1) * l + (k + 1)) * fft + 8 * (k + 1) ** 2 * l * M
+
+
+def ffnt_single_ms(P, bk, tv, ct):
+    """BASELINE.json configs[0]: ONE programmable bootstrap through the reference's portable FFNT pure-C build (plumbing, no GPU)."""
+    from oracle import reflib
+    if not reflib.available("ffnt"):
+        return None
+    ref = reflib.get("ffnt")
+    ref.init(P["N"])
+    h = ref.bk_new(bk, P["k"], P["l"], P["Bg_bit"])
+    ref.bench_programmable_bootstrap(tv, ct, h, 3, 1)
+    ms = 1e3 * ref.bench_programmable_bootstrap(tv, ct, h, 3, 5) / 5
+    ref.bk_free(h)
+    return ms
 
 
 def cpu_baseline(P, bk, tv, cts, target_seconds):
@@ -98,6 +127,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4096, help="bootstraps per GPU per step")
+    ap.add_argument("--ep-batch", type=int, default=65536, help="TRLWE samples of the external-product roofline line")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -181,20 +211,55 @@ def main():
 
     # dominant kernel: average launch duration by hipEvents on the launch stream
     kernel_ms = eng.time_programmable_bootstrap(bsk, d_tv, d_ct, 3, max(3, min(args.steps, 10)), out=d_out)
+    flops_per_launch = flops_per_cmux(P) * P["n"] * B
+    achieved_tflops = flops_per_launch / (kernel_ms * 1e-3) / 1e12
     bytes_per_launch = algorithmic_bytes_per_bootstrap(P) * B
-    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
 
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "latest_traffic.json")
     if B == 4096 and os.path.exists(tfile):
-        # HBM-side bytes per launch from the committed rocprofv3 PMC passes (tools/profile_bench.sh: FETCH_SIZE and
-        # WRITE_SIZE in separate passes, gfx950 correction applied by tools/make_traffic_json.py)
+        # memory-side bytes per launch from the committed rocprofv3 PMC passes (tools/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate
+        # passes, gfx950 correction applied by tools/make_traffic_json.py) -- only if they were taken from the library that is running now
         with open(tfile) as f:
-            traffic = json.load(f).get("traffic_bytes_per_launch")
+            t = json.load(f)
+        try:
+            with open(build.STAMP) as f:
+                srchash = f.read().strip()
+        except OSError:
+            srchash = None
+        if srchash and t.get("srchash") == srchash:
+            traffic = t.get("traffic_bytes_per_launch")
+
+    # the external-product kernel on its own (BASELINE.json's HBM target): B_ep TRLWE samples against ONE key entry, inputs and outputs in HBM
+    ep = None
+    if rank == 0:
+        import torch
+        B_ep, N_, l_ = args.ep_batch, P["N"], P["l"]
+        g = torch.Generator(device="cpu").manual_seed(SEED)
+        d_ep_in = torch.randint(-2 ** 63, 2 ** 63 - 1, (B_ep, 2, N_), dtype=torch.int64, generator=g).to(eng.device)
+        d_ep_out = eng.empty(B_ep, 2, N_)
+        eng.external_product(bsk, 1, d_ep_in, out=d_ep_out)
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        reps = 10
+        ev[0].record(torch.cuda.current_stream())      # the engine launches on torch's current stream (mosfhet_amd/engine.py: _stream)
+        for _ in range(reps):
+            eng.external_product(bsk, 1, d_ep_in, out=d_ep_out)
+        ev[1].record(torch.cuda.current_stream())
+        ev[1].synchronize()
+        ep_ms = ev[0].elapsed_time(ev[1]) / reps
+        ep_bytes = B_ep * 2 * (2 * N_ * 8) + (2 * l_) * 2 * N_ * 8        # TRLWE in + TRLWE out per unit, the key entry once
+        ep_gbs = ep_bytes / (ep_ms * 1e-3) / 1e9
+        ep = {"bound": "hbm", "achieved": ep_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ep_gbs / HBM_PEAK_GBS, "traffic": None,
+              "kernel": "mosfhet::external_product_kernel<mosfhet::Fft1024, 2>", "kernel_ms": ep_ms, "units_per_launch": B_ep,
+              "algorithmic_bytes_per_launch": ep_bytes, "external_products_per_s": B_ep / (ep_ms * 1e-3),
+              "workload": "%d x trgsw_mul_trlwe_DFT + trlwe_from_DFT at SET_1 against one TRGSW_DFT (src/trgsw.c:385-423)" % B_ep}
+        del d_ep_in, d_ep_out
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(P, bk, tv, cts[:64], args.cpu_seconds)
+        cpu["ffnt_single_ms"] = ffnt_single_ms(P, bk, tv, cts[0])      # BASELINE.json configs[0]
 
     if rank == 0:
         total = world * args.steps * B
@@ -215,10 +280,14 @@ def main():
                                    "(BASELINE.json configs[1])" % B,
                        "batch_per_gpu": B, "parallelism": "batch sharded over %d GPU(s), bootstrap key replicated, "
                                                           "no collective on the data path" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "roofline": {"bound": "fp64_valu", "achieved": achieved_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved_tflops / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": "mosfhet::pbs_kernel<mosfhet::Fft1024, 2, 8>", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": bytes_per_launch},
+                         "flops_per_launch": flops_per_launch, "flops_per_cmux": flops_per_cmux(P),
+                         "hbm_algorithmic": {"bytes_per_launch": bytes_per_launch, "gb_per_s": bytes_per_launch / (kernel_ms * 1e-3) / 1e9,
+                                             "note": "SURVEY 8(d) byte model (bootstrap key streamed once per ciphertext): not a bound, the "
+                                                     "key is shared by the batch through L2 (see `traffic` for measured memory-side bytes)"}},
+            "roofline_external_product": ep,
             "cpu_baseline": cpu,
             "max_phase_error_log2": float(np.log2(err + 1)),
             "host_buffer_rate_per_gpu": host_rate,

@@ -53,6 +53,11 @@ typedef struct _Bootstrap_Key { TRGSW_DFT *s; TRGSW *su; int n, k, N, Bg_bit, l,
 /* ---- engine control (new) ---- */
 void mosfhet_seed(uint64_t seed);              /* reseed the host generator used by all *_sample / *_key functions */
 void mosfhet_set_device(int device);           /* GPU used by this process (default: env MOSFHET_HIP_DEVICE or 0) */
+void mosfhet_set_devices(int n, const int *ids);   /* several GPUs (default: env MOSFHET_HIP_DEVICES="0,1,..."): ids[0] is the primary device (keys are made
+                                                    * there, single-sample calls run there); the *_batch entry points of bootstraps and LWE key switches cut
+                                                    * their batch into n contiguous slices, one per GPU, each on its own host thread, stream and staging, with
+                                                    * the keys replicated per GPU on first use.  SURVEY 8(e); no collective.  Before the first call. */
+int mosfhet_device_count(void);                /* GPUs in use */
 void *mosfhet_engine_ctx(void);                /* the mosfhet_hip_ctx_t behind the compat layer */
 void *mosfhet_bootstrap_key_device(Bootstrap_Key key);   /* the mosfhet_hip_bsk_t behind a Bootstrap_Key */
 

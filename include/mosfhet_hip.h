@@ -329,6 +329,11 @@ int mosfhet_hip_time_programmable_bootstrap(mosfhet_hip_ctx_t ctx, mosfhet_hip_b
                                             const uint64_t *d_tv, int tv_count, const uint64_t *d_in, int count,
                                             int precision, int reps, void *stream, float *ms_per_launch);
 
+/* Secret of the on-device key generators (bsk_generate, *_ksk_generate): the 256-bit ChaCha20 key their NOISE terms are drawn under.  It is independent
+ * of the public 64-bit mask seed those calls take (masks are public and regenerable from that seed; noise is not).  Drawn from the operating system at
+ * first use unless set here (32 bytes); process-wide. */
+int mosfhet_hip_set_keygen_secret(const void *key32);
+
 /* ---- DFT-level entry points behind the reference's legacy signatures (mosfhet.h:179-182,263-264,342-344,454,296 of the reference; csrc/capi_dft.inc).
  * DFT-domain objects are device arrays of doubles in the engine's slot order ([polynomial][N/2] complex). ---- */
 /* non-owning key handle over n consecutive TRGSW_DFT entries ([(k+1)l][k+1][N/2] complex each) already on the device; destroy with mosfhet_hip_bsk_destroy */

@@ -823,64 +823,75 @@ __global__ __launch_bounds__(F::THREADS) void dft_to_torus_kernel(const d2 *__re
   }
 }
 
-// trgsw_mul_trlwe_DFT + trlwe_from_DFT for a batch against ONE key entry [src/trgsw.c:385-423, src/trlwe.c:629-634]:
-// out[b] = TRGSW (.) in[b], back in the torus domain.  bkrow = start of that entry's (k+1)l rows.
-template <class F, int L>
-__global__ __launch_bounds__(F::THREADS) void external_product_kernel(const d2 *__restrict__ bkrow, const d2 *__restrict__ tw,
-                                                                    const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
-                                                                    int Bg_bit, size_t key_stride = 0, size_t in_stride = 2 * F::N,
-                                                                    const uint64_t *__restrict__ in0 = nullptr, d2 *__restrict__ out_dft = nullptr) {
-  // key_stride (in d2): 0 = one TRGSW for the whole batch, else TRGSW b starts at bkrow + b * key_stride (per-ciphertext
-  // selectors, functional_bootstrap_trgsw_phase2); in_stride (words): 0 = one shared TRLWE input.
-  // in0 != nullptr: CMUX (applications/leveled_lut/vertical_packing.c:24-33): out[b] = in0[b] + TRGSW (.) (in[b] - in0[b])
-  // out_dft != nullptr: trgsw_mul_trlwe_DFT as the reference declares it (include/mosfhet.h:344): the result stays in the DFT domain,
-  // out_dft[b][c][slot] in slot order; trlwe_from_DFT (dft_to_torus_kernel) finishes it with the same inverse transform and rounding.
+// trgsw_mul_trlwe_DFT + trlwe_from_DFT for a batch [src/trgsw.c:385-423, src/trlwe.c:629-634]: out[b] = TRGSW (.) in[b], back in the torus domain.
+// The HBM-bound kernel of the path: per unit one TRLWE in and one out (32 KiB at N = 1024) against a key entry that stays in the caches.
+//   * persistent teams: the grid is the chip's resident capacity and every team walks units b, b + grid, ... -- twiddles, rounding constants and the
+//     launch cost are paid once per team; the second wavefront of the SIMD covers a team's load latency (holding the next unit's input in registers
+//     as well spills: 756 bytes of scratch and a third of the speed);
+//   * BG > 0: gadget base known at compile time (packed digit words, as in pbs_kernel); BG = 0: run-time Bg_bit;
+//   * the two inverse transforms are pipelined through the one transpose buffer (inverse2), the first key row initialises the accumulators.
+// key_stride (in d2): 0 = one TRGSW for the whole batch, else TRGSW b starts at bkrow + b * key_stride (per-ciphertext selectors,
+// functional_bootstrap_trgsw_phase2); in_stride (words): 0 = one shared TRLWE input.
+// in0 != nullptr: CMUX (applications/leveled_lut/vertical_packing.c:24-33): out[b] = in0[b] + TRGSW (.) (in[b] - in0[b])  (out may alias in0)
+// out_dft != nullptr: trgsw_mul_trlwe_DFT as the reference declares it (include/mosfhet.h:344): the result stays in the DFT domain,
+// out_dft[b][c][slot] in slot order; trlwe_from_DFT (dft_to_torus_kernel) finishes it with the same inverse transform and rounding.
+template <class F, int L, int BG>
+__global__ __launch_bounds__(F::THREADS, 2) void external_product_kernel(const d2 *__restrict__ bkrow0, const d2 *__restrict__ tw,
+                                                                       const uint64_t *__restrict__ in, uint64_t *__restrict__ out, int Bg_bit_rt, int count,
+                                                                       size_t key_stride = 0, size_t in_stride = 2 * F::N,
+                                                                       const uint64_t *__restrict__ in0 = nullptr, d2 *__restrict__ out_dft = nullptr) {
   constexpr int N = F::N, M = F::M, T = F::THREADS;
+  using D = Digits<L, BG>;
+  // rounding without the reduction mod 1 where the gadget bounds the sums (see pbs_kernel)
+  constexpr bool kReduce = !(BG > 0 && kCeilLog2<2 * L>::value + (F::LOGM + 1) + BG - 1 + 63 < 83);
   __shared__ __attribute__((aligned(16))) d2 xch[F::XCH_SLOTS];
   const int t = threadIdx.x;
-  const uint64_t *ct = in + (size_t)blockIdx.x * in_stride;
-  const uint64_t *c0 = in0 ? in0 + (size_t)blockIdx.x * 2 * N : nullptr;
-  bkrow += (size_t)blockIdx.x * key_stride;
+  const int Bg_bit = BG > 0 ? BG : Bg_bit_rt;
   F fft;
   fft.init(tw, t);
   uint64_t off = 1ull << (63 - L * Bg_bit);
 #pragma unroll
   for (int i = 0; i < L; i++) off += 1ull << (63 - i * Bg_bit);
-  double o_re[2][8], o_im[2][8];
-#pragma unroll
-  for (int c = 0; c < 2; c++)
-#pragma unroll
-    for (int m = 0; m < 8; m++) { o_re[c][m] = 0.0; o_im[c][m] = 0.0; }
-#pragma unroll 1
-  for (int q = 0; q < 2; q++) {
-    typename Digits<L, 0>::word_t w_lo[8], w_hi[8];
-    uint32_t ext[8];
-#pragma unroll
-    for (int m = 0; m < 8; m++) {
-      const uint64_t s_lo = c0 ? c0[q * N + m * T + t] : 0, s_hi = c0 ? c0[q * N + M + m * T + t] : 0;
-      Digits<L, 0>::pack(w_lo[m], w_hi[m], ext[m], ct[q * N + m * T + t] - s_lo + off, ct[q * N + M + m * T + t] - s_hi + off);
-    }
-    cmux_rows<F, L, 0>(w_lo, w_hi, ext, q, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
-  }
-  if (out_dft) {
-    d2 *dd = out_dft + (size_t)blockIdx.x * 2 * M;
+  const RoundCtx scale(0x1p-64 / (double)M);
+
+  for (size_t u = blockIdx.x; u < (size_t)count; u += gridDim.x) {
+    const uint64_t *ct = in + u * in_stride;
+    const uint64_t *c0 = in0 ? in0 + u * 2 * N : nullptr;
+    const d2 *__restrict__ bkrow = bkrow0 + u * key_stride;
+    double o_re[2][8], o_im[2][8];
 #pragma unroll
     for (int c = 0; c < 2; c++)
 #pragma unroll
-      for (int m = 0; m < 8; m++) dd[c * M + m * T + t] = d2{o_re[c][m], o_im[c][m]};
-    return;
-  }
-  const RoundCtx scale(0x1p-64 / (double)M);
-  uint64_t *dst = out + (size_t)blockIdx.x * 2 * N;
+      for (int m = 0; m < 8; m++) { o_re[c][m] = 0.0; o_im[c][m] = 0.0; }
+#pragma unroll 1
+    for (int q = 0; q < 2; q++) {   // rolled: the loop body must stay small (registers, instruction cache)
+      typename D::word_t w_lo[8], w_hi[8];
+      uint32_t ext[8];
 #pragma unroll
-  for (int c = 0; c < 2; c++) {
-    fft.inverse(o_re[c], o_im[c], xch, t);
-#pragma unroll
-    for (int m = 0; m < 8; m++) {   // (out may alias in0: each lane reads its words of in0 before it writes them)
-      const uint64_t s_lo = c0 ? c0[c * N + m * T + t] : 0, s_hi = c0 ? c0[c * N + m * T + t + M] : 0;
-      dst[c * N + m * T + t] = round_mod_2_64(o_re[c][m], scale) + s_lo;
-      dst[c * N + m * T + t + M] = round_mod_2_64(o_im[c][m], scale) + s_hi;
+      for (int m = 0; m < 8; m++) {
+        const uint64_t s_lo = c0 ? c0[q * N + m * T + t] : 0, s_hi = c0 ? c0[q * N + M + m * T + t] : 0;
+        D::pack(w_lo[m], w_hi[m], ext[m], ct[q * N + m * T + t] - s_lo + off, ct[q * N + M + m * T + t] - s_hi + off);
+      }
+      cmux_rows<F, L, BG>(w_lo, w_hi, ext, q, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
     }
+    if (out_dft) {
+      d2 *dd = out_dft + u * 2 * M;
+#pragma unroll
+      for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int m = 0; m < 8; m++) dd[c * M + m * T + t] = d2{o_re[c][m], o_im[c][m]};
+      continue;
+    }
+    fft.inverse2(o_re[0], o_im[0], o_re[1], o_im[1], xch, t);
+    uint64_t *dst = out + u * 2 * N;
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int m = 0; m < 8; m++) {   // (out may alias in0: each lane reads its words of in0 before it writes them)
+        const uint64_t s_lo = c0 ? c0[c * N + m * T + t] : 0, s_hi = c0 ? c0[c * N + m * T + t + M] : 0;
+        dst[c * N + m * T + t] = add_rounded<kReduce>(s_lo, o_re[c][m], scale);
+        dst[c * N + m * T + t + M] = add_rounded<kReduce>(s_hi, o_im[c][m], scale);
+      }
   }
 }
 

@@ -312,6 +312,34 @@ extern "C" int mosfhet_hip_bsk_export_dft(mosfhet_hip_bsk_t bsk, double *h_out) 
   return MOSFHET_HIP_OK;
 }
 
+// ---- external-product launches ----
+// Persistent teams (external_product_kernel): the grid is the chip's resident capacity -- 2 wavefronts per SIMD, i.e. CUs x 8 / (wavefronts per team)
+// teams -- capped by the batch; gadgets of the reference's parameter sets get the compile-time instantiation.
+static int resident_teams(int threads) {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  }
+  return cus * 8 / (threads / 64);
+}
+
+template <class F>
+static void launch_external_product(int l, int Bg_bit, hipStream_t s, const d2 *row, const d2 *tw, const uint64_t *d_in, uint64_t *d_out, int count, size_t key_stride,
+                                    size_t in_stride, const uint64_t *d_in0, d2 *d_out_dft) {
+  const int cap = resident_teams(F::THREADS);
+  const dim3 grid((unsigned)(count < cap ? count : cap)), block(F::THREADS);
+#define EP_GO(LL, BB) hipLaunchKernelGGL((external_product_kernel<F, LL, BB>), grid, block, 0, s, row, tw, d_in, d_out, Bg_bit, count, key_stride, in_stride, d_in0, d_out_dft)
+  if (l == 2 && Bg_bit == 8) EP_GO(2, 8);
+  else if (l == 4 && Bg_bit == 9) EP_GO(4, 9);
+  else if (l == 1 && Bg_bit == 23) EP_GO(1, 23);
+  else if (l == 1) EP_GO(1, 0);
+  else if (l == 2) EP_GO(2, 0);
+  else if (l == 3) EP_GO(3, 0);
+  else EP_GO(4, 0);
+#undef EP_GO
+}
+
 // ---- bootstrap launches ----
 // One launch per residency round when the key does not fit the L2s (N >= 2048).  All teams walk the key rows in the same order and
 // share each row through their XCD's L2 while they stay close together; in one big launch the teams of later rounds start as earlier
@@ -466,14 +494,7 @@ extern "C" int mosfhet_hip_external_product_batch(mosfhet_hip_ctx_t ctx, mosfhet
   HIP_TRY(hipSetDevice(ctx->device));
   const d2 *row = bsk->d_bk + (size_t)key_index * (2 * bsk->l * 2 * (bsk->N / 2));
   hipStream_t s = pick(ctx, stream);
-#define EP_LAUNCH(LL) RING_DISPATCH(ctx, bsk->N, hipLaunchKernelGGL((external_product_kernel<F, LL>), dim3(count), dim3(F::THREADS), 0, s, row, TW, d_in, d_out, bsk->Bg_bit))
-  switch (bsk->l) {
-    case 1: EP_LAUNCH(1); break;
-    case 2: EP_LAUNCH(2); break;
-    case 3: EP_LAUNCH(3); break;
-    default: EP_LAUNCH(4); break;
-  }
-#undef EP_LAUNCH
+  RING_DISPATCH(ctx, bsk->N, launch_external_product<F>(bsk->l, bsk->Bg_bit, s, row, TW, d_in, d_out, count, (size_t)0, (size_t)2 * F::N, nullptr, nullptr));
   HIP_TRY(hipGetLastError());
   return MOSFHET_HIP_OK;
 }

@@ -37,6 +37,21 @@ MC_HIDDEN void mc_use_device(void);                            /* make the engin
 MC_HIDDEN void mc_trlwe_to_flat(Torus *flat, TRLWE c);
 MC_HIDDEN void mc_trlwe_from_flat(TRLWE c, const Torus *flat);
 
+/* mosfhet_compat_multi.c: several devices behind the API.  Device INDEX d = position in the list given to mosfhet_set_devices; index 0 is the primary */
+#define MC_MAX_DEVICES 16
+enum { MC_KEY_BSK = 0, MC_KEY_KSK = 1 };
+extern MC_HIDDEN int g_mc_ndev;                    /* devices in use */
+extern MC_HIDDEN int g_mc_devs[MC_MAX_DEVICES];    /* their HIP ordinals */
+extern MC_HIDDEN __thread int t_mc_in_shard;      /* inside one slice of a sharded batch (no nested sharding) */
+extern MC_HIDDEN __thread int t_mc_dev;            /* device index of the calling thread (workers of a sharded batch: their slice's device) */
+MC_HIDDEN int mc_engine_started(void);
+MC_HIDDEN mosfhet_hip_ctx_t mc_ctx_of(int d);      /* context of device index d */
+MC_HIDDEN void mc_devices_from_env(void);
+MC_HIDDEN void *mc_key_here(void *primary, int kind);   /* the key's handle on the calling thread's device */
+MC_HIDDEN void mc_replicas_free(void *primary);
+typedef void (*mc_slice_fn)(void *args, int lo, int hi);
+MC_HIDDEN void mc_run_sharded(mc_slice_fn fn, void *args, int count, void *const *keys, const int *kinds, int n_keys);
+
 /* csprng.c: ChaCha20 generator, one stream per host thread */
 MC_HIDDEN uint64_t mc_rnd64(void);
 MC_HIDDEN void mc_rnd_bytes(void *out, size_t bytes);

@@ -33,16 +33,19 @@ void *mc_xmalloc(size_t sz) {
 void *safe_malloc(size_t size) { return mc_xmalloc(size); }           /* src/misc.c:104-113 */
 void *safe_aligned_malloc(size_t size) { return mc_xmalloc(size); }   /* src/misc.c:115-128 */
 
-/* ------------------------------------------------------------------ engine singleton */
-static mosfhet_hip_ctx_t g_ctx = NULL;
-static int g_device = -1;
+/* ------------------------------------------------------------------ engine: one context per device in use (mosfhet_compat_multi.c) */
+static mosfhet_hip_ctx_t g_ctxs[MC_MAX_DEVICES];
+static int g_started = 0;
+
+int mc_engine_started(void) { return __atomic_load_n(&g_started, __ATOMIC_ACQUIRE); }
 
 void mosfhet_set_device(int device) {
-  if (g_ctx && device != g_device) {
+  if (mc_engine_started() && device != g_mc_devs[0]) {
     fprintf(stderr, "mosfhet_amd: mosfhet_set_device after the engine was created\n");
     abort();
   }
-  g_device = device;
+  g_mc_ndev = 1;
+  g_mc_devs[0] = device;
 }
 
 /* The layer is re-entrant like the reference (thread-local FFT state there, src/polynomial.c:269-352): the engine is created once under a lock,
@@ -50,34 +53,42 @@ void mosfhet_set_device(int device) {
  * csrc/capi.hip), every thread has its own staging buffer and its own random stream (csprng.c). */
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 
-void *mosfhet_engine_ctx(void) {
-  mosfhet_hip_ctx_t c = __atomic_load_n(&g_ctx, __ATOMIC_ACQUIRE);
-  if (c) return c;
+static void engine_start(void) {
   pthread_mutex_lock(&g_lock);
-  if (!g_ctx) {
-    if (g_device < 0) {
-      const char *e = getenv("MOSFHET_HIP_DEVICE");
-      g_device = e ? atoi(e) : 0;
+  if (!g_started) {
+    if (g_mc_devs[0] < 0) {
+      mc_devices_from_env();
+      if (g_mc_devs[0] < 0) {
+        const char *e = getenv("MOSFHET_HIP_DEVICE");
+        g_mc_devs[0] = e ? atoi(e) : 0;
+      }
     }
-    mosfhet_hip_ctx_t fresh = NULL;
-    if (mosfhet_hip_ctx_create(&fresh, g_device)) mc_die("engine start-up");
-    __atomic_store_n(&g_ctx, fresh, __ATOMIC_RELEASE);
+    for (int d = 0; d < g_mc_ndev; d++)
+      if (mosfhet_hip_ctx_create(&g_ctxs[d], g_mc_devs[d])) mc_die("engine start-up");
+    /* the device generators' noise key comes from this layer's generator: the operating system's entropy, or the mosfhet_seed stream in test runs */
+    uint8_t secret[32];
+    mc_rnd_bytes(secret, sizeof(secret));
+    if (mosfhet_hip_set_keygen_secret(secret)) mc_die("engine start-up (key-generation secret)");
+    __atomic_store_n(&g_started, 1, __ATOMIC_RELEASE);
   }
   pthread_mutex_unlock(&g_lock);
-  return g_ctx;
 }
 
+mosfhet_hip_ctx_t mc_ctx_of(int d) {
+  if (!mc_engine_started()) engine_start();
+  return g_ctxs[d];
+}
+
+void *mosfhet_engine_ctx(void) { return mc_ctx_of(t_mc_dev); }
+
 /* HIP's current device is per host thread and starts at 0: every thread that allocates staging memory or creates streams for the engine first makes
- * the ENGINE's device current (the C ABI does the same at the top of every call). */
+ * ITS device current (the C ABI does the same at the top of every call). */
 void mc_use_device(void) {
-  static __thread int t_done = 0;
-  if (t_done) return;
   (void)mosfhet_engine_ctx();
-  if (hipSetDevice(g_device)) {
-    fprintf(stderr, "mosfhet_amd: hipSetDevice(%d) failed\n", g_device);
+  if (hipSetDevice(g_mc_devs[t_mc_dev])) {
+    fprintf(stderr, "mosfhet_amd: hipSetDevice(%d) failed\n", g_mc_devs[t_mc_dev]);
     abort();
   }
-  t_done = 1;
 }
 
 /* ------------------------------------------------------------------ torus scalars */
@@ -660,6 +671,7 @@ void free_bootstrap_key(Bootstrap_Key key) {
   if (!key) return;
   forget_key(key);
   if (key->s) mc_trgsw_dft_views_free(key->s, key->n);
+  mc_replicas_free(key->device);
   mosfhet_hip_bsk_destroy((mosfhet_hip_bsk_t)key->device);
   free(key);
 }
@@ -674,7 +686,7 @@ enum { MODE_FUNCTIONAL, MODE_PROGRAMMABLE, MODE_WO_EXTRACT };
 static __thread void *g_pipe_streams[2];
 static void bootstrap_pipelined(int mode, TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_Key key, int a0, int kappa, int theta) {
   mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
-  mosfhet_hip_bsk_t bsk = (mosfhet_hip_bsk_t)mosfhet_bootstrap_key_device(key);
+  mosfhet_hip_bsk_t bsk = (mosfhet_hip_bsk_t)mc_key_here(key->device, MC_KEY_BSK);
   const int n = key->n, N = key->N, k = key->k;
   const size_t in_row = (size_t)n + 1, out_row = (size_t)k * N + 1, tv_w = (size_t)(k + 1) * N;
   const size_t in_w = (size_t)count * in_row, out_w = (size_t)count * out_row;
@@ -710,8 +722,23 @@ static void bootstrap_pipelined(int mode, TLWE *out, TRLWE tv, TLWE *in, int cou
   mc_hstage_free(h);
 }
 
+typedef struct { int mode; TLWE *out; TRLWE tv; TLWE *in; Bootstrap_Key key; int a0, kappa, theta; } BootstrapSlice;
+static void bootstrap_many(int mode, TLWE *out, TRLWE out_trlwe, TRLWE tv, TLWE *in, int count, Bootstrap_Key key, int a0, int kappa, int theta);
+static void bootstrap_slice(void *pv, int lo, int hi) {
+  BootstrapSlice *a = (BootstrapSlice *)pv;
+  if (hi > lo) bootstrap_many(a->mode, a->out + lo, NULL, a->tv, a->in + lo, hi - lo, a->key, a->a0, a->kappa, a->theta);
+}
+
 static void bootstrap_many(int mode, TLWE *out, TRLWE out_trlwe, TRLWE tv, TLWE *in, int count, Bootstrap_Key key,
                            int a0, int kappa, int theta) {
+  if (g_mc_ndev > 1 && !t_mc_in_shard && mode != MODE_WO_EXTRACT && count >= 2 * g_mc_ndev) {
+    /* several devices: contiguous slices, one per device, each through this same function on its device's host thread (mosfhet_compat_multi.c) */
+    BootstrapSlice a = {mode, out, tv, in, key, a0, kappa, theta};
+    void *keys[1] = {key->device};
+    const int kinds[1] = {MC_KEY_BSK};
+    mc_run_sharded(bootstrap_slice, &a, count, keys, kinds, 1);
+    return;
+  }
   /* unfolded keys keep the single-stream path: their accumulators live in the calling thread's device pool, one set per thread, so chunks on two
    * streams would share it (mosfhet_hip.h: compositions on several streams must be ordered by the caller) */
   if (mode != MODE_WO_EXTRACT && count >= 2 * PIPE_CHUNK && key->unfolding == 1) {
@@ -719,7 +746,7 @@ static void bootstrap_many(int mode, TLWE *out, TRLWE out_trlwe, TRLWE tv, TLWE 
     return;
   }
   mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
-  mosfhet_hip_bsk_t bsk = (mosfhet_hip_bsk_t)mosfhet_bootstrap_key_device(key);
+  mosfhet_hip_bsk_t bsk = (mosfhet_hip_bsk_t)mc_key_here(key->device, MC_KEY_BSK);
   const int n = key->n, N = key->N, k = key->k;
   const size_t in_w = (size_t)count * (n + 1), tv_w = (size_t)(k + 1) * N;
   const size_t out_w = (mode == MODE_WO_EXTRACT) ? (size_t)count * tv_w : (size_t)count * (k * N + 1);
@@ -771,7 +798,20 @@ void trlwe_torus_packing_many_LUT(TRLWE out, Torus *in, int lut_size, int n_luts
       for (int r = 0; r < span; r++) out->b->coeffs[(i * n_luts + j) * span + r] = in[j * lut_size + i];
 }
 
+typedef struct { TLWE *out; TRLWE tv; TLWE *in; Bootstrap_Key key; TLWE_KS_Key ksk; int precision; } FdfbSlice;
+static void fdfb_slice(void *pv, int lo, int hi) {
+  FdfbSlice *a = (FdfbSlice *)pv;
+  if (hi > lo) full_domain_functional_bootstrap_batch(a->out + lo, a->tv, a->in + lo, hi - lo, a->key, a->ksk, a->precision);
+}
+
 void full_domain_functional_bootstrap_batch(TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_Key key, TLWE_KS_Key ksk, int precision) {
+  if (g_mc_ndev > 1 && !t_mc_in_shard && count >= 2 * g_mc_ndev) {
+    FdfbSlice a = {out, tv, in, key, ksk, precision};
+    void *keys[2] = {key->device, ksk->device};
+    const int kinds[2] = {MC_KEY_BSK, MC_KEY_KSK};
+    mc_run_sharded(fdfb_slice, &a, count, keys, kinds, 2);
+    return;
+  }
   mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
   const int n = key->n, N = key->N, k = key->k;
   const size_t in_w = (size_t)count * (n + 1), tv_w = (size_t)(k + 1) * N, out_w = (size_t)count * (k * N + 1);
@@ -780,8 +820,8 @@ void full_domain_functional_bootstrap_batch(TLWE *out, TRLWE tv, TLWE *in, int c
   mc_trlwe_to_flat(h + in_w, tv);
   Torus *d = (Torus *)mc_stage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
   mc_dev_copy(d, h, sizeof(Torus) * (in_w + tv_w), HIP_H2D);
-  if (mosfhet_hip_full_domain_functional_bootstrap_batch(ctx, (mosfhet_hip_bsk_t)mosfhet_bootstrap_key_device(key),
-                                                         (mosfhet_hip_ksk_t)ksk->device, d + in_w + tv_w, d + in_w, 1, d, count, precision, NULL) ||
+  if (mosfhet_hip_full_domain_functional_bootstrap_batch(ctx, (mosfhet_hip_bsk_t)mc_key_here(key->device, MC_KEY_BSK),
+                                                         (mosfhet_hip_ksk_t)mc_key_here(ksk->device, MC_KEY_KSK), d + in_w + tv_w, d + in_w, 1, d, count, precision, NULL) ||
       mosfhet_hip_ctx_sync(ctx, NULL))
     mc_die("full_domain_functional_bootstrap");
   mc_dev_copy(h + in_w + tv_w, d + in_w + tv_w, sizeof(Torus) * out_w, HIP_D2H);
@@ -875,19 +915,21 @@ Bootstrap_GA_Key new_bootstrap_key_ga(TRGSW_Key out_key, TLWE_Key in_key) {
   free_polynomial(perm);
   mosfhet_hip_gak_t gak = fft_ks_keys_new(out_key->trlwe_key, msgs, N, l, out_key->Bg_bit, "new_bootstrap_key_ga (automorphism keys)");
   free(msgs);
-  res->s = (TRGSW_DFT *)mc_xmalloc(sizeof(TRGSW_DFT));
-  res->s[0] = (TRGSW_DFT)dev;
-  res->ak = (void **)mc_xmalloc(sizeof(void *));
-  res->ak[0] = gak;
+  res->device = dev;
+  res->ak_device = gak;
+  res->s = key_views(dev, n, l, out_key->Bg_bit, N);
+  res->ak = (TRLWE_KS_Key *)mc_xmalloc(sizeof(TRLWE_KS_Key) * (size_t)N);   /* src/bootstrap_ga.c:10: entry j <-> generator 2j + 1 */
+  for (int j = 0; j < N; j++) res->ak[j] = trlwe_ks_header(gak, j, 0, l, out_key->Bg_bit);
   return res;
 }
 
 void free_bootstrap_key_ga(Bootstrap_GA_Key key) {
   if (!key) return;
+  if (key->s) mc_trgsw_dft_views_free(key->s, key->n);
+  for (int j = 0; j < key->N; j++) free(key->ak[j]);
+  free(key->ak);
   mosfhet_hip_bsk_destroy((mosfhet_hip_bsk_t)key->device);
   mosfhet_hip_gak_destroy((mosfhet_hip_gak_t)key->ak_device);
-  free(key->s);
-  free(key->ak);
   free(key);
 }
 
@@ -984,11 +1026,25 @@ void free_tlwe_ks_key(TLWE_KS_Key key) {
   }
   free(key->s);
   free(flat);
+  mc_replicas_free(key->device);
   mosfhet_hip_ksk_destroy((mosfhet_hip_ksk_t)key->device);
   free(key);
 }
 
+typedef struct { TLWE *out, *in; TLWE_KS_Key ks; } KsSlice;
+static void ks_slice(void *pv, int lo, int hi) {
+  KsSlice *a = (KsSlice *)pv;
+  if (hi > lo) tlwe_keyswitch_batch(a->out + lo, a->in + lo, hi - lo, a->ks);
+}
+
 void tlwe_keyswitch_batch(TLWE *out, TLWE *in, int count, TLWE_KS_Key ks) {
+  if (g_mc_ndev > 1 && !t_mc_in_shard && count >= 2 * g_mc_ndev) {
+    KsSlice a = {out, in, ks};
+    void *keys[1] = {ks->device};
+    const int kinds[1] = {MC_KEY_KSK};
+    mc_run_sharded(ks_slice, &a, count, keys, kinds, 1);
+    return;
+  }
   mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
   const int n_in = ks->n, n_out = out[0]->n;
   const size_t in_w = (size_t)count * (n_in + 1), out_w = (size_t)count * (n_out + 1);
@@ -996,7 +1052,7 @@ void tlwe_keyswitch_batch(TLWE *out, TLWE *in, int count, TLWE_KS_Key ks) {
   tlwe_array_to_flat(h, in, count, n_in);
   Torus *d = (Torus *)mc_stage_alloc(sizeof(Torus) * (in_w + out_w));
   mc_dev_copy(d, h, sizeof(Torus) * in_w, HIP_H2D);
-  if (mosfhet_hip_tlwe_keyswitch_batch(ctx, (mosfhet_hip_ksk_t)ks->device, d + in_w, d, count, NULL) || mosfhet_hip_ctx_sync(ctx, NULL))
+  if (mosfhet_hip_tlwe_keyswitch_batch(ctx, (mosfhet_hip_ksk_t)mc_key_here(ks->device, MC_KEY_KSK), d + in_w, d, count, NULL) || mosfhet_hip_ctx_sync(ctx, NULL))
     mc_die("tlwe_keyswitch");
   mc_dev_copy(h + in_w, d + in_w, sizeof(Torus) * out_w, HIP_D2H);
   tlwe_array_from_flat(out, h + in_w, count, n_out);
@@ -1138,6 +1194,7 @@ Generic_KS_Key trlwe_new_packing1_KS_key(TRLWE_Key out_key, TLWE_Key in_key, int
 
 void free_trlwe_generic_ks_key(Generic_KS_Key key) {
   if (!key) return;
+  mc_replicas_free(key->device);
   mosfhet_hip_ksk_destroy((mosfhet_hip_ksk_t)key->device);
   free(key);
 }

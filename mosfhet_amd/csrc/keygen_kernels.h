@@ -2,9 +2,14 @@
 // packing key of trlwe_new_packing1_KS_key (src/keyswitch.c:368-390) and the private key of trlwe_new_priv_SK_KS_key_N2
 // (src/keyswitch.c:611-637).  Every row is a fresh TRLWE encryption under the binary key s_out:
 //     a uniform,  b = a * s_out + e + message,  e ~ N(0, sigma) on the torus  (src/trlwe.c:296-316)
-// with a counter-based generator (splitmix64 of (seed, row, coefficient)) instead of the reference's AES / SHAKE streams
-// (src/misc.c:34-91): statistically the same objects, reproducible from the seed, and a 6 GB key takes milliseconds instead of
-// minutes of host time.  The product a * s_out is exact (integer adds over the set bits of the key).
+// Randomness (the reference: AES-CTR / SHAKE256 streams seeded from RDSEED, src/misc.c:34-91, and for seed-compressed rows a public per-row seed,
+// src/trlwe_compressed_vaes.c:139-160):
+//   * MASKS are public values and come from a counter-based generator on a PUBLIC 64-bit seed (keygen_mix: splitmix64 of (seed, row, word)), so that a
+//     seed-compressed key can regenerate them inside the key-switch kernel for a few integer operations per word;
+//   * NOISE is secret: it comes from ChaCha20 under a 256-bit key that is independent of the mask seed (NoiseKey: drawn from the operating system by the
+//     C ABI, or handed over by the host layer from its own ChaCha20 stream), counter = (row, coefficient), nonce = the mask seed.  Knowing every mask
+//     word and the mask seed says nothing about the noise terms.
+// A 6 GB key takes milliseconds instead of minutes of host time.  The product a * s_out is exact (integer adds over the set bits of the key).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -18,12 +23,43 @@ __device__ __forceinline__ uint64_t keygen_mix(uint64_t seed, uint64_t row, uint
   return z ^ (z >> 31);
 }
 
+struct NoiseKey { uint32_t k[8]; };
+
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, 32 - n); }
+#define MOSFHET_QR(a, b, c, d) \
+  a += b; d ^= a; d = rotl32(d, 16); c += d; b ^= c; b = rotl32(b, 12); a += b; d ^= a; d = rotl32(d, 8); c += d; b ^= c; b = rotl32(b, 7)
+
+// first four words of the ChaCha20 block (RFC 8439 core, 64-bit block counter + 64-bit nonce): two 64-bit uniforms
+__device__ __forceinline__ void chacha20_uniforms(const NoiseKey &key, uint64_t counter, uint64_t nonce, uint64_t &u1, uint64_t &u2) {
+  const uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key.k[0], key.k[1], key.k[2], key.k[3], key.k[4], key.k[5], key.k[6], key.k[7],
+                          (uint32_t)counter, (uint32_t)(counter >> 32), (uint32_t)nonce, (uint32_t)(nonce >> 32)};
+  uint32_t x[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) x[i] = s[i];
+#pragma unroll 2
+  for (int r = 0; r < 10; r++) {
+    MOSFHET_QR(x[0], x[4], x[8], x[12]); MOSFHET_QR(x[1], x[5], x[9], x[13]); MOSFHET_QR(x[2], x[6], x[10], x[14]); MOSFHET_QR(x[3], x[7], x[11], x[15]);
+    MOSFHET_QR(x[0], x[5], x[10], x[15]); MOSFHET_QR(x[1], x[6], x[11], x[12]); MOSFHET_QR(x[2], x[7], x[8], x[13]); MOSFHET_QR(x[3], x[4], x[9], x[14]);
+  }
+  u1 = (uint64_t)(x[0] + s[0]) | ((uint64_t)(x[1] + s[1]) << 32);
+  u2 = (uint64_t)(x[2] + s[2]) | ((uint64_t)(x[3] + s[3]) << 32);
+}
+
+// Gaussian noise term of coefficient x of row r on the torus: Box-Muller on two uniforms (src/misc.c:87-91), double2torus of sigma z (src/misc.c:13-15)
+__device__ __forceinline__ uint64_t keygen_noise(const NoiseKey &key, uint64_t mask_seed, uint64_t row, uint64_t x, double sigma) {
+  uint64_t a, b;
+  chacha20_uniforms(key, (row << 16) | x, mask_seed, a, b);
+  const double u1 = ((double)(a >> 11) + 0.5) * 0x1p-53, u2 = ((double)(b >> 11) + 0.5) * 0x1p-53;
+  const double z = cos(6.283185307179586 * u1) * sqrt(-2.0 * log(u2)) * sigma;
+  return (uint64_t)(int64_t)(18446744073709551616.0 * z);
+}
+
 // kind 0 (packing): rows (i < n, j < t, v in 1..2^bb-1), message = s_in[i] v 2^(64-(j+1)bb) on X^0
 // kind 1 (private): rows (i <= n, ...), message polynomial = -s_out * (s_i v 2^(64-(j+1)bb)), s_n = -1
 // One workgroup of 256 threads per row; the mask lives in LDS while the key's set bits are walked.
 __global__ __launch_bounds__(256) void trlwe_table_keygen_kernel(uint64_t *__restrict__ rows, const uint64_t *__restrict__ s_out,
                                                                const uint64_t *__restrict__ s_in, int n, int N, int t, int base_bit, double sigma,
-                                                               uint64_t seed, int kind, size_t first_row, int compressed) {
+                                                               uint64_t seed, int kind, size_t first_row, int compressed, NoiseKey nkey) {
   extern __shared__ uint64_t sh[];   // a[N], then the indices of the set key bits (uint16) packed behind it
   uint64_t *a = sh;
   uint16_t *ones = reinterpret_cast<uint16_t *>(sh + N);
@@ -57,10 +93,7 @@ __global__ __launch_bounds__(256) void trlwe_table_keygen_kernel(uint64_t *__res
       const uint64_t w = a[src & (N - 1)];
       acc += src < 0 ? (uint64_t)0 - w : w;
     }
-    // Box-Muller on two uniforms (src/misc.c:87-91), double2torus of sigma * z (src/misc.c:13-15)
-    const double u1 = ((double)(keygen_mix(seed, r, x, 1) >> 11) + 0.5) * 0x1p-53, u2 = ((double)(keygen_mix(seed, r, x, 2) >> 11) + 0.5) * 0x1p-53;
-    const double z = cos(6.283185307179586 * u1) * sqrt(-2.0 * log(u2)) * sigma;
-    acc += (uint64_t)(int64_t)(18446744073709551616.0 * z);
+    acc += keygen_noise(nkey, seed, r, (uint64_t)x, sigma);
     if (kind == 0) { if (x == 0) acc += dec; }
     else acc += ((uint64_t)0 - s_out[x]) * dec;
     dst_b[x] = acc;
@@ -71,7 +104,7 @@ __global__ __launch_bounds__(256) void trlwe_table_keygen_kernel(uint64_t *__res
 // src/bootstrap_ga.c:17-20): row r = i * 2l + q, q = c * l + j, is a fresh TRLWE(0) with m * 2^(64 - (j+1) Bg) added to coefficient e of component c
 // (trgsw_monomial_sample, src/trgsw.c:152-168; k = 1).  One workgroup per row, same generator and exact a * s as the table keys above.
 __global__ __launch_bounds__(256) void trgsw_bk_keygen_kernel(uint64_t *__restrict__ rows, const uint64_t *__restrict__ s_out, const uint64_t *__restrict__ s_in,
-                                                            int N, int l, int Bg_bit, double sigma, uint64_t seed, int ga) {
+                                                            int N, int l, int Bg_bit, double sigma, uint64_t seed, int ga, NoiseKey nkey) {
   extern __shared__ uint64_t sh[];
   uint64_t *a = sh;
   uint16_t *ones = reinterpret_cast<uint16_t *>(sh + N);
@@ -100,9 +133,7 @@ __global__ __launch_bounds__(256) void trgsw_bk_keygen_kernel(uint64_t *__restri
       const uint64_t w = a[src & (N - 1)];
       acc += src < 0 ? (uint64_t)0 - w : w;
     }
-    const double u1 = ((double)(keygen_mix(seed, r, x, 1) >> 11) + 0.5) * 0x1p-53, u2 = ((double)(keygen_mix(seed, r, x, 2) >> 11) + 0.5) * 0x1p-53;
-    const double z = cos(6.283185307179586 * u1) * sqrt(-2.0 * log(u2)) * sigma;
-    acc += (uint64_t)(int64_t)(18446744073709551616.0 * z);
+    acc += keygen_noise(nkey, seed, r, (uint64_t)x, sigma);
     dst[x] = a[x] + ((c == 0 && x == e) ? val : 0);     // the gadget goes on the mask AFTER b = a * s + e was formed from the plain mask
     dst[N + x] = acc + ((c == 1 && x == e) ? val : 0);
   }
@@ -112,7 +143,7 @@ __global__ __launch_bounds__(256) void trgsw_bk_keygen_kernel(uint64_t *__restri
 // pair, :39-50; the relinearisation key, :3-10 -- they differ only in the polynomial being switched from): entry e, row r < t is
 // TRLWE_{s_out}(msg_e(X) * 2^(64 - (r+1) bb)).  One workgroup per row; the caller transforms the rows afterwards.
 __global__ __launch_bounds__(256) void trlwe_poly_keygen_kernel(uint64_t *__restrict__ rows, const uint64_t *__restrict__ s_out, const uint64_t *__restrict__ msgs,
-                                                              int N, int t, int base_bit, double sigma, uint64_t seed) {
+                                                              int N, int t, int base_bit, double sigma, uint64_t seed, NoiseKey nkey) {
   extern __shared__ uint64_t sh[];
   uint64_t *a = sh;
   uint16_t *ones = reinterpret_cast<uint16_t *>(sh + N);
@@ -142,9 +173,7 @@ __global__ __launch_bounds__(256) void trlwe_poly_keygen_kernel(uint64_t *__rest
       const uint64_t w = a[src & (N - 1)];
       acc += src < 0 ? (uint64_t)0 - w : w;
     }
-    const double u1 = ((double)(keygen_mix(seed, r, x, 1) >> 11) + 0.5) * 0x1p-53, u2 = ((double)(keygen_mix(seed, r, x, 2) >> 11) + 0.5) * 0x1p-53;
-    const double z = cos(6.283185307179586 * u1) * sqrt(-2.0 * log(u2)) * sigma;
-    acc += (uint64_t)(int64_t)(18446744073709551616.0 * z);
+    acc += keygen_noise(nkey, seed, r, (uint64_t)x, sigma);
     dst[N + x] = acc + (msgs[e * (size_t)N + x] << shift);
   }
 }
@@ -162,7 +191,7 @@ __global__ __launch_bounds__(256) void table_expand_kernel(uint64_t *__restrict_
 // LWE -> LWE key-switch table (tlwe_new_KS_key, src/tlwe.c:193-212): row (i, j, v) = TLWE_{s_out}(s_in[i] v 2^(64 - (j+1) bb)), a uniform from the
 // counter-based generator, b = <a, s_out> + e + message.  One wavefront per row.  compressed: only b is stored ([rows] words).
 __global__ __launch_bounds__(64) void tlwe_ksk_keygen_kernel(uint64_t *__restrict__ rows, const uint64_t *__restrict__ s_out, const uint64_t *__restrict__ s_in,
-                                                            int n_out, int t, int base_bit, double sigma, uint64_t seed, size_t first_row, int compressed) {
+                                                            int n_out, int t, int base_bit, double sigma, uint64_t seed, size_t first_row, int compressed, NoiseKey nkey) {
   const size_t r = first_row + blockIdx.x;
   const int cands = (1 << base_bit) - 1, lane = threadIdx.x;
   const int v = (int)(r % cands) + 1, j = (int)((r / cands) % t);
@@ -176,9 +205,7 @@ __global__ __launch_bounds__(64) void tlwe_ksk_keygen_kernel(uint64_t *__restric
   }
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
   if (lane == 0) {
-    const double u1 = ((double)(keygen_mix(seed, r, 0, 1) >> 11) + 0.5) * 0x1p-53, u2 = ((double)(keygen_mix(seed, r, 0, 2) >> 11) + 0.5) * 0x1p-53;
-    const double z = cos(6.283185307179586 * u1) * sqrt(-2.0 * log(u2)) * sigma;
-    acc += (uint64_t)(int64_t)(18446744073709551616.0 * z);
+    acc += keygen_noise(nkey, seed, r, 0, sigma);
     acc += s_in[i] * (uint64_t)v * (1ull << (64 - (j + 1) * base_bit));
     dst[compressed ? 0 : n_out] = acc;
   }

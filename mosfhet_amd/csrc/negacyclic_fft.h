@@ -595,10 +595,11 @@ struct Fft4096 {
 // copied into its accumulator in front of every use (96-128 extra moves per CMUX when left to the compiler), so 2^32 is pinned
 // in a scalar register pair and the magic number in a vector register pair, once per kernel (RoundCtx).
 struct RoundCtx {
-  double scale, magic, two32;
-  __device__ __forceinline__ explicit RoundCtx(double s) : scale(s), magic(0x1.8p52), two32(0x1p32) {
+  double scale, magic, two32, scale32;
+  __device__ __forceinline__ explicit RoundCtx(double s) : scale(s), magic(0x1.8p52), two32(0x1p32), scale32(s * 0x1p32) {
     asm volatile("" : "+v"(magic));
     asm volatile("" : "+s"(two32));
+    asm volatile("" : "+s"(scale32));
   }
 };
 __device__ __forceinline__ uint64_t round_mod_2_64(double v, const RoundCtx &rc) {
@@ -620,17 +621,27 @@ __device__ __forceinline__ uint64_t round_mod_2_64(double v, const RoundCtx &rc)
 // caller may only ask for it when the bound holds for EVERY input (see pbs_kernel: |sum| <= rows * N * Bg/2 * 2^63 by construction).
 template <bool REDUCE = true>
 __device__ __forceinline__ uint64_t add_rounded(uint64_t acc, double v, const RoundCtx &rc) {
-  double f = v * rc.scale;
-  if constexpr (REDUCE) f = f - __builtin_rint(f);
-  const double A = __builtin_fma(f, rc.two32, rc.magic);
-  const double B = A - rc.magic;
-  const double q = __builtin_fma(f, rc.two32, -B);
+  // scale is a power of two, so v * scale is exact and fma(v, scale 2^32, c) == fma(v scale, 2^32, c) bit for bit: without the reduction the scaling
+  // multiply folds into the two fmas
+  double A, B, q;
+  if constexpr (REDUCE) {
+    double f = v * rc.scale;
+    f = f - __builtin_rint(f);
+    A = __builtin_fma(f, rc.two32, rc.magic);
+    B = A - rc.magic;
+    q = __builtin_fma(f, rc.two32, -B);
+  } else {
+    A = __builtin_fma(v, rc.scale32, rc.magic);
+    B = A - rc.magic;
+    q = __builtin_fma(v, rc.scale32, -B);
+  }
   const double C = __builtin_fma(q, rc.two32, rc.magic);
   const uint64_t a = (uint64_t)__double_as_longlong(A), c = (uint64_t)__double_as_longlong(C);
   const uint32_t c_lo = (uint32_t)c;
   const uint32_t lo = (uint32_t)acc + c_lo;
   const uint32_t carry = lo < c_lo ? 1u : 0u;
-  const uint32_t borrow = (uint32_t)(int)__builtin_amdgcn_sbfe((uint32_t)(c >> 32), 0u, 1u);   // 0 or 0xffffffff: -(bit 32 of C), one v_bfe_i32
+  uint32_t borrow;   // 0 or 0xffffffff: -(bit 32 of C).  Spelled in assembly: the compiler turns the bit-field builtin into v_alignbit_b32 + v_ashrrev_i32
+  asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(borrow) : "v"((uint32_t)(c >> 32)));
   const uint32_t hi = (uint32_t)(acc >> 32) + (uint32_t)a + borrow + carry;
   return ((uint64_t)hi << 32) | (uint64_t)lo;
 }

@@ -750,7 +750,7 @@ static void case_dft_level_api(void) {
     trlwe_eval_automorphism(c2, c1, gen, gk->ak[(gen - 1) >> 1]);
     polynomial_permute(want, msg, gen);
     trlwe_phase(ph, c2, rlwe_key);
-    for (int i = 0; i < N; i++) WITHIN(1ULL << 52, want->coeffs[i], ph->coeffs[i], "trlwe_eval_automorphism");
+    for (int i = 0; i < N; i++) WITHIN(1ULL << 56, want->coeffs[i], ph->coeffs[i], "trlwe_eval_automorphism");   /* key-switch noise of a 2 x 2^8 gadget: ~2^52 */
     CHECK(inverse_mod_2N(5, N) * 5 % (2 * N) == 1, "inverse_mod_2N");
     TLWE in = tlwe_new_sample(double2torus(1 / 8.), short_key);
     Torus l4[4] = {int2torus(1, 4), int2torus(5, 4), int2torus(9, 4), int2torus(13, 4)};

@@ -1,0 +1,89 @@
+"""Same-box A/B of bootstrap-kernel variants.
+
+    python tools/ab/run_ab.py build  name[:-DFLAG[,-DFLAG...]] ...     (CPU container: hipcc cross-compiles tools/ab/pbs_ab.hip per variant)
+    python tools/ab/run_ab.py run    [set1|lvl2] [B] [rounds]           (GPU box: times every built variant, interleaved, checks bits vs production)
+
+Variants are tools/ab/_build/ab_<name>.so (git-ignored, shipped by gpurun).  `base` (no flags) is always the production source as it stands.
+"""
+import ctypes as C
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+OUT = os.path.join(HERE, "_build")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unused-value", "-Wno-comment"]
+
+
+def build(specs):
+    os.makedirs(OUT, exist_ok=True)
+    procs = []
+    for spec in specs:
+        name, _, flags = spec.partition(":")
+        cmd = ["hipcc"] + FLAGS + [f for f in flags.split(",") if f] + [os.path.join(HERE, "pbs_ab.hip"), "-o", os.path.join(OUT, "ab_%s.so" % name)]
+        procs.append((name, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for name, p in procs:
+        out = p.communicate()[0]
+        print(name, "ok" if p.returncode == 0 else "FAILED\n" + out[-3000:])
+
+
+def run(pset, B, rounds):
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch
+    import mosfhet_amd as ma
+    from mosfhet_amd import host, engine
+    P = dict({"set1": ma.PARAMS_SET1, "lvl2": ma.PARAMS_LVL2}[pset])
+    host.seed(0x4D4F5346)
+    lk = host.LweKey(P["n"], P["lwe_sigma"])
+    rk = host.RlweKey(P["N"], 1, P["rlwe_sigma"])
+    eng = ma.Engine(0)
+    bsk = eng.load_bootstrap_key(host.gen_bootstrap_key(rk, lk, P["l"], P["Bg_bit"]), 1, P["l"], P["Bg_bit"])
+    lut = np.array([1 << 60, 5 << 60, 9 << 60, 13 << 60], dtype=np.uint64)
+    tv = host.torus_packing(lut, 1, P["N"])
+    cts = host.tlwe_samples([host.double2torus((b % 4) / 8.0) for b in range(B)], lk)
+    d_tv, d_ct = ma.to_device(tv[None], eng.device), ma.to_device(cts, eng.device)
+    want = ma.to_numpy(eng.programmable_bootstrap(bsk, d_tv, d_ct, 3))
+    L = engine.lib()
+    L.mosfhet_hip_bsk_device_dft.restype = C.c_void_p
+    d_bk = L.mosfhet_hip_bsk_device_dft(bsk.h)
+    tw = np.zeros(2 * (P["N"] // 2 - 1), dtype=np.float64)
+    L.mosfhet_hip_twiddles(P["N"], tw.ctypes.data_as(C.c_void_p))
+    d_tw = torch.from_numpy(tw).to(eng.device)
+    libs = {}
+    for path in sorted(glob.glob(os.path.join(OUT, "ab_*.so"))):
+        name = os.path.basename(path)[3:-3]
+        if len(sys.argv) > 5 and name not in sys.argv[5].split(","):
+            continue
+        libs[name] = C.CDLL(path)
+    out = eng.empty(B, P["N"] + 1)
+    times = {k: [] for k in libs}
+    exact = {}
+    for r in range(rounds):
+        for name, lib in libs.items():
+            ms = C.c_float()
+            out.zero_()
+            rc = lib.ab_pbs(C.c_void_p(d_bk), C.c_void_p(d_tw.data_ptr()), C.c_void_p(d_ct.data_ptr()), C.c_void_p(d_tv.data_ptr()), C.c_void_p(out.data_ptr()),
+                            P["n"], B, 3, 3, C.byref(ms))
+            assert rc == 0, (name, rc)
+            times[name].append(ms.value)
+            if r == 0:
+                got = ma.to_numpy(out)
+                exact[name] = bool((got == want).all())
+                if not exact[name]:
+                    ph = host.tlwe_phase(got, rk.extracted_lwe_key().s)
+                    err = np.abs((ph - lut[np.arange(B) % 4]).astype(np.int64).astype(np.float64)).max()
+                    exact[name] = "DIFFERS (max phase error 2^%.1f, %d of %d words differ)" % (np.log2(err + 1), int((got != want).sum()), got.size)
+    base = min(times["base"]) if "base" in times else None
+    for name in libs:
+        t = times[name]
+        print("%-28s min %.3f  med %.3f ms  %s  bit-exact-vs-production=%s" % (name, min(t), sorted(t)[len(t) // 2], ("(%+.1f %% vs base)" % (100 * (min(t) / base - 1))) if base else "", exact[name]))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "build":
+        build(sys.argv[2:])
+    else:
+        run(sys.argv[2] if len(sys.argv) > 2 else "set1", int(sys.argv[3]) if len(sys.argv) > 3 else 4096, int(sys.argv[4]) if len(sys.argv) > 4 else 5)

@@ -16,9 +16,12 @@ for line in open(summary):
     m = re.search(r"(\S+)\s+per-dispatch mean=([0-9.e+]+)", line)
     if m and kernel in line:
         vals[m.group(1)] = float(m.group(2))
+import os
+stamp = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mosfhet_amd", "libmosfhet_hip.so.srchash")
+srchash = open(stamp).read().strip() if os.path.exists(stamp) else None   # bench.py reports `traffic` only for the build it was measured on
 fetch = 2.0 * vals["FETCH_SIZE"] * 1024
 write = vals["WRITE_SIZE"] * 1024
-json.dump({"kernel": kernel, "source": summary, "fetch_bytes_per_launch_corrected": fetch, "write_bytes_per_launch": write,
+json.dump({"kernel": kernel, "source": summary, "srchash": srchash, "fetch_bytes_per_launch_corrected": fetch, "write_bytes_per_launch": write,
            "traffic_bytes_per_launch": fetch + write, "FETCH_SIZE_KiB_raw": vals["FETCH_SIZE"], "WRITE_SIZE_KiB_raw": vals["WRITE_SIZE"],
            "TCC_HIT_sum": vals.get("TCC_HIT_sum"), "TCC_MISS_sum": vals.get("TCC_MISS_sum"),
            "note": "fabric-side L2 counters (Infinity-Cache hits included); FETCH_SIZE doubled per the gfx950 correction"},
