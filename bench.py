@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4096, help="bootstraps per GPU per step")
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams the steps alternate over (1 = strictly back to back)")
     ap.add_argument("--ep-batch", type=int, default=65536, help="TRLWE samples of the external-product roofline line")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -167,9 +168,17 @@ def main():
     d_tv = ma.to_device(tv[None], eng.device)
     d_ct = ma.to_device(cts, eng.device)
     d_out = eng.empty(B, P["k"] * P["N"] + 1)
+    # Consecutive steps are independent batches: they alternate over `--streams` HIP streams (own output buffer each, the inputs are read-only), so
+    # the tail of one launch -- CUs that have run out of work while the slowest teams finish -- is filled by the head of the next.
+    streams = [torch.cuda.Stream(device=eng.device) for _ in range(max(1, args.streams))]
+    d_outs = [d_out] + [eng.empty(B, P["k"] * P["N"] + 1) for _ in streams[1:]]
+    turn = [0]
 
     def step():
-        eng.programmable_bootstrap(bsk, d_tv, d_ct, 3, 0, 0, out=d_out)
+        i = turn[0] % len(streams)
+        turn[0] += 1
+        with torch.cuda.stream(streams[i]):
+            eng.programmable_bootstrap(bsk, d_tv, d_ct, 3, 0, 0, out=d_outs[i])
 
     step()
     torch.cuda.synchronize()
@@ -196,10 +205,13 @@ def main():
     h_in = torch.from_numpy(cts.view(np.int64)).pin_memory()
     h_out = torch.empty(B, P["k"] * P["N"] + 1, dtype=torch.int64).pin_memory()
 
-    def step_host():
-        d_ct.copy_(h_in, non_blocking=True)
-        step()
-        h_out.copy_(d_out, non_blocking=True)
+    d_ct_h = torch.empty_like(d_ct)
+
+    def step_host():   # one stream: copy in, bootstrap, copy out
+        with torch.cuda.stream(streams[0]):
+            d_ct_h.copy_(h_in, non_blocking=True)
+            eng.programmable_bootstrap(bsk, d_tv, d_ct_h, 3, 0, 0, out=d_out)
+            h_out.copy_(d_out, non_blocking=True)
 
     step_host()
     torch.cuda.synchronize()
@@ -278,7 +290,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "batch of %d programmable bootstraps per GPU, SET_1 n=585 N=1024 k=1 l=2 Bg=2^8 "
                                    "(BASELINE.json configs[1])" % B,
-                       "batch_per_gpu": B, "parallelism": "batch sharded over %d GPU(s), bootstrap key replicated, "
+                       "batch_per_gpu": B, "streams": len(streams), "parallelism": "batch sharded over %d GPU(s), bootstrap key replicated, "
                                                           "no collective on the data path" % world},
             "roofline": {"bound": "fp64_valu", "achieved": achieved_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tflops / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,

@@ -181,9 +181,60 @@ __device__ __forceinline__ void cmux_digits(typename Digits<L, BG>::word_t (&w_l
   }
 }
 
+#ifdef MOSFHET_EXP_PLAN
+// ---- rotation with wave-uniform bookkeeping (one wavefront per ciphertext: F = Fft1024) ----
+// Lane t owns coefficients j = t + 64 m', m' < 16.  With abar = 64 q + r the source index of (X^abar p)[j] in the antiperiodic extension of p
+// (period 2N, p[i + N] = -p[i]) is 64 row + u with  u = t - r, row = (m' - q) mod 32  for lanes t >= r  and  u = t - r + 64, row = (m' - q - 1) mod 32
+// for the others: the physical row is row mod 16, the sign is bit 4 of row.  Everything that depends on m' and abar only -- the row offsets and, per
+// m', WHICH LANES see a negated value -- is scalar arithmetic; a lane's address is its own base plus a scalar.  The array carries a copy of its last
+// row (coefficients N - 64 .. N - 1) in the 64 words in front of it, so that "one row lower" needs no wrap-around for the lanes t < r.
+struct RotPlan {
+  uint64_t G;            // lanes with t >= r
+  uint32_t negA, negB;   // bit m': coefficient m' comes out negated, for the lanes in G / the others
+  int qa;                // (-q) mod 32
+  int base8;             // per lane: byte offset of this lane's source in row 0 (lanes t < r: one row lower)
+};
+__device__ __forceinline__ RotPlan make_rot_plan(int abar, int t) {
+  RotPlan pl;
+  const int r = abar & 63, q = abar >> 6;
+  pl.qa = (32 - q) & 31;
+  const int qb = (pl.qa + 31) & 31;
+  pl.G = ~0ull << r;
+  pl.negA = ((pl.qa & 16) ? 0xffffu : 0u) ^ ((0xffffu << (16 - (pl.qa & 15))) & 0xffffu);
+  pl.negB = ((qb & 16) ? 0xffffu : 0u) ^ ((0xffffu << (16 - (qb & 15))) & 0xffffu);
+  pl.base8 = (((t - r) & 63) << 3) - (t < r ? 512 : 0);
+  return pl;
+}
+__device__ __forceinline__ uint32_t lane_select(uint32_t if_clear, uint32_t if_set, uint64_t lane_mask) {
+  uint32_t r;
+  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(lane_mask));
+  return r;
+}
+// digit words of (X^abar - 1) p + off for this lane's 16 coefficients; `arr` = the component in LDS (64 mirror words, then N words)
+template <int L, int BG>
+__device__ __forceinline__ void cmux_digits_plan(typename Digits<L, BG>::word_t (&w_lo)[8], typename Digits<L, BG>::word_t (&w_hi)[8], uint32_t (&ext)[8],
+                                                 const uint64_t *arr, const RotPlan &pl, uint64_t off, int t) {
+  using D = Digits<L, BG>;
+  const char *row0 = reinterpret_cast<const char *>(arr + 64) + pl.base8;
+  uint64_t dd[16];
+#pragma unroll
+  for (int mp = 0; mp < 16; mp++) {
+    const int soff = ((pl.qa + mp) & 15) << 9;
+    const uint64_t nm = (((pl.negA >> mp) & 1u) ? pl.G : 0ull) | (((pl.negB >> mp) & 1u) ? ~pl.G : 0ull);
+    const uint64_t v = *reinterpret_cast<const uint64_t *>(row0 + soff);
+    const uint64_t nv = 0 - v;
+    const uint64_t x = ((uint64_t)lane_select((uint32_t)(v >> 32), (uint32_t)(nv >> 32), nm) << 32) | lane_select((uint32_t)v, (uint32_t)nv, nm);
+    dd[mp] = x - arr[64 + mp * 64 + t] + off;
+  }
+#pragma unroll
+  for (int m = 0; m < 8; m++) D::pack(w_lo[m], w_hi[m], ext[m], dd[m], dd[m + 8]);
+}
+#endif
+
 // The L rows of component p: digits -> forward transform -> MAC against key rows p*L .. p*L+L-1.
 // The key row's component 0 is loaded under the last transform pass, component 1 under the MAC of component 0.
-template <class F, int L, int BG>
+// ONE_K: one register buffer for the key row (component 1 is loaded when component 0 has been consumed) -- for callers that need the 32 registers
+template <class F, int L, int BG, bool ONE_K = false>
 __device__ __forceinline__ void cmux_rows(const typename Digits<L, BG>::word_t (&w_lo)[8], const typename Digits<L, BG>::word_t (&w_hi)[8],
                                           const uint32_t (&ext)[8], int p, double (&o_re)[2][8], double (&o_im)[2][8], d2 *xch,
                                           const F &fft, const d2 *__restrict__ bkrow, int Bg_bit, int t) {
@@ -205,6 +256,22 @@ __device__ __forceinline__ void cmux_rows(const typename Digits<L, BG>::word_t (
 #pragma unroll
     for (int m = 0; m < 8; m++) k0[m] = row[m * T + t];
     fft.forward_tail(re, im);
+    if constexpr (ONE_K) {
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        o_re[0][m] = __builtin_fma(-im[m], k0[m].y, __builtin_fma(re[m], k0[m].x, o_re[0][m]));
+        o_im[0][m] = __builtin_fma(im[m], k0[m].x, __builtin_fma(re[m], k0[m].y, o_im[0][m]));
+      }
+      asm volatile("" ::: "memory");   // keep the second load behind the first product: it reuses the registers
+#pragma unroll
+      for (int m = 0; m < 8; m++) k0[m] = row[M + m * T + t];
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        o_re[1][m] = __builtin_fma(-im[m], k0[m].y, __builtin_fma(re[m], k0[m].x, o_re[1][m]));
+        o_im[1][m] = __builtin_fma(im[m], k0[m].x, __builtin_fma(re[m], k0[m].y, o_im[1][m]));
+      }
+      continue;
+    }
 #pragma unroll
     for (int m = 0; m < 8; m++) {
       k1[m] = row[M + m * T + t];
@@ -232,7 +299,13 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
   // reduction mod 1 in front (add_rounded); that holds for SET_1's 2 x 2^8 gadget at N = 1024 (2^82) and is decided at compile time.
   constexpr bool kReduce = !(BG > 0 && kCeilLog2<2 * L>::value + (F::LOGM + 1) + BG - 1 + 63 < 83);
   __shared__ __attribute__((aligned(16))) d2 xch[F::XCH_SLOTS];
-  __shared__ __attribute__((aligned(16))) uint64_t acc1[N];
+#ifdef MOSFHET_EXP_PLAN
+  constexpr int kMirror = std::is_same<F, Fft1024>::value ? 64 : 0;   // copy of the component's last 64 coefficients in front of it (cmux_digits_plan)
+#else
+  constexpr int kMirror = 0;
+#endif
+  __shared__ __attribute__((aligned(16))) uint64_t acc1_store[N + kMirror];
+  uint64_t *const acc1 = acc1_store + kMirror;
   const int t = threadIdx.x;
   const size_t b = blockIdx.x;
   const uint64_t *__restrict__ ct = p.in + (p.rows > 1 ? b / (size_t)p.rows : b) * (size_t)(p.n + 1);
@@ -251,6 +324,7 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
       acc1[m * T + t] = src[N + m * T + t];
       acc1[M + m * T + t] = src[N + M + m * T + t];
     }
+    if (kMirror) acc1_store[t] = src[N + M + 7 * T + t];
   } else {
     // src/bootstrap.c:194-195: acc = tv * X^(2N - bbar), gathered straight from global memory
     const uint64_t *__restrict__ tv = p.rows > 1 ? p.tv + (b % (size_t)p.rows) * (size_t)(2 * N) : p.tv + b * (size_t)p.tv_stride;
@@ -265,6 +339,7 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
       acc1[m * T + t] = rot_coeff<N>(tv + N, m * T + t, a_lo, flip);
       acc1[M + m * T + t] = rot_coeff<N>(tv + N, M + m * T + t, a_lo, flip);
     }
+    if (kMirror) acc1_store[t] = rot_coeff<N>(tv + N, M + 7 * T + t, a_lo, flip);
   }
   F::sync();
 
@@ -285,13 +360,38 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
     for (int c = 0; c < 2; c++)
 #pragma unroll
       for (int m = 0; m < 8; m++) { o_re[c][m] = 0.0; o_im[c][m] = 0.0; }
-    constexpr int kUnrollQ = L == 1 ? 2 : 1;
+#ifdef MOSFHET_EXP_PLAN
+    if constexpr (std::is_same<F, Fft1024>::value) {
+      const RotPlan pl = make_rot_plan(abar, t);
+#pragma unroll 1
+      for (int q = 0; q < 2; q++) {
+        typename Digits<L, BG>::word_t w_lo[8], w_hi[8];
+        uint32_t ext[8];
+        uint64_t *st = reinterpret_cast<uint64_t *>(xch);
+        if (q == 0) {   // component a lives in registers: stage it (with the mirror of its last row), then it is read like component b
+          st[t] = ah[7];
+#pragma unroll
+          for (int m = 0; m < 8; m++) {
+            st[64 + m * T + t] = al[m];
+            st[64 + M + m * T + t] = ah[m];
+          }
+          F::sync();
+        }
+        cmux_digits_plan<L, BG>(w_lo, w_hi, ext, q ? acc1_store : st, pl, off, t);
+        if (q == 0) F::sync();
+        cmux_rows<F, L, BG>(w_lo, w_hi, ext, q, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
+      }
+    } else
+#endif
+    {
+      constexpr int kUnrollQ = L == 1 ? 2 : 1;
 #pragma unroll kUnrollQ
-    for (int q = 0; q < 2; q++) {
-      typename Digits<L, BG>::word_t w_lo[8], w_hi[8];
-      uint32_t ext[8];
-      cmux_digits<F, L, BG>(w_lo, w_hi, ext, al, ah, q ? acc1 : nullptr, xch, a_lo, flip, off, t);
-      cmux_rows<F, L, BG>(w_lo, w_hi, ext, q, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
+      for (int q = 0; q < 2; q++) {
+        typename Digits<L, BG>::word_t w_lo[8], w_hi[8];
+        uint32_t ext[8];
+        cmux_digits<F, L, BG>(w_lo, w_hi, ext, al, ah, q ? acc1 : nullptr, xch, a_lo, flip, off, t);
+        cmux_rows<F, L, BG>(w_lo, w_hi, ext, q, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
+      }
     }
     fft.inverse2(o_re[0], o_im[0], o_re[1], o_im[1], xch, t);
 #pragma unroll
@@ -302,7 +402,9 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
 #pragma unroll
     for (int m = 0; m < 8; m++) {
       acc1[m * T + t] = add_rounded<kReduce>(acc1[m * T + t], o_re[1][m], scale);
-      acc1[M + m * T + t] = add_rounded<kReduce>(acc1[M + m * T + t], o_im[1][m], scale);
+      const uint64_t upd = add_rounded<kReduce>(acc1[M + m * T + t], o_im[1][m], scale);
+      acc1[M + m * T + t] = upd;
+      if (kMirror && m == 7) acc1_store[t] = upd;
     }
     F::sync();
   }
@@ -826,8 +928,7 @@ __global__ __launch_bounds__(F::THREADS) void dft_to_torus_kernel(const d2 *__re
 // trgsw_mul_trlwe_DFT + trlwe_from_DFT for a batch [src/trgsw.c:385-423, src/trlwe.c:629-634]: out[b] = TRGSW (.) in[b], back in the torus domain.
 // The HBM-bound kernel of the path: per unit one TRLWE in and one out (32 KiB at N = 1024) against a key entry that stays in the caches.
 //   * persistent teams: the grid is the chip's resident capacity and every team walks units b, b + grid, ... -- twiddles, rounding constants and the
-//     launch cost are paid once per team; the second wavefront of the SIMD covers a team's load latency (holding the next unit's input in registers
-//     as well spills: 756 bytes of scratch and a third of the speed);
+//     launch cost are paid once per team, and half a ciphertext is always in flight from HBM (software pipeline below);
 //   * BG > 0: gadget base known at compile time (packed digit words, as in pbs_kernel); BG = 0: run-time Bg_bit;
 //   * the two inverse transforms are pipelined through the one transpose buffer (inverse2), the first key row initialises the accumulators.
 // key_stride (in d2): 0 = one TRGSW for the whole batch, else TRGSW b starts at bkrow + b * key_stride (per-ciphertext selectors,
@@ -835,7 +936,10 @@ __global__ __launch_bounds__(F::THREADS) void dft_to_torus_kernel(const d2 *__re
 // in0 != nullptr: CMUX (applications/leveled_lut/vertical_packing.c:24-33): out[b] = in0[b] + TRGSW (.) (in[b] - in0[b])  (out may alias in0)
 // out_dft != nullptr: trgsw_mul_trlwe_DFT as the reference declares it (include/mosfhet.h:344): the result stays in the DFT domain,
 // out_dft[b][c][slot] in slot order; trlwe_from_DFT (dft_to_torus_kernel) finishes it with the same inverse transform and rounding.
-template <class F, int L, int BG>
+#ifndef EP_ONE_K
+#define EP_ONE_K false
+#endif
+template <class F, int L, int BG, bool CMUX>
 __global__ __launch_bounds__(F::THREADS, 2) void external_product_kernel(const d2 *__restrict__ bkrow0, const d2 *__restrict__ tw,
                                                                        const uint64_t *__restrict__ in, uint64_t *__restrict__ out, int Bg_bit_rt, int count,
                                                                        size_t key_stride = 0, size_t in_stride = 2 * F::N,
@@ -854,26 +958,84 @@ __global__ __launch_bounds__(F::THREADS, 2) void external_product_kernel(const d
   for (int i = 0; i < L; i++) off += 1ull << (63 - i * Bg_bit);
   const RoundCtx scale(0x1p-64 / (double)M);
 
+  // Software pipeline over the team's units: the 8 KiB of a component are requested one phase before they are needed and wait in registers as raw
+  // words (32 VGPRs) only until they arrive, then as packed digit words (16) -- so a team always has half a ciphertext in flight from HBM.
+  uint64_t raw_lo[8], raw_hi[8];
+  auto request = [&](size_t u, int q) {
+    const uint64_t *ct = in + u * in_stride + (size_t)q * N;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      raw_lo[m] = ct[m * T + t];
+      raw_hi[m] = ct[M + m * T + t];
+    }
+    if constexpr (CMUX) {
+      const uint64_t *c0 = in0 + u * 2 * N + (size_t)q * N;
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        raw_lo[m] -= c0[m * T + t];
+        raw_hi[m] -= c0[M + m * T + t];
+      }
+    }
+  };
+  typename D::word_t w_lo[8], w_hi[8];
+  uint32_t ext[8];
+  auto pack = [&]() {
+#pragma unroll
+    for (int m = 0; m < 8; m++) D::pack(w_lo[m], w_hi[m], ext[m], raw_lo[m] + off, raw_hi[m] + off);
+  };
+  if constexpr (T > 64) {
+    // Rings of two or four wavefronts per team keep the plain structure -- component loop rolled, each component requested where it is used.  (The
+    // pipelined form below gave intermittently wrong outputs at N = 4096 in the parity tests and is confined to the one-wavefront ring, where it is
+    // measured and where the team needs no workgroup barriers.)
+    for (size_t u = blockIdx.x; u < (size_t)count; u += gridDim.x) {
+      const d2 *__restrict__ bkrow = bkrow0 + u * key_stride;
+      double o_re[2][8], o_im[2][8];
+#pragma unroll
+      for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int m = 0; m < 8; m++) { o_re[c][m] = 0.0; o_im[c][m] = 0.0; }
+#pragma unroll 1
+      for (int q = 0; q < 2; q++) {
+        request(u, q);
+        pack();
+        cmux_rows<F, L, BG>(w_lo, w_hi, ext, q, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
+      }
+      if (out_dft) {
+        d2 *dd = out_dft + u * 2 * M;
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+          for (int m = 0; m < 8; m++) dd[c * M + m * T + t] = d2{o_re[c][m], o_im[c][m]};
+        continue;
+      }
+      fft.inverse2(o_re[0], o_im[0], o_re[1], o_im[1], xch, t);
+      uint64_t *dst = out + u * 2 * N;
+      const uint64_t *c0 = CMUX ? in0 + u * 2 * N : nullptr;
+#pragma unroll
+      for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          const uint64_t s_lo = CMUX ? c0[c * N + m * T + t] : 0, s_hi = CMUX ? c0[c * N + m * T + t + M] : 0;
+          dst[c * N + m * T + t] = add_rounded<kReduce>(s_lo, o_re[c][m], scale);
+          dst[c * N + m * T + t + M] = add_rounded<kReduce>(s_hi, o_im[c][m], scale);
+        }
+    }
+    return;
+  }
+  if ((size_t)blockIdx.x < (size_t)count) request(blockIdx.x, 0);
   for (size_t u = blockIdx.x; u < (size_t)count; u += gridDim.x) {
-    const uint64_t *ct = in + u * in_stride;
-    const uint64_t *c0 = in0 ? in0 + u * 2 * N : nullptr;
     const d2 *__restrict__ bkrow = bkrow0 + u * key_stride;
     double o_re[2][8], o_im[2][8];
 #pragma unroll
     for (int c = 0; c < 2; c++)
 #pragma unroll
       for (int m = 0; m < 8; m++) { o_re[c][m] = 0.0; o_im[c][m] = 0.0; }
-#pragma unroll 1
-    for (int q = 0; q < 2; q++) {   // rolled: the loop body must stay small (registers, instruction cache)
-      typename D::word_t w_lo[8], w_hi[8];
-      uint32_t ext[8];
-#pragma unroll
-      for (int m = 0; m < 8; m++) {
-        const uint64_t s_lo = c0 ? c0[q * N + m * T + t] : 0, s_hi = c0 ? c0[q * N + M + m * T + t] : 0;
-        D::pack(w_lo[m], w_hi[m], ext[m], ct[q * N + m * T + t] - s_lo + off, ct[q * N + M + m * T + t] - s_hi + off);
-      }
-      cmux_rows<F, L, BG>(w_lo, w_hi, ext, q, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
-    }
+    pack();              // component a (requested during the previous unit)
+    request(u, 1);       // component b: in flight under the rows of component a
+    cmux_rows<F, L, BG, EP_ONE_K>(w_lo, w_hi, ext, 0, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
+    pack();
+    if (u + gridDim.x < (size_t)count) request(u + gridDim.x, 0);   // the next unit's component a: under the rows of b, the inverse pair and the stores
+    cmux_rows<F, L, BG, EP_ONE_K>(w_lo, w_hi, ext, 1, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
     if (out_dft) {
       d2 *dd = out_dft + u * 2 * M;
 #pragma unroll
@@ -884,11 +1046,12 @@ __global__ __launch_bounds__(F::THREADS, 2) void external_product_kernel(const d
     }
     fft.inverse2(o_re[0], o_im[0], o_re[1], o_im[1], xch, t);
     uint64_t *dst = out + u * 2 * N;
+    const uint64_t *c0 = CMUX ? in0 + u * 2 * N : nullptr;
 #pragma unroll
     for (int c = 0; c < 2; c++)
 #pragma unroll
       for (int m = 0; m < 8; m++) {   // (out may alias in0: each lane reads its words of in0 before it writes them)
-        const uint64_t s_lo = c0 ? c0[c * N + m * T + t] : 0, s_hi = c0 ? c0[c * N + m * T + t + M] : 0;
+        const uint64_t s_lo = CMUX ? c0[c * N + m * T + t] : 0, s_hi = CMUX ? c0[c * N + m * T + t + M] : 0;
         dst[c * N + m * T + t] = add_rounded<kReduce>(s_lo, o_re[c][m], scale);
         dst[c * N + m * T + t + M] = add_rounded<kReduce>(s_hi, o_im[c][m], scale);
       }

@@ -329,7 +329,11 @@ static void launch_external_product(int l, int Bg_bit, hipStream_t s, const d2 *
                                     size_t in_stride, const uint64_t *d_in0, d2 *d_out_dft) {
   const int cap = resident_teams(F::THREADS);
   const dim3 grid((unsigned)(count < cap ? count : cap)), block(F::THREADS);
-#define EP_GO(LL, BB) hipLaunchKernelGGL((external_product_kernel<F, LL, BB>), grid, block, 0, s, row, tw, d_in, d_out, Bg_bit, count, key_stride, in_stride, d_in0, d_out_dft)
+#define EP_GO(LL, BB)                                                                                                                                    \
+  do {                                                                                                                                                   \
+    if (d_in0) hipLaunchKernelGGL((external_product_kernel<F, LL, BB, true>), grid, block, 0, s, row, tw, d_in, d_out, Bg_bit, count, key_stride, in_stride, d_in0, d_out_dft);   \
+    else hipLaunchKernelGGL((external_product_kernel<F, LL, BB, false>), grid, block, 0, s, row, tw, d_in, d_out, Bg_bit, count, key_stride, in_stride, d_in0, d_out_dft);      \
+  } while (0)
   if (l == 2 && Bg_bit == 8) EP_GO(2, 8);
   else if (l == 4 && Bg_bit == 9) EP_GO(4, 9);
   else if (l == 1 && Bg_bit == 23) EP_GO(1, 23);

@@ -55,9 +55,9 @@ int main(int argc, char **argv) {
     Torus lut8[8];
     for (int i = 0; i < 8; i++) lut8[i] = int2torus((uint64_t)((3 * i + 1) & 7), 3);
     TRLWE tv8 = trlwe_alloc_new_sample(k, N);
-    trlwe_torus_packing(tv8, lut8, 8);
+    trlwe_torus_packing_many_LUT(tv8, lut8, 4, 2);   /* test_FDFB_new (test/tests.c:1095-1127): 2 interleaved tables of 4 */
     TLWE *fin = tlwe_alloc_sample_array(16, n), *fout = tlwe_alloc_sample_array(16, N);
-    for (int i = 0; i < 16; i++) tlwe_sample(fin[i], double2torus((i % 8) / 8.), lwe_key);
+    for (int i = 0; i < 16; i++) tlwe_sample(fin[i], int2torus((uint64_t)(i % 8), 3), lwe_key);
     full_domain_functional_bootstrap_batch(fout, tv8, fin, 16, bk, ks, 3);
     for (int i = 0; i < 16; i++) {
       full_domain_functional_bootstrap(one, tv8, fin[i], bk, ks, 3);

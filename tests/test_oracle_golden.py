@@ -192,3 +192,35 @@ def test_callers_match_reference_golden(oracle):
             assert O.torus_dist(ph_m, U["lut"][m]) < 2.0 ** 58 and O.torus_dist(ph_r, U["lut"][m]) < 2.0 ** 58
             assert O.torus_dist(ph_m, ph_r) < 2.0 ** 50, (be, m)
     assert seen >= 1
+
+
+def test_reference_phase_error_distribution_pins_the_batch_criterion(oracle):
+    """tests/golden/phase_error.npz = |phase - LUT slot| of 2048 SET_1 programmable bootstraps through BOTH reference builds and the oracle
+    (make_phase_error_golden.py).  It pins the batch criterion the GPU tests and bench.py use (none beyond 2^60, >= 99.5 % within 2^58) to what
+    the reference produces itself, and the host layer's seeded generator + the oracle reproduce the oracle column bit for bit."""
+    import sys
+    GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(GOLDEN, "phase_error.npz"))
+    ref = {k: g["err_" + k] for k in ("avx512", "ffnt", "oracle")}
+    for k, e in ref.items():
+        assert e.size == 2048 and e.max() < 2.0 ** 58 and (e < 2.0 ** 57).mean() > 0.94, k          # the reference's own tail
+        assert 55.8 < np.log2(np.sqrt((e ** 2).mean())) < 56.1, k                                     # sigma ~ 2^55.97: 2^58 is 4.1 sigma
+    # Per SAMPLE the three disagree (a gadget digit that FFT rounding flips early in a bootstrap re-rolls the rest of its noise: a third of the
+    # samples agree to 2^40, the others differ by up to 2^57) -- only the DISTRIBUTION is comparable: equal rms within 3 %, equal quartiles within 8 %
+    for k in ("ffnt", "oracle"):
+        assert abs(np.sqrt((ref[k] ** 2).mean()) / np.sqrt((ref["avx512"] ** 2).mean()) - 1) < 0.03, k
+        for q in (0.25, 0.5, 0.75, 0.95):
+            assert abs(np.quantile(ref[k], q) / np.quantile(ref["avx512"], q) - 1) < 0.08, (k, q)
+    agree = np.abs(ref["avx512"] - ref["oracle"]) < 2.0 ** 40
+    assert 0.2 < agree.mean() < 1.0, agree.mean()
+    # reproducibility: same seed -> same keys and ciphertexts -> the oracle's outputs again (a sample of the batch; the full batch takes a minute)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_phase_error_golden as M
+    from mosfhet_amd import host
+    P, lk, rk, bk, lut, tv, cts = M.inputs()
+    assert (cts[0] == g["first_ct"]).all() and (tv == g["tv"]).all()
+    bk_dft = oracle.bk_to_dft(bk, P["k"], P["l"])
+    s_out = rk.extracted_lwe_key().s
+    for b in (0, 1, 777, 2047):
+        out = oracle.programmable_bootstrap(tv, cts[b], bk_dft, P["l"], P["Bg_bit"], 3, 0, 0)
+        assert M.dist(host.tlwe_phase(out[None], s_out), lut[[b % 4]])[0] == ref["oracle"][b], b

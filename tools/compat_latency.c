@@ -1,7 +1,7 @@
 /* single-call latency through the compat API: gcc -O2 -Iinclude tools/compat_latency.c -Lmosfhet_amd -lmosfhet_hip -Wl,-rpath,$PWD/mosfhet_amd */
 #include <stdio.h>
 #include <time.h>
-#include "mosfhet_compat.h"
+#include <mosfhet.h>
 static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
 int main(void) {
   mosfhet_seed(1);
@@ -17,6 +17,24 @@ int main(void) {
   const double t0 = now();
   for (int i = 0; i < 50; i++) programmable_bootstrap(out, tv, in, bk, 3, 0, 0);
   printf("programmable_bootstrap(out, tv, in, bk, 3, 0, 0): %.3f ms per call (single sample, host structs in and out)\n", (now() - t0) / 50);
+  /* the canonical gate of the reference's callers (applications/multi-ciphertext-arith/src/integer.c:94-95): key switch N -> n, then bootstrap */
+  {
+    TLWE_Key xk = tlwe_alloc_key(1024, 2.989e-8);
+    trlwe_extract_tlwe_key(xk, rk);
+    TLWE_KS_Key ks = tlwe_new_KS_key(lk, xk, 5, 2);
+    TLWE big = tlwe_new_sample(double2torus(1. / 8), xk), small = tlwe_alloc_sample(585);
+    tlwe_keyswitch(small, big, ks);
+    programmable_bootstrap(out, tv, small, bk, 3, 0, 0);
+    const double g0 = now();
+    for (int i = 0; i < 50; i++) {
+      tlwe_keyswitch(small, big, ks);
+      programmable_bootstrap(out, tv, small, bk, 3, 0, 0);
+    }
+    printf("tlwe_keyswitch + programmable_bootstrap (one gate): %.3f ms per gate (two calls, host structs in and out)\n", (now() - g0) / 50);
+    const double k0 = now();
+    for (int i = 0; i < 50; i++) tlwe_keyswitch(small, big, ks);
+    printf("tlwe_keyswitch alone: %.3f ms per call\n", (now() - k0) / 50);
+  }
   /* the batch entry with host structs: marshalling + copies + kernel */
   enum { B = 4096 };
   TLWE *ins = tlwe_alloc_sample_array(B, 585), *outs = tlwe_alloc_sample_array(B, 1024);
