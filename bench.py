@@ -252,8 +252,10 @@ def main():
         d_ep_out = eng.empty(B_ep, 2, N_)
         eng.external_product(bsk, 1, d_ep_in, out=d_ep_out)
         torch.cuda.synchronize()
+        for _ in range(5):      # warm-up: the first launches of a new kernel run 10-15 % slower (clock and cache state)
+            eng.external_product(bsk, 1, d_ep_in, out=d_ep_out)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        reps = 10
+        reps = 20
         ev[0].record(torch.cuda.current_stream())      # the engine launches on torch's current stream (mosfhet_amd/engine.py: _stream)
         for _ in range(reps):
             eng.external_product(bsk, 1, d_ep_in, out=d_ep_out)

@@ -234,14 +234,20 @@ __device__ __forceinline__ void cmux_digits_plan(typename Digits<L, BG>::word_t 
 // The L rows of component p: digits -> forward transform -> MAC against key rows p*L .. p*L+L-1.
 // The key row's component 0 is loaded under the last transform pass, component 1 under the MAC of component 0.
 // ONE_K: one register buffer for the key row (component 1 is loaded when component 0 has been consumed) -- for callers that need the 32 registers
-template <class F, int L, int BG, bool ONE_K = false>
+// FIRST: this call holds the first row of the product (component 0, level 0): its products INITIALISE the accumulators (x * y where the chain would
+// compute fma(x, y, 0.0): the same number), so the accumulator registers are free until then
+template <class F, int L, int BG, bool ONE_K = false, bool FIRST = false>
 __device__ __forceinline__ void cmux_rows(const typename Digits<L, BG>::word_t (&w_lo)[8], const typename Digits<L, BG>::word_t (&w_hi)[8],
                                           const uint32_t (&ext)[8], int p, double (&o_re)[2][8], double (&o_im)[2][8], d2 *xch,
                                           const F &fft, const d2 *__restrict__ bkrow, int Bg_bit, int t) {
   constexpr int M = F::M, T = F::THREADS;
   using D = Digits<L, BG>;
   // two levels are unrolled (the next row's digit conversion and first pass overlap the MAC tail; no scratch at l = 2), more stay rolled
+#ifdef MOSFHET_ROWS_ROLLED
+  constexpr int kUnroll = 1;
+#else
   constexpr int kUnroll = L <= 2 ? L : 1;
+#endif
 #pragma unroll kUnroll
   for (int lv = 0; lv < L; lv++) {
     const d2 *__restrict__ row = bkrow + (size_t)(p * L + lv) * (2 * M);
@@ -256,6 +262,20 @@ __device__ __forceinline__ void cmux_rows(const typename Digits<L, BG>::word_t (
 #pragma unroll
     for (int m = 0; m < 8; m++) k0[m] = row[m * T + t];
     fft.forward_tail(re, im);
+    if (FIRST && lv == 0) {
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        k1[m] = row[M + m * T + t];
+        o_re[0][m] = __builtin_fma(-im[m], k0[m].y, re[m] * k0[m].x);
+        o_im[0][m] = __builtin_fma(im[m], k0[m].x, re[m] * k0[m].y);
+      }
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        o_re[1][m] = __builtin_fma(-im[m], k1[m].y, re[m] * k1[m].x);
+        o_im[1][m] = __builtin_fma(im[m], k1[m].x, re[m] * k1[m].y);
+      }
+      continue;
+    }
     if constexpr (ONE_K) {
 #pragma unroll
       for (int m = 0; m < 8; m++) {
@@ -939,6 +959,13 @@ __global__ __launch_bounds__(F::THREADS) void dft_to_torus_kernel(const d2 *__re
 #ifndef EP_ONE_K
 #define EP_ONE_K false
 #endif
+#ifdef MOSFHET_EP_NO_NT
+#define EP_NT_LOAD(p) (*(p))
+#define EP_NT_STORE(v, p) (*(p) = (v))
+#else
+#define EP_NT_LOAD(p) __builtin_nontemporal_load(p)
+#define EP_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#endif
 template <class F, int L, int BG, bool CMUX>
 __global__ __launch_bounds__(F::THREADS, 2) void external_product_kernel(const d2 *__restrict__ bkrow0, const d2 *__restrict__ tw,
                                                                        const uint64_t *__restrict__ in, uint64_t *__restrict__ out, int Bg_bit_rt, int count,
@@ -962,11 +989,12 @@ __global__ __launch_bounds__(F::THREADS, 2) void external_product_kernel(const d
   // words (32 VGPRs) only until they arrive, then as packed digit words (16) -- so a team always has half a ciphertext in flight from HBM.
   uint64_t raw_lo[8], raw_hi[8];
   auto request = [&](size_t u, int q) {
+    // ciphertexts stream through once: non-temporal loads and stores (EP_NT) keep them from displacing the key entry and the twiddles in the caches
     const uint64_t *ct = in + u * in_stride + (size_t)q * N;
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-      raw_lo[m] = ct[m * T + t];
-      raw_hi[m] = ct[M + m * T + t];
+      raw_lo[m] = EP_NT_LOAD(&ct[m * T + t]);
+      raw_hi[m] = EP_NT_LOAD(&ct[M + m * T + t]);
     }
     if constexpr (CMUX) {
       const uint64_t *c0 = in0 + u * 2 * N + (size_t)q * N;
@@ -1016,8 +1044,8 @@ __global__ __launch_bounds__(F::THREADS, 2) void external_product_kernel(const d
 #pragma unroll
         for (int m = 0; m < 8; m++) {
           const uint64_t s_lo = CMUX ? c0[c * N + m * T + t] : 0, s_hi = CMUX ? c0[c * N + m * T + t + M] : 0;
-          dst[c * N + m * T + t] = add_rounded<kReduce>(s_lo, o_re[c][m], scale);
-          dst[c * N + m * T + t + M] = add_rounded<kReduce>(s_hi, o_im[c][m], scale);
+          EP_NT_STORE(add_rounded<kReduce>(s_lo, o_re[c][m], scale), &dst[c * N + m * T + t]);
+          EP_NT_STORE(add_rounded<kReduce>(s_hi, o_im[c][m], scale), &dst[c * N + m * T + t + M]);
         }
     }
     return;
@@ -1026,13 +1054,19 @@ __global__ __launch_bounds__(F::THREADS, 2) void external_product_kernel(const d
   for (size_t u = blockIdx.x; u < (size_t)count; u += gridDim.x) {
     const d2 *__restrict__ bkrow = bkrow0 + u * key_stride;
     double o_re[2][8], o_im[2][8];
+#ifndef MOSFHET_EP_FIRST
 #pragma unroll
     for (int c = 0; c < 2; c++)
 #pragma unroll
       for (int m = 0; m < 8; m++) { o_re[c][m] = 0.0; o_im[c][m] = 0.0; }
+#endif
     pack();              // component a (requested during the previous unit)
     request(u, 1);       // component b: in flight under the rows of component a
+#ifdef MOSFHET_EP_FIRST
+    cmux_rows<F, L, BG, EP_ONE_K, true>(w_lo, w_hi, ext, 0, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
+#else
     cmux_rows<F, L, BG, EP_ONE_K>(w_lo, w_hi, ext, 0, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
+#endif
     pack();
     if (u + gridDim.x < (size_t)count) request(u + gridDim.x, 0);   // the next unit's component a: under the rows of b, the inverse pair and the stores
     cmux_rows<F, L, BG, EP_ONE_K>(w_lo, w_hi, ext, 1, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
@@ -1052,8 +1086,8 @@ __global__ __launch_bounds__(F::THREADS, 2) void external_product_kernel(const d
 #pragma unroll
       for (int m = 0; m < 8; m++) {   // (out may alias in0: each lane reads its words of in0 before it writes them)
         const uint64_t s_lo = CMUX ? c0[c * N + m * T + t] : 0, s_hi = CMUX ? c0[c * N + m * T + t + M] : 0;
-        dst[c * N + m * T + t] = add_rounded<kReduce>(s_lo, o_re[c][m], scale);
-        dst[c * N + m * T + t + M] = add_rounded<kReduce>(s_hi, o_im[c][m], scale);
+        EP_NT_STORE(add_rounded<kReduce>(s_lo, o_re[c][m], scale), &dst[c * N + m * T + t]);
+        EP_NT_STORE(add_rounded<kReduce>(s_hi, o_im[c][m], scale), &dst[c * N + m * T + t + M]);
       }
   }
 }

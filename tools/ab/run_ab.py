@@ -17,12 +17,12 @@ OUT = os.path.join(HERE, "_build")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unused-value", "-Wno-comment"]
 
 
-def build(specs):
+def build(specs, src="pbs_ab.hip", prefix="ab_"):
     os.makedirs(OUT, exist_ok=True)
     procs = []
     for spec in specs:
         name, _, flags = spec.partition(":")
-        cmd = ["hipcc"] + FLAGS + [f for f in flags.split(",") if f] + [os.path.join(HERE, "pbs_ab.hip"), "-o", os.path.join(OUT, "ab_%s.so" % name)]
+        cmd = ["hipcc"] + FLAGS + [f for f in flags.split(",") if f] + [os.path.join(HERE, src), "-o", os.path.join(OUT, "%s%s.so" % (prefix, name))]
         procs.append((name, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for name, p in procs:
         out = p.communicate()[0]
@@ -82,8 +82,53 @@ def run(pset, B, rounds):
         print("%-28s min %.3f  med %.3f ms  %s  bit-exact-vs-production=%s" % (name, min(t), sorted(t)[len(t) // 2], ("(%+.1f %% vs base)" % (100 * (min(t) / base - 1))) if base else "", exact[name]))
 
 
+def run_ep(B, rounds, grids):
+    """external-product variants (tools/ab/_build/ep_*.so) at SET_1: B units against one key entry, each at the grid sizes given"""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch
+    import mosfhet_amd as ma
+    from mosfhet_amd import host, engine
+    P = dict(ma.PARAMS_SET1)
+    host.seed(0x4D4F5346)
+    lk = host.LweKey(4, P["lwe_sigma"])
+    rk = host.RlweKey(P["N"], 1, P["rlwe_sigma"])
+    eng = ma.Engine(0)
+    bsk = eng.load_bootstrap_key(host.gen_bootstrap_key(rk, lk, P["l"], P["Bg_bit"]), 1, P["l"], P["Bg_bit"])
+    g = torch.Generator(device="cpu").manual_seed(1)
+    d_in = torch.randint(-2 ** 63, 2 ** 63 - 1, (B, 2, P["N"]), dtype=torch.int64, generator=g).to(eng.device)
+    want = eng.external_product(bsk, 1, d_in)
+    L = engine.lib()
+    L.mosfhet_hip_bsk_device_dft.restype = C.c_void_p
+    d_row = L.mosfhet_hip_bsk_device_dft(bsk.h) + 1 * (2 * P["l"] * 2 * P["N"]) * 8
+    tw = np.zeros(2 * (P["N"] // 2 - 1), dtype=np.float64)
+    L.mosfhet_hip_twiddles(P["N"], tw.ctypes.data_as(C.c_void_p))
+    d_tw = torch.from_numpy(tw).to(eng.device)
+    libs = {os.path.basename(p)[3:-3]: C.CDLL(p) for p in sorted(glob.glob(os.path.join(OUT, "ep_*.so")))}
+    out = eng.empty(B, 2, P["N"])
+    res = {}
+    for r in range(rounds):
+        for name, lib in libs.items():
+            for grid in grids:
+                ms = C.c_float()
+                out.zero_()
+                rc = lib.ab_ep(C.c_void_p(d_row), C.c_void_p(d_tw.data_ptr()), C.c_void_p(d_in.data_ptr()), C.c_void_p(out.data_ptr()), B, grid, 5, C.byref(ms))
+                assert rc == 0, (name, rc)
+                ok = bool((out == want).all())
+                res.setdefault((name, grid), []).append((ms.value, ok))
+    for (name, grid), v in res.items():
+        t = [x[0] for x in v]
+        print("%-20s grid %5d  min %.3f  med %.3f ms  -> %.0f GB/s (%.1f %% of 8 TB/s)  bit-exact=%s" % (name, grid, min(t), sorted(t)[len(t) // 2], B * 32768 / min(t) / 1e6,
+                                                                                                       B * 32768 / min(t) / 1e6 / 80, all(x[1] for x in v)))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "build":
         build(sys.argv[2:])
+    elif sys.argv[1] == "build_ep":
+        build(sys.argv[2:], "ep_ab.hip", "ep_")
+    elif sys.argv[1] == "run_ep":
+        run_ep(int(sys.argv[2]) if len(sys.argv) > 2 else 65536, int(sys.argv[3]) if len(sys.argv) > 3 else 5,
+               [int(x) for x in (sys.argv[4] if len(sys.argv) > 4 else "2048").split(",")])
     else:
         run(sys.argv[2] if len(sys.argv) > 2 else "set1", int(sys.argv[3]) if len(sys.argv) > 3 else 4096, int(sys.argv[4]) if len(sys.argv) > 4 else 5)
