@@ -236,7 +236,8 @@ __device__ __forceinline__ void cmux_digits_plan(typename Digits<L, BG>::word_t 
 // ONE_K: one register buffer for the key row (component 1 is loaded when component 0 has been consumed) -- for callers that need the 32 registers
 // FIRST: this call holds the first row of the product (component 0, level 0): its products INITIALISE the accumulators (x * y where the chain would
 // compute fma(x, y, 0.0): the same number), so the accumulator registers are free until then
-template <class F, int L, int BG, bool ONE_K = false, bool FIRST = false>
+// KEY_LDS: the key rows are in LDS (external_product_ldskey_kernel): no early fetch into registers, each component's slots are read where they are used
+template <class F, int L, int BG, bool ONE_K = false, bool FIRST = false, bool KEY_LDS = false>
 __device__ __forceinline__ void cmux_rows(const typename Digits<L, BG>::word_t (&w_lo)[8], const typename Digits<L, BG>::word_t (&w_hi)[8],
                                           const uint32_t (&ext)[8], int p, double (&o_re)[2][8], double (&o_im)[2][8], d2 *xch,
                                           const F &fft, const d2 *__restrict__ bkrow, int Bg_bit, int t) {
@@ -246,7 +247,7 @@ __device__ __forceinline__ void cmux_rows(const typename Digits<L, BG>::word_t (
 #ifdef MOSFHET_ROWS_ROLLED
   constexpr int kUnroll = 1;
 #else
-  constexpr int kUnroll = L <= 2 ? L : 1;
+  constexpr int kUnroll = (L <= 2 && !KEY_LDS) ? L : 1;   // KEY_LDS: rolled -- unrolled, the LDS reads of both rows are hoisted and spill
 #endif
 #pragma unroll kUnroll
   for (int lv = 0; lv < L; lv++) {
@@ -258,6 +259,21 @@ __device__ __forceinline__ void cmux_rows(const typename Digits<L, BG>::word_t (
       im[m] = D::digit(w_hi[m], ext[m], 1, lv, Bg_bit);
     }
     fft.forward_head(re, im, xch, t);
+    if constexpr (KEY_LDS) {
+      fft.forward_tail(re, im);
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        d2 kk[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) kk[m] = row[c * M + m * T + t];
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          o_re[c][m] = __builtin_fma(-im[m], kk[m].y, __builtin_fma(re[m], kk[m].x, o_re[c][m]));
+          o_im[c][m] = __builtin_fma(im[m], kk[m].x, __builtin_fma(re[m], kk[m].y, o_im[c][m]));
+        }
+      }
+      continue;
+    }
     d2 k0[8], k1[8];
 #pragma unroll
     for (int m = 0; m < 8; m++) k0[m] = row[m * T + t];
@@ -826,8 +842,10 @@ __device__ __forceinline__ void ks_rows_rt(const uint64_t (&dd_lo)[8], const uin
 // mode 1: out = trlwe_priv_keyswitch_2(in, {ks0, ks1})         = -as(in.a; ks0) - as(-in.b; ks1)
 // mode 2: out = base - trlwe_keyswitch(in, ks0)                = base - (0, in.b) + as(in.a; ks0)   (relinearisation step of
 //         trlwe_tensor_prod_FFT, src/trlwe.c:758-761)
+// One wavefront per SIMD (launch bound 1): the two result pairs, the digit words and the product accumulators are ~330 live registers; with room for
+// the overflow in the accumulation registers there is no scratch (two per SIMD: 388 bytes of it).  The kernel is 0.16 ms of a 38 ms circuit bootstrap.
 template <class F>
-__global__ __launch_bounds__(F::THREADS, 2) void trlwe_fft_keyswitch_kernel(const d2 *__restrict__ ks0, const d2 *__restrict__ ks1,
+__global__ __launch_bounds__(F::THREADS, 1) void trlwe_fft_keyswitch_kernel(const d2 *__restrict__ ks0, const d2 *__restrict__ ks1,
                                                                           const d2 *__restrict__ tw, const uint64_t *__restrict__ in,
                                                                           size_t in_stride, uint64_t *__restrict__ out, size_t out_stride,
                                                                           int t, int base_bit, int mode,
@@ -1085,6 +1103,90 @@ __global__ __launch_bounds__(F::THREADS, 2) void external_product_kernel(const d
     for (int c = 0; c < 2; c++)
 #pragma unroll
       for (int m = 0; m < 8; m++) {   // (out may alias in0: each lane reads its words of in0 before it writes them)
+        const uint64_t s_lo = CMUX ? c0[c * N + m * T + t] : 0, s_hi = CMUX ? c0[c * N + m * T + t + M] : 0;
+        EP_NT_STORE(add_rounded<kReduce>(s_lo, o_re[c][m], scale), &dst[c * N + m * T + t]);
+        EP_NT_STORE(add_rounded<kReduce>(s_hi, o_im[c][m], scale), &dst[c * N + m * T + t + M]);
+      }
+  }
+}
+
+// The same at N = 1024 when the whole batch shares ONE key entry (key_stride = 0): eight teams (wavefronts) per workgroup, one workgroup per CU, and
+// the 2 l rows of the entry (64 KiB at l = 2) staged ONCE into LDS next to the teams' transpose buffers (8 x 9 KiB) -- the key rows then cost
+// ds_read_b128 instead of 64 KiB of L2 traffic per unit behind the HBM loads in the wavefront's in-order memory queue.  l <= 2.
+template <int L, int BG, bool CMUX>
+__global__ __launch_bounds__(512, 2) void external_product_ldskey_kernel(const d2 *__restrict__ bkrow0, const d2 *__restrict__ tw, const uint64_t *__restrict__ in,
+                                                                       uint64_t *__restrict__ out, int Bg_bit_rt, int count, size_t in_stride,
+                                                                       const uint64_t *__restrict__ in0, d2 *__restrict__ out_dft) {
+  using F = Fft1024;
+  constexpr int N = F::N, M = F::M, T = 64, TEAMS = 8;
+  using D = Digits<L, BG>;
+  constexpr bool kReduce = !(BG > 0 && kCeilLog2<2 * L>::value + (F::LOGM + 1) + BG - 1 + 63 < 83);
+  __shared__ __attribute__((aligned(16))) d2 key[2 * L * 2 * M];
+  __shared__ __attribute__((aligned(16))) d2 xch_all[TEAMS][F::XCH_SLOTS];
+  const int w = threadIdx.x >> 6, t = threadIdx.x & 63;
+  d2 *xch = xch_all[w];
+  for (int i = threadIdx.x; i < 2 * L * 2 * M; i += 64 * TEAMS) key[i] = bkrow0[i];
+  const int Bg_bit = BG > 0 ? BG : Bg_bit_rt;
+  F fft;
+  fft.init(tw, t);
+  uint64_t off = 1ull << (63 - L * Bg_bit);
+#pragma unroll
+  for (int i = 0; i < L; i++) off += 1ull << (63 - i * Bg_bit);
+  const RoundCtx scale(0x1p-64 / (double)M);
+  __syncthreads();
+  const size_t first = (size_t)blockIdx.x * TEAMS + w, stride = (size_t)gridDim.x * TEAMS;
+
+  uint64_t raw_lo[8], raw_hi[8];
+  auto request = [&](size_t u, int q) {
+    const uint64_t *ct = in + u * in_stride + (size_t)q * N;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      raw_lo[m] = EP_NT_LOAD(&ct[m * T + t]);
+      raw_hi[m] = EP_NT_LOAD(&ct[M + m * T + t]);
+    }
+    if constexpr (CMUX) {
+      const uint64_t *c0 = in0 + u * 2 * N + (size_t)q * N;
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        raw_lo[m] -= c0[m * T + t];
+        raw_hi[m] -= c0[M + m * T + t];
+      }
+    }
+  };
+  typename D::word_t w_lo[8], w_hi[8];
+  uint32_t ext[8];
+  auto pack = [&]() {
+#pragma unroll
+    for (int m = 0; m < 8; m++) D::pack(w_lo[m], w_hi[m], ext[m], raw_lo[m] + off, raw_hi[m] + off);
+  };
+  if (first < (size_t)count) request(first, 0);
+  for (size_t u = first; u < (size_t)count; u += stride) {
+    double o_re[2][8], o_im[2][8];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int m = 0; m < 8; m++) { o_re[c][m] = 0.0; o_im[c][m] = 0.0; }
+    pack();
+    request(u, 1);
+    cmux_rows<F, L, BG, false, false, true>(w_lo, w_hi, ext, 0, o_re, o_im, xch, fft, key, Bg_bit, t);
+    pack();
+    if (u + stride < (size_t)count) request(u + stride, 0);
+    cmux_rows<F, L, BG, false, false, true>(w_lo, w_hi, ext, 1, o_re, o_im, xch, fft, key, Bg_bit, t);
+    if (out_dft) {
+      d2 *dd = out_dft + u * 2 * M;
+#pragma unroll
+      for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int m = 0; m < 8; m++) dd[c * M + m * T + t] = d2{o_re[c][m], o_im[c][m]};
+      continue;
+    }
+    fft.inverse2(o_re[0], o_im[0], o_re[1], o_im[1], xch, t);
+    uint64_t *dst = out + u * 2 * N;
+    const uint64_t *c0 = CMUX ? in0 + u * 2 * N : nullptr;
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
         const uint64_t s_lo = CMUX ? c0[c * N + m * T + t] : 0, s_hi = CMUX ? c0[c * N + m * T + t + M] : 0;
         EP_NT_STORE(add_rounded<kReduce>(s_lo, o_re[c][m], scale), &dst[c * N + m * T + t]);
         EP_NT_STORE(add_rounded<kReduce>(s_hi, o_im[c][m], scale), &dst[c * N + m * T + t + M]);

@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <memory>
+#include <type_traits>
 #include <vector>
 
 #include "bootstrap_kernels.h"
@@ -328,6 +329,24 @@ template <class F>
 static void launch_external_product(int l, int Bg_bit, hipStream_t s, const d2 *row, const d2 *tw, const uint64_t *d_in, uint64_t *d_out, int count, size_t key_stride,
                                     size_t in_stride, const uint64_t *d_in0, d2 *d_out_dft) {
   const int cap = resident_teams(F::THREADS);
+  if constexpr (std::is_same<F, Fft1024>::value) {
+    // one key entry for the whole batch at N = 1024, l <= 2: the entry fits LDS next to eight teams' transpose buffers (external_product_ldskey_kernel)
+    if (key_stride == 0 && l <= 2 && count >= 64) {
+      const int wgs = (count + 7) / 8, cus = cap / 8;
+      const dim3 grid((unsigned)(wgs < cus ? wgs : cus)), block(512);
+#define EPL_GO(LL, BB)                                                                                                                                    \
+  do {                                                                                                                                                    \
+    if (d_in0) hipLaunchKernelGGL((external_product_ldskey_kernel<LL, BB, true>), grid, block, 0, s, row, tw, d_in, d_out, Bg_bit, count, in_stride, d_in0, d_out_dft);   \
+    else hipLaunchKernelGGL((external_product_ldskey_kernel<LL, BB, false>), grid, block, 0, s, row, tw, d_in, d_out, Bg_bit, count, in_stride, d_in0, d_out_dft);      \
+  } while (0)
+      if (l == 2 && Bg_bit == 8) EPL_GO(2, 8);
+      else if (l == 1 && Bg_bit == 23) EPL_GO(1, 23);
+      else if (l == 1) EPL_GO(1, 0);
+      else EPL_GO(2, 0);
+#undef EPL_GO
+      return;
+    }
+  }
   const dim3 grid((unsigned)(count < cap ? count : cap)), block(F::THREADS);
 #define EP_GO(LL, BB)                                                                                                                                    \
   do {                                                                                                                                                   \

@@ -107,15 +107,17 @@ def run_ep(B, rounds, grids):
     libs = {os.path.basename(p)[3:-3]: C.CDLL(p) for p in sorted(glob.glob(os.path.join(OUT, "ep_*.so")))}
     out = eng.empty(B, 2, P["N"])
     res = {}
+    reps = int(os.environ.get("AB_REPS", "5"))
     for r in range(rounds):
         for name, lib in libs.items():
-            for grid in grids:
-                ms = C.c_float()
-                out.zero_()
-                rc = lib.ab_ep(C.c_void_p(d_row), C.c_void_p(d_tw.data_ptr()), C.c_void_p(d_in.data_ptr()), C.c_void_p(out.data_ptr()), B, grid, 5, C.byref(ms))
-                assert rc == 0, (name, rc)
-                ok = bool((out == want).all())
-                res.setdefault((name, grid), []).append((ms.value, ok))
+            for fn, gr in (("ab_ep", grids), ("ab_epl", [256, 512])):
+                for grid in gr:
+                    ms = C.c_float()
+                    out.zero_()
+                    rc = getattr(lib, fn)(C.c_void_p(d_row), C.c_void_p(d_tw.data_ptr()), C.c_void_p(d_in.data_ptr()), C.c_void_p(out.data_ptr()), B, grid, reps, C.byref(ms))
+                    assert rc == 0, (name, fn, rc)
+                    ok = bool((out == want).all())
+                    res.setdefault((name + ":" + fn, grid), []).append((ms.value, ok))
     for (name, grid), v in res.items():
         t = [x[0] for x in v]
         print("%-20s grid %5d  min %.3f  med %.3f ms  -> %.0f GB/s (%.1f %% of 8 TB/s)  bit-exact=%s" % (name, grid, min(t), sorted(t)[len(t) // 2], B * 32768 / min(t) / 1e6,
