@@ -227,20 +227,25 @@ def main():
     achieved_tflops = flops_per_launch / (kernel_ms * 1e-3) / 1e12
     bytes_per_launch = algorithmic_bytes_per_bootstrap(P) * B
 
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "latest_traffic.json")
-    if B == 4096 and os.path.exists(tfile):
-        # memory-side bytes per launch from the committed rocprofv3 PMC passes (tools/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate
-        # passes, gfx950 correction applied by tools/make_traffic_json.py) -- only if they were taken from the library that is running now
+    def measured_traffic(name, units):
+        """memory-side bytes per launch from the committed rocprofv3 PMC passes (tools/profile_r02.sh: FETCH_SIZE and WRITE_SIZE in separate
+        passes, gfx950 correction applied by tools/make_traffic_json.py) -- only if they were taken from the library that is running now and at
+        this launch size; otherwise null"""
+        tfile = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(tfile):
+            return None
         with open(tfile) as f:
             t = json.load(f)
         try:
             with open(build.STAMP) as f:
                 srchash = f.read().strip()
         except OSError:
-            srchash = None
-        if srchash and t.get("srchash") == srchash:
-            traffic = t.get("traffic_bytes_per_launch")
+            return None
+        if t.get("srchash") != srchash or t.get("units_per_launch", units) != units:
+            return None
+        return t.get("traffic_bytes_per_launch")
+
+    traffic = measured_traffic("latest_traffic.json", 4096) if B == 4096 else None
 
     # the external-product kernel on its own (BASELINE.json's HBM target): B_ep TRLWE samples against ONE key entry, inputs and outputs in HBM
     ep = None
@@ -267,7 +272,7 @@ def main():
         ep_ms = groups[len(groups) // 2]
         ep_bytes = B_ep * 2 * (2 * N_ * 8) + (2 * l_) * 2 * N_ * 8        # TRLWE in + TRLWE out per unit, the key entry once
         ep_gbs = ep_bytes / (ep_ms * 1e-3) / 1e9
-        ep = {"bound": "hbm", "achieved": ep_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ep_gbs / HBM_PEAK_GBS, "traffic": None,
+        ep = {"bound": "hbm", "achieved": ep_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ep_gbs / HBM_PEAK_GBS, "traffic": measured_traffic("latest_traffic_ep.json", B_ep),
               "kernel": "mosfhet::external_product_ldskey_kernel<2, 8, false>", "kernel_ms": ep_ms, "kernel_ms_min_max": [groups[0], groups[-1]], "units_per_launch": B_ep,
               "algorithmic_bytes_per_launch": ep_bytes, "external_products_per_s": B_ep / (ep_ms * 1e-3),
               "workload": "%d x trgsw_mul_trlwe_DFT + trlwe_from_DFT at SET_1 against one TRGSW_DFT (src/trgsw.c:385-423)" % B_ep}

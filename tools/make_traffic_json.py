@@ -11,6 +11,7 @@ import re
 import sys
 
 summary, out, kernel = sys.argv[1], sys.argv[2], sys.argv[3]
+units = int(sys.argv[4]) if len(sys.argv) > 4 else None   # ciphertexts (units) per launch of the profiled run
 vals = {}
 for line in open(summary):
     m = re.search(r"(\S+)\s+per-dispatch mean=([0-9.e+]+)", line)
@@ -21,7 +22,7 @@ stamp = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 srchash = open(stamp).read().strip() if os.path.exists(stamp) else None   # bench.py reports `traffic` only for the build it was measured on
 fetch = 2.0 * vals["FETCH_SIZE"] * 1024
 write = vals["WRITE_SIZE"] * 1024
-json.dump({"kernel": kernel, "source": summary, "srchash": srchash, "fetch_bytes_per_launch_corrected": fetch, "write_bytes_per_launch": write,
+json.dump({"kernel": kernel, "source": summary, "srchash": srchash, **({"units_per_launch": units} if units else {}), "fetch_bytes_per_launch_corrected": fetch, "write_bytes_per_launch": write,
            "traffic_bytes_per_launch": fetch + write, "FETCH_SIZE_KiB_raw": vals["FETCH_SIZE"], "WRITE_SIZE_KiB_raw": vals["WRITE_SIZE"],
            "TCC_HIT_sum": vals.get("TCC_HIT_sum"), "TCC_MISS_sum": vals.get("TCC_MISS_sum"),
            "note": "fabric-side L2 counters (Infinity-Cache hits included); FETCH_SIZE doubled per the gfx950 correction"},
