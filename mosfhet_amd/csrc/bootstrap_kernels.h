@@ -181,55 +181,6 @@ __device__ __forceinline__ void cmux_digits(typename Digits<L, BG>::word_t (&w_l
   }
 }
 
-#ifdef MOSFHET_EXP_PLAN
-// ---- rotation with wave-uniform bookkeeping (one wavefront per ciphertext: F = Fft1024) ----
-// Lane t owns coefficients j = t + 64 m', m' < 16.  With abar = 64 q + r the source index of (X^abar p)[j] in the antiperiodic extension of p
-// (period 2N, p[i + N] = -p[i]) is 64 row + u with  u = t - r, row = (m' - q) mod 32  for lanes t >= r  and  u = t - r + 64, row = (m' - q - 1) mod 32
-// for the others: the physical row is row mod 16, the sign is bit 4 of row.  Everything that depends on m' and abar only -- the row offsets and, per
-// m', WHICH LANES see a negated value -- is scalar arithmetic; a lane's address is its own base plus a scalar.  The array carries a copy of its last
-// row (coefficients N - 64 .. N - 1) in the 64 words in front of it, so that "one row lower" needs no wrap-around for the lanes t < r.
-struct RotPlan {
-  uint64_t G;            // lanes with t >= r
-  uint32_t negA, negB;   // bit m': coefficient m' comes out negated, for the lanes in G / the others
-  int qa;                // (-q) mod 32
-  int base8;             // per lane: byte offset of this lane's source in row 0 (lanes t < r: one row lower)
-};
-__device__ __forceinline__ RotPlan make_rot_plan(int abar, int t) {
-  RotPlan pl;
-  const int r = abar & 63, q = abar >> 6;
-  pl.qa = (32 - q) & 31;
-  const int qb = (pl.qa + 31) & 31;
-  pl.G = ~0ull << r;
-  pl.negA = ((pl.qa & 16) ? 0xffffu : 0u) ^ ((0xffffu << (16 - (pl.qa & 15))) & 0xffffu);
-  pl.negB = ((qb & 16) ? 0xffffu : 0u) ^ ((0xffffu << (16 - (qb & 15))) & 0xffffu);
-  pl.base8 = (((t - r) & 63) << 3) - (t < r ? 512 : 0);
-  return pl;
-}
-__device__ __forceinline__ uint32_t lane_select(uint32_t if_clear, uint32_t if_set, uint64_t lane_mask) {
-  uint32_t r;
-  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(lane_mask));
-  return r;
-}
-// digit words of (X^abar - 1) p + off for this lane's 16 coefficients; `arr` = the component in LDS (64 mirror words, then N words)
-template <int L, int BG>
-__device__ __forceinline__ void cmux_digits_plan(typename Digits<L, BG>::word_t (&w_lo)[8], typename Digits<L, BG>::word_t (&w_hi)[8], uint32_t (&ext)[8],
-                                                 const uint64_t *arr, const RotPlan &pl, uint64_t off, int t) {
-  using D = Digits<L, BG>;
-  const char *row0 = reinterpret_cast<const char *>(arr + 64) + pl.base8;
-  uint64_t dd[16];
-#pragma unroll
-  for (int mp = 0; mp < 16; mp++) {
-    const int soff = ((pl.qa + mp) & 15) << 9;
-    const uint64_t nm = (((pl.negA >> mp) & 1u) ? pl.G : 0ull) | (((pl.negB >> mp) & 1u) ? ~pl.G : 0ull);
-    const uint64_t v = *reinterpret_cast<const uint64_t *>(row0 + soff);
-    const uint64_t nv = 0 - v;
-    const uint64_t x = ((uint64_t)lane_select((uint32_t)(v >> 32), (uint32_t)(nv >> 32), nm) << 32) | lane_select((uint32_t)v, (uint32_t)nv, nm);
-    dd[mp] = x - arr[64 + mp * 64 + t] + off;
-  }
-#pragma unroll
-  for (int m = 0; m < 8; m++) D::pack(w_lo[m], w_hi[m], ext[m], dd[m], dd[m + 8]);
-}
-#endif
 
 // The L rows of component p: digits -> forward transform -> MAC against key rows p*L .. p*L+L-1.
 // The key row's component 0 is loaded under the last transform pass, component 1 under the MAC of component 0.
@@ -335,13 +286,7 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
   // reduction mod 1 in front (add_rounded); that holds for SET_1's 2 x 2^8 gadget at N = 1024 (2^82) and is decided at compile time.
   constexpr bool kReduce = !(BG > 0 && kCeilLog2<2 * L>::value + (F::LOGM + 1) + BG - 1 + 63 < 83);
   __shared__ __attribute__((aligned(16))) d2 xch[F::XCH_SLOTS];
-#ifdef MOSFHET_EXP_PLAN
-  constexpr int kMirror = std::is_same<F, Fft1024>::value ? 64 : 0;   // copy of the component's last 64 coefficients in front of it (cmux_digits_plan)
-#else
-  constexpr int kMirror = 0;
-#endif
-  __shared__ __attribute__((aligned(16))) uint64_t acc1_store[N + kMirror];
-  uint64_t *const acc1 = acc1_store + kMirror;
+  __shared__ __attribute__((aligned(16))) uint64_t acc1[N];
   const int t = threadIdx.x;
   const size_t b = blockIdx.x;
   const uint64_t *__restrict__ ct = p.in + (p.rows > 1 ? b / (size_t)p.rows : b) * (size_t)(p.n + 1);
@@ -360,7 +305,6 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
       acc1[m * T + t] = src[N + m * T + t];
       acc1[M + m * T + t] = src[N + M + m * T + t];
     }
-    if (kMirror) acc1_store[t] = src[N + M + 7 * T + t];
   } else {
     // src/bootstrap.c:194-195: acc = tv * X^(2N - bbar), gathered straight from global memory
     const uint64_t *__restrict__ tv = p.rows > 1 ? p.tv + (b % (size_t)p.rows) * (size_t)(2 * N) : p.tv + b * (size_t)p.tv_stride;
@@ -375,7 +319,6 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
       acc1[m * T + t] = rot_coeff<N>(tv + N, m * T + t, a_lo, flip);
       acc1[M + m * T + t] = rot_coeff<N>(tv + N, M + m * T + t, a_lo, flip);
     }
-    if (kMirror) acc1_store[t] = rot_coeff<N>(tv + N, M + 7 * T + t, a_lo, flip);
   }
   F::sync();
 
@@ -396,29 +339,6 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
     for (int c = 0; c < 2; c++)
 #pragma unroll
       for (int m = 0; m < 8; m++) { o_re[c][m] = 0.0; o_im[c][m] = 0.0; }
-#ifdef MOSFHET_EXP_PLAN
-    if constexpr (std::is_same<F, Fft1024>::value) {
-      const RotPlan pl = make_rot_plan(abar, t);
-#pragma unroll 1
-      for (int q = 0; q < 2; q++) {
-        typename Digits<L, BG>::word_t w_lo[8], w_hi[8];
-        uint32_t ext[8];
-        uint64_t *st = reinterpret_cast<uint64_t *>(xch);
-        if (q == 0) {   // component a lives in registers: stage it (with the mirror of its last row), then it is read like component b
-          st[t] = ah[7];
-#pragma unroll
-          for (int m = 0; m < 8; m++) {
-            st[64 + m * T + t] = al[m];
-            st[64 + M + m * T + t] = ah[m];
-          }
-          F::sync();
-        }
-        cmux_digits_plan<L, BG>(w_lo, w_hi, ext, q ? acc1_store : st, pl, off, t);
-        if (q == 0) F::sync();
-        cmux_rows<F, L, BG>(w_lo, w_hi, ext, q, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
-      }
-    } else
-#endif
     {
       constexpr int kUnrollQ = L == 1 ? 2 : 1;
 #pragma unroll kUnrollQ
@@ -438,9 +358,7 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
 #pragma unroll
     for (int m = 0; m < 8; m++) {
       acc1[m * T + t] = add_rounded<kReduce>(acc1[m * T + t], o_re[1][m], scale);
-      const uint64_t upd = add_rounded<kReduce>(acc1[M + m * T + t], o_im[1][m], scale);
-      acc1[M + m * T + t] = upd;
-      if (kMirror && m == 7) acc1_store[t] = upd;
+      acc1[M + m * T + t] = add_rounded<kReduce>(acc1[M + m * T + t], o_im[1][m], scale);
     }
     F::sync();
   }
