@@ -495,6 +495,53 @@ class Engine:
         _check(lib().mosfhet_hip_external_product_batch(self.h, bsk.h, key_index, _ptr(out), _ptr(ct), count, self._stream()))
         return out
 
+    # ---- DFT-level objects of the legacy API (include/mosfhet.h of the reference: TRGSW_DFT, TRLWE_DFT stay on the device in slot order) ----
+    def trgsw_to_dft(self, trgsw):
+        """trgsw_to_DFT (src/trgsw.c:359-366) for a batch: [count][(k+1)l][k+1][N] torus words -> the same shape in doubles (N/2 complex per polynomial)"""
+        shape = tuple(trgsw.shape)
+        return self.torus_to_dft(trgsw.reshape(-1, shape[-1])).reshape(shape)
+
+    def external_product_dft(self, trgsw_dft, ct, l, Bg_bit):
+        """trgsw_mul_trlwe_DFT (src/trgsw.c:385-423), result left in the DFT domain.  trgsw_dft: [2l][2][N] doubles (one TRGSW for the batch)
+        or [count][2l][2][N] (one per unit); ct: [count][2][N]"""
+        count, two, N = ct.shape
+        per_unit = trgsw_dft.dim() == 4
+        assert (trgsw_dft.shape[0] == count) if per_unit else True
+        out = self.torch.empty(count, 2, N, dtype=self.torch.float64, device=self.device)
+        stride = C.c_size_t(2 * l * 2 * N if per_unit else 0)
+        _check(lib().mosfhet_hip_external_product_dft_batch(self.h, _ptr(trgsw_dft), stride, _ptr(out), _ptr(ct), N, l, Bg_bit, count, self._stream()))
+        return out
+
+    def bootstrap_key_view(self, trgsw_dft, k, l, Bg_bit):
+        """non-owning key handle over n TRGSW_DFT entries already on the device ([n][(k+1)l][k+1][N] doubles): blind_rotate(tv, a, TRGSW_DFT *s, size)"""
+        n, N = trgsw_dft.shape[0], trgsw_dft.shape[-1]
+        h = C.c_void_p()
+        _check(lib().mosfhet_hip_bsk_view_create(self.h, C.byref(h), _ptr(trgsw_dft), n, k, N, l, Bg_bit))
+        key = BootstrapKey(self, h, n, k, N, l, Bg_bit)
+        key._keep = trgsw_dft     # the view borrows the tensor's memory
+        return key
+
+    def public_mux_dft(self, p0, p1, sel_dft, Bg_bit, out=None):
+        """public_mux (src/bootstrap.c:369-389) with the selector rows already in the DFT domain: sel_dft [count][l][2][N] doubles"""
+        count, l, two, N = sel_dft.shape
+        if out is None:
+            out = self.empty(count, 2, N)
+        _check(lib().mosfhet_hip_public_mux_dft_batch(self.h, _ptr(out), _ptr(p0), _ptr(p1), _ptr(sel_dft), N, l, Bg_bit, count, self._stream()))
+        return out
+
+    def blind_rotate_ga(self, bsk, gak, acc, ct):
+        """blind_rotate_ga (src/bootstrap_ga.c:35-60) in place on acc [count][2][N]"""
+        _check(lib().mosfhet_hip_blind_rotate_ga_batch(self.h, bsk.h, gak.h, _ptr(acc), _ptr(ct), ct.shape[0], self._stream()))
+        return acc
+
+    def trlwe_eval_automorphism_entry(self, gak, entry, ct, gen, out=None):
+        """trlwe_eval_automorphism (src/trlwe.c:775-781) with the key-set entry the caller names"""
+        count = ct.shape[0]
+        if out is None:
+            out = self.empty(count, 2, gak.N)
+        _check(lib().mosfhet_hip_trlwe_eval_automorphism_entry_batch(self.h, gak.h, int(entry), _ptr(out), _ptr(ct), int(gen), count, self._stream()))
+        return out
+
     # ---- polynomial level ----
     def torus_to_dft(self, polys):
         count, N = polys.shape

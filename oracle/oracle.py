@@ -326,6 +326,13 @@ def ks_to_dft(ks):
     return out.reshape(ks.shape)
 
 
+def blind_rotate_ga(acc, a, bk_dft, ak_dft, l, Bg_bit):
+    """src/bootstrap_ga.c:39-60 on a caller-supplied accumulator; a: the n mask words"""
+    out = acc.copy()
+    lib().orc_blind_rotate_ga(plan(acc.shape[1]).h, _u(out), _u(a), _d(bk_dft), _d(ak_dft), C.c_int(a.size), l, Bg_bit)
+    return out
+
+
 def functional_bootstrap_ga(tv, c, bk_dft, ak_dft, l, Bg_bit, torus_base, extract=True):
     k1, N = tv.shape
     n = c.size - 1
