@@ -404,8 +404,9 @@ static int launch_pbs_f(int l, int Bg_bit, const PbsParams &p, int count, hipStr
   // test/tests.c:37-62,967); anything else runs the run-time-Bg variant.
   if (l == 2 && Bg_bit == 8) launch_pbs<F, 2, 8>(p, count, s);
   else if (l == 4 && Bg_bit == 9) launch_pbs<F, 4, 9>(p, count, s);
-  else if (l == 1 && Bg_bit == 23) launch_pbs<F, 1, 23>(p, count, s);
-  else if (l == 1) launch_pbs<F, 1, 0>(p, count, s);
+  // l = 1: the transform grouping with a full last pass (negacyclic_fft.h, Fft2048T: same results, same key layout; +2 % at SET_2, +6 % at SET_3)
+  else if (l == 1 && Bg_bit == 23) launch_pbs<typename WideTail<F>::type, 1, 23>(p, count, s);
+  else if (l == 1) launch_pbs<typename WideTail<F>::type, 1, 0>(p, count, s);
   else if (l == 2) launch_pbs<F, 2, 0>(p, count, s);
   else if (l == 3) launch_pbs<F, 3, 0>(p, count, s);
   else if (l == 4) launch_pbs<F, 4, 0>(p, count, s);

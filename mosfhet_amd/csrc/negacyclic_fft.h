@@ -97,6 +97,30 @@ __device__ __forceinline__ void pass_inv(double (&re)[8], double (&im)[8], const
   for (int m = 0; m < 4; m++) bf_inv(re[m], im[m], re[m + 4], im[m + 4], w.w0r, w.w0i);
 }
 
+// the first one / two levels of a three-level pass alone (N = 2048 / 4096 with the short pass in front of the last full one, see Fft2048T)
+__device__ __forceinline__ void pass_fwd_top1(double (&re)[8], double (&im)[8], const PassTw &w) {
+#pragma unroll
+  for (int m = 0; m < 4; m++) bf_fwd(re[m], im[m], re[m + 4], im[m + 4], w.w0r, w.w0i);
+}
+__device__ __forceinline__ void pass_inv_top1(double (&re)[8], double (&im)[8], const PassTw &w) {
+#pragma unroll
+  for (int m = 0; m < 4; m++) bf_inv(re[m], im[m], re[m + 4], im[m + 4], w.w0r, w.w0i);
+}
+__device__ __forceinline__ void pass_fwd_top2(double (&re)[8], double (&im)[8], const PassTw &w) {
+  pass_fwd_top1(re, im, w);
+  bf_fwd(re[0], im[0], re[2], im[2], w.w1r, w.w1i);
+  bf_fwd(re[1], im[1], re[3], im[3], w.w1r, w.w1i);
+  bf_fwd_i(re[4], im[4], re[6], im[6], w.w1r, w.w1i);
+  bf_fwd_i(re[5], im[5], re[7], im[7], w.w1r, w.w1i);
+}
+__device__ __forceinline__ void pass_inv_top2(double (&re)[8], double (&im)[8], const PassTw &w) {
+  bf_inv(re[0], im[0], re[2], im[2], w.w1r, w.w1i);
+  bf_inv(re[1], im[1], re[3], im[3], w.w1r, w.w1i);
+  bf_inv_i(re[4], im[4], re[6], im[6], w.w1r, w.w1i);
+  bf_inv_i(re[5], im[5], re[7], im[7], w.w1r, w.w1i);
+  pass_inv_top1(re, im, w);
+}
+
 // Twiddle table: (re, im) of node (2^lev - 1 + nu), M - 1 entries (host: make_twiddles()).
 __device__ __forceinline__ PassTw load_pass_tw(const d2 *__restrict__ tw, int lev, int nu) {
   const d2 a = tw[(1 << lev) - 1 + nu];
@@ -233,19 +257,33 @@ struct Fft1024 {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void team_sync() { __syncthreads(); }
 
-struct Fft2048 {
+// TAIL3 = false: levels grouped 3 + 3 + 3 + 1 over the four layouts (pass C = levels 6-8, pass D = level 9).
+// TAIL3 = true:  3 + 3 + 1 + 3 (pass C = level 6, the top register bit of layout C; pass D = levels 7-9): the pass the caller overlaps with its key-row
+// loads (forward_tail) is then a full three-level one, as at N = 1024.  Same layouts, same exchanges, same butterflies with the same twiddles in the
+// same order per element -- bit-identical results (oracle_fft.c), same slot order.  Which one is faster depends on the registers the caller has left
+// under the last pass: l = 1 bootstraps gain 2 % (SET_2) to 6 % (SET_3), the l = 4 kernel of lvl2 loses 5 % (experiments/README.md, round 2).
+template <bool TAIL3>
+struct Fft2048T {
   static constexpr int N = 2048, M = 1024, LOGM = 10, THREADS = 128, P = 8;
   static constexpr int XCH_SLOTS = 1152;
   static __device__ __forceinline__ void sync() { team_sync(); }
   PassTw wa, wb, wc;
-  double wd0r, wd0i, wd1r, wd1i;  // level 9: nodes 4t and 4t+2 (4t+1, 4t+3 are i times those)
+  PassTw wd;   // TAIL3: levels 7-9 of layout D (and only w0 of wc is used); else only w2a / w2b: level 9, nodes 4t and 4t+2 (4t+1, 4t+3 are i times those)
 
   __device__ __forceinline__ void init(const d2 *__restrict__ tw, int t) {
     wa = load_pass_tw(tw, 0, 0);
     wb = load_pass_tw(tw, 3, t >> 4);
-    wc = load_pass_tw(tw, 6, t >> 1);
-    const d2 a = tw[(1 << 9) - 1 + 4 * t], b = tw[(1 << 9) - 1 + 4 * t + 2];
-    wd0r = a.x; wd0i = a.y; wd1r = b.x; wd1i = b.y;
+    if constexpr (TAIL3) {
+      const d2 c = tw[(1 << 6) - 1 + (t >> 1)];
+      wc.w0r = c.x; wc.w0i = c.y;
+      wc.w1r = wc.w1i = wc.w2ar = wc.w2ai = wc.w2br = wc.w2bi = 0.0;
+      wd = load_pass_tw(tw, 7, t);
+    } else {
+      wc = load_pass_tw(tw, 6, t >> 1);
+      const d2 a = tw[(1 << 9) - 1 + 4 * t], b = tw[(1 << 9) - 1 + 4 * t + 2];
+      wd.w0r = wd.w0i = wd.w1r = wd.w1i = 0.0;
+      wd.w2ar = a.x; wd.w2ai = a.y; wd.w2br = b.x; wd.w2bi = b.y;
+    }
   }
 
   // thread bases (in 16-byte slots) of the four layouts under the three slot maps
@@ -258,17 +296,33 @@ struct Fft2048 {
   // layout C under slot = j + (j >> 3): j = 16u + 2m + e  ->  18u + e + 2m + (m >> 2)
   static __device__ __forceinline__ constexpr int off_c3(int m) { return 2 * m + (m >> 2); }
 
+  __device__ __forceinline__ void pass_c_fwd(double (&re)[8], double (&im)[8]) const {
+    if constexpr (TAIL3) pass_fwd_top1(re, im, wc);
+    else pass_fwd(re, im, wc);
+  }
+  __device__ __forceinline__ void pass_c_inv(double (&re)[8], double (&im)[8]) const {
+    if constexpr (TAIL3) pass_inv_top1(re, im, wc);
+    else pass_inv(re, im, wc);
+  }
   __device__ __forceinline__ void pass_d_fwd(double (&re)[8], double (&im)[8]) const {
-    bf_fwd(re[0], im[0], re[1], im[1], wd0r, wd0i);
-    bf_fwd_i(re[2], im[2], re[3], im[3], wd0r, wd0i);
-    bf_fwd(re[4], im[4], re[5], im[5], wd1r, wd1i);
-    bf_fwd_i(re[6], im[6], re[7], im[7], wd1r, wd1i);
+    if constexpr (TAIL3) {
+      pass_fwd(re, im, wd);
+    } else {
+      bf_fwd(re[0], im[0], re[1], im[1], wd.w2ar, wd.w2ai);
+      bf_fwd_i(re[2], im[2], re[3], im[3], wd.w2ar, wd.w2ai);
+      bf_fwd(re[4], im[4], re[5], im[5], wd.w2br, wd.w2bi);
+      bf_fwd_i(re[6], im[6], re[7], im[7], wd.w2br, wd.w2bi);
+    }
   }
   __device__ __forceinline__ void pass_d_inv(double (&re)[8], double (&im)[8]) const {
-    bf_inv(re[0], im[0], re[1], im[1], wd0r, wd0i);
-    bf_inv_i(re[2], im[2], re[3], im[3], wd0r, wd0i);
-    bf_inv(re[4], im[4], re[5], im[5], wd1r, wd1i);
-    bf_inv_i(re[6], im[6], re[7], im[7], wd1r, wd1i);
+    if constexpr (TAIL3) {
+      pass_inv(re, im, wd);
+    } else {
+      bf_inv(re[0], im[0], re[1], im[1], wd.w2ar, wd.w2ai);
+      bf_inv_i(re[2], im[2], re[3], im[3], wd.w2ar, wd.w2ai);
+      bf_inv(re[4], im[4], re[5], im[5], wd.w2br, wd.w2bi);
+      bf_inv_i(re[6], im[6], re[7], im[7], wd.w2br, wd.w2bi);
+    }
   }
 
   // forward: input in layout A, output in layout D.  forward_head leaves the data ready for pass D so the caller
@@ -296,7 +350,7 @@ struct Fft2048 {
 #pragma unroll
       for (int m = 0; m < 8; m++) { const d2 v = r[2 * m]; re[m] = v.x; im[m] = v.y; }
     }
-    pass_fwd(re, im, wc);
+    pass_c_fwd(re, im);
     wave_lds_sync();
     {
       d2 *w = xch + base_c3(t), *r = xch + base_d3(t);
@@ -327,7 +381,7 @@ struct Fft2048 {
 #pragma unroll
       for (int m = 0; m < 8; m++) { const d2 v = r[off_c3(m)]; re[m] = v.x; im[m] = v.y; }
     }
-    pass_inv(re, im, wc);
+    pass_c_inv(re, im);
     wave_lds_sync();
     {
       d2 *w = xch + base_c2(t), *r = xch + base_b2(t);
@@ -367,14 +421,14 @@ struct Fft2048 {
 #pragma unroll
     for (int m = 0; m < 8; m++) pd[m] = d2{yr[m], yi[m]};
     wave_lds_sync();
-    pass_inv(xr, xi, wc);
+    pass_c_inv(xr, xi);
 #pragma unroll
     for (int m = 0; m < 8; m++) { const d2 v = pc3[off_c3(m)]; yr[m] = v.x; yi[m] = v.y; }
     wave_lds_sync();
 #pragma unroll
     for (int m = 0; m < 8; m++) pc2[2 * m] = d2{xr[m], xi[m]};
     wave_lds_sync();
-    pass_inv(yr, yi, wc);
+    pass_c_inv(yr, yi);
 #pragma unroll
     for (int m = 0; m < 8; m++) { const d2 v = pb2[18 * m]; xr[m] = v.x; xi[m] = v.y; }
     wave_lds_sync();
@@ -402,6 +456,8 @@ struct Fft2048 {
     team_sync();
   }
 };
+using Fft2048 = Fft2048T<false>;
+using Fft2048W = Fft2048T<true>;
 
 // ------------------------------------------------------------------------------------------------
 // N = 4096 (M = 2048; the reference's SET_3, test/tests.c:48): four wavefronts (256 threads) x 8 points.
@@ -416,19 +472,28 @@ struct Fft2048 {
 // slots, so B<->C and C<->D stay inside a wavefront (wave-level ordering); only A<->B crosses wavefronts.
 // Slot order of the DFT domain = layout D: device index m * 256 + thread.
 // ------------------------------------------------------------------------------------------------
-struct Fft4096 {
+// TAIL3: levels grouped 3 + 3 + 2 + 3 instead of 3 + 3 + 3 + 2 (cf. Fft2048T)
+template <bool TAIL3>
+struct Fft4096T {
   static constexpr int N = 4096, M = 2048, LOGM = 11, THREADS = 256, P = 8;
   static constexpr int XCH_SLOTS = 2304;
   static __device__ __forceinline__ void sync() { team_sync(); }
-  PassTw wa, wb, wc, wd;  // wd: only w1 (level 9, node 2t) and w2a / w2b (level 10, nodes 4t, 4t + 2) are used
+  PassTw wa, wb, wc, wd;  // TAIL3: wc = levels 6-7 (w0, w1), wd = levels 8-10; else wc = levels 6-8, wd: only w1 (level 9, node 2t) and w2a / w2b (level 10)
 
   __device__ __forceinline__ void init(const d2 *__restrict__ tw, int t) {
     wa = load_pass_tw(tw, 0, 0);
     wb = load_pass_tw(tw, 3, t >> 5);
-    wc = load_pass_tw(tw, 6, t >> 2);
-    const d2 a = tw[(1 << 9) - 1 + 2 * t], b = tw[(1 << 10) - 1 + 4 * t], c = tw[(1 << 10) - 1 + 4 * t + 2];
-    wd.w0r = 0.0; wd.w0i = 0.0;
-    wd.w1r = a.x; wd.w1i = a.y; wd.w2ar = b.x; wd.w2ai = b.y; wd.w2br = c.x; wd.w2bi = c.y;
+    if constexpr (TAIL3) {
+      const d2 c0 = tw[(1 << 6) - 1 + (t >> 2)], c1 = tw[(1 << 7) - 1 + 2 * (t >> 2)];
+      wc.w0r = c0.x; wc.w0i = c0.y; wc.w1r = c1.x; wc.w1i = c1.y;
+      wc.w2ar = wc.w2ai = wc.w2br = wc.w2bi = 0.0;
+      wd = load_pass_tw(tw, 8, t);
+    } else {
+      wc = load_pass_tw(tw, 6, t >> 2);
+      const d2 a = tw[(1 << 9) - 1 + 2 * t], b = tw[(1 << 10) - 1 + 4 * t], c = tw[(1 << 10) - 1 + 4 * t + 2];
+      wd.w0r = 0.0; wd.w0i = 0.0;
+      wd.w1r = a.x; wd.w1i = a.y; wd.w2ar = b.x; wd.w2ai = b.y; wd.w2br = c.x; wd.w2bi = c.y;
+    }
   }
 
   static __device__ __forceinline__ int base_a(int t) { return t; }                                  // + 256 m   (slot = j)
@@ -439,25 +504,41 @@ struct Fft4096 {
   static __device__ __forceinline__ constexpr int off_c3(int m) { return 4 * m + (m >> 1); }
 
   // the last two stages of a three-level pass (register pairs (m, m+2), then (m, m+1))
+  __device__ __forceinline__ void pass_c_fwd(double (&re)[8], double (&im)[8]) const {
+    if constexpr (TAIL3) pass_fwd_top2(re, im, wc);
+    else pass_fwd(re, im, wc);
+  }
+  __device__ __forceinline__ void pass_c_inv(double (&re)[8], double (&im)[8]) const {
+    if constexpr (TAIL3) pass_inv_top2(re, im, wc);
+    else pass_inv(re, im, wc);
+  }
   __device__ __forceinline__ void pass_d_fwd(double (&re)[8], double (&im)[8]) const {
-    bf_fwd(re[0], im[0], re[2], im[2], wd.w1r, wd.w1i);
-    bf_fwd(re[1], im[1], re[3], im[3], wd.w1r, wd.w1i);
-    bf_fwd_i(re[4], im[4], re[6], im[6], wd.w1r, wd.w1i);
-    bf_fwd_i(re[5], im[5], re[7], im[7], wd.w1r, wd.w1i);
-    bf_fwd(re[0], im[0], re[1], im[1], wd.w2ar, wd.w2ai);
-    bf_fwd_i(re[2], im[2], re[3], im[3], wd.w2ar, wd.w2ai);
-    bf_fwd(re[4], im[4], re[5], im[5], wd.w2br, wd.w2bi);
-    bf_fwd_i(re[6], im[6], re[7], im[7], wd.w2br, wd.w2bi);
+    if constexpr (TAIL3) {
+      pass_fwd(re, im, wd);
+    } else {
+      bf_fwd(re[0], im[0], re[2], im[2], wd.w1r, wd.w1i);
+      bf_fwd(re[1], im[1], re[3], im[3], wd.w1r, wd.w1i);
+      bf_fwd_i(re[4], im[4], re[6], im[6], wd.w1r, wd.w1i);
+      bf_fwd_i(re[5], im[5], re[7], im[7], wd.w1r, wd.w1i);
+      bf_fwd(re[0], im[0], re[1], im[1], wd.w2ar, wd.w2ai);
+      bf_fwd_i(re[2], im[2], re[3], im[3], wd.w2ar, wd.w2ai);
+      bf_fwd(re[4], im[4], re[5], im[5], wd.w2br, wd.w2bi);
+      bf_fwd_i(re[6], im[6], re[7], im[7], wd.w2br, wd.w2bi);
+    }
   }
   __device__ __forceinline__ void pass_d_inv(double (&re)[8], double (&im)[8]) const {
-    bf_inv(re[0], im[0], re[1], im[1], wd.w2ar, wd.w2ai);
-    bf_inv_i(re[2], im[2], re[3], im[3], wd.w2ar, wd.w2ai);
-    bf_inv(re[4], im[4], re[5], im[5], wd.w2br, wd.w2bi);
-    bf_inv_i(re[6], im[6], re[7], im[7], wd.w2br, wd.w2bi);
-    bf_inv(re[0], im[0], re[2], im[2], wd.w1r, wd.w1i);
-    bf_inv(re[1], im[1], re[3], im[3], wd.w1r, wd.w1i);
-    bf_inv_i(re[4], im[4], re[6], im[6], wd.w1r, wd.w1i);
-    bf_inv_i(re[5], im[5], re[7], im[7], wd.w1r, wd.w1i);
+    if constexpr (TAIL3) {
+      pass_inv(re, im, wd);
+    } else {
+      bf_inv(re[0], im[0], re[1], im[1], wd.w2ar, wd.w2ai);
+      bf_inv_i(re[2], im[2], re[3], im[3], wd.w2ar, wd.w2ai);
+      bf_inv(re[4], im[4], re[5], im[5], wd.w2br, wd.w2bi);
+      bf_inv_i(re[6], im[6], re[7], im[7], wd.w2br, wd.w2bi);
+      bf_inv(re[0], im[0], re[2], im[2], wd.w1r, wd.w1i);
+      bf_inv(re[1], im[1], re[3], im[3], wd.w1r, wd.w1i);
+      bf_inv_i(re[4], im[4], re[6], im[6], wd.w1r, wd.w1i);
+      bf_inv_i(re[5], im[5], re[7], im[7], wd.w1r, wd.w1i);
+    }
   }
 
   __device__ __forceinline__ void forward_head(double (&re)[8], double (&im)[8], d2 *xch, int t) const {
@@ -480,7 +561,7 @@ struct Fft4096 {
 #pragma unroll
       for (int m = 0; m < 8; m++) { const d2 v = r[4 * m]; re[m] = v.x; im[m] = v.y; }
     }
-    pass_fwd(re, im, wc);
+    pass_c_fwd(re, im);
     wave_lds_sync();
     {
       d2 *w = xch + base_c(t), *r = xch + base_d3(t);
@@ -510,7 +591,7 @@ struct Fft4096 {
 #pragma unroll
       for (int m = 0; m < 8; m++) { const d2 v = r[off_c3(m)]; re[m] = v.x; im[m] = v.y; }
     }
-    pass_inv(re, im, wc);
+    pass_c_inv(re, im);
     wave_lds_sync();
     {
       d2 *w = xch + base_c(t), *r = xch + base_b2(t);
@@ -547,14 +628,14 @@ struct Fft4096 {
 #pragma unroll
     for (int m = 0; m < 8; m++) pd[m] = d2{yr[m], yi[m]};
     wave_lds_sync();
-    pass_inv(xr, xi, wc);
+    pass_c_inv(xr, xi);
 #pragma unroll
     for (int m = 0; m < 8; m++) { const d2 v = pc[off_c3(m)]; yr[m] = v.x; yi[m] = v.y; }
     wave_lds_sync();
 #pragma unroll
     for (int m = 0; m < 8; m++) pc[4 * m] = d2{xr[m], xi[m]};
     wave_lds_sync();
-    pass_inv(yr, yi, wc);
+    pass_c_inv(yr, yi);
 #pragma unroll
     for (int m = 0; m < 8; m++) { const d2 v = pb2[36 * m]; xr[m] = v.x; xi[m] = v.y; }
     wave_lds_sync();
@@ -582,6 +663,13 @@ struct Fft4096 {
     team_sync();
   }
 };
+using Fft4096 = Fft4096T<false>;
+using Fft4096W = Fft4096T<true>;
+
+// the wide-tail sibling of a transform (itself where there is none)
+template <class F> struct WideTail { using type = F; };
+template <> struct WideTail<Fft2048> { using type = Fft2048W; };
+template <> struct WideTail<Fft4096> { using type = Fft4096W; };
 
 // double -> Torus64, round to nearest, mod 2^64 (values reach ~2^84).  `scale` = 2^-64 / M.
 // Same result as oracle_fft.c:round_mod_2_64 for every input (semantics of the reference's AVX-512 path,
