@@ -5,15 +5,18 @@
 
 using namespace mosfhet;
 
+#ifndef AB_WIDE
+#define AB_WIDE false
+#endif
 #ifndef AB_N
 #define AB_N 1024
 #endif
 #if AB_N == 1024
 using ABF = Fft1024;
 #elif AB_N == 2048
-using ABF = Fft2048;
+using ABF = Fft2048T<AB_WIDE>;
 #else
-using ABF = Fft4096;
+using ABF = Fft4096T<AB_WIDE>;
 #endif
 #ifndef AB_L
 #define AB_L 2
