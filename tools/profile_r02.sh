@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): round-2 rocprofv3 summaries of every kernel DESIGN.md section 4 names, from the CURRENT tree.
-#   tools/profile_r02.sh <tag>  ->  gpurun_out/prof_<tag>_{pbs,ep,lvl2,ks}/summary.txt  (copy into profiles/)
+#   tools/profile_r02.sh <tag> ["pbs ep ..."]  ->  gpurun_out/prof_<tag>_{pbs,ep,lvl2,ks}/summary.txt  (copy into profiles/)
 # Kernel-trace statistics and counters are taken in SEPARATE runs; every --pmc pass is its own run (MI355X_MICROARCH.md, rocprofv3 PMC slots).
 set -u
 TAG=${1:-r02}
@@ -18,13 +18,15 @@ prof() {   # prof <name> <counter sets separated by ;> <program args...>
   done
   python3 $ROOT/tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 }
+ONLY=${2:-"pbs ep lvl2 ks cb"}   # second argument: the profiles to take
+want() { case " $ONLY " in *" $1 "*) return 0;; esac; return 1; }
 SQ1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
 SQ2="SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU GRBM_GUI_ACTIVE"
 LDS="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL"
 ALL="FETCH_SIZE;WRITE_SIZE;$LDS;$SQ1;TCC_HIT_sum TCC_MISS_sum;$SQ2"
-prof pbs "$ALL" $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --streams 1
-prof ep "$ALL" $ROOT/tools/gpu_perf_ep.py 65536 set1
-prof lvl2 "$ALL" $ROOT/tools/gpu_perf.py 4096 lvl2
-prof ks "$ALL" $ROOT/tools/gpu_perf_ks.py 4096 lvl2 device
-prof cb "FETCH_SIZE;WRITE_SIZE;$SQ2" $ROOT/tools/gpu_perf_cb.py 1024
-for n in pbs ep lvl2 ks cb; do echo "=== $n"; grep -E "kernel stats|calls=|per-dispatch" $ROOT/gpurun_out/prof_${TAG}_$n/summary.txt | head -60; done
+want pbs && prof pbs "$ALL" $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --streams 1
+want ep && prof ep "$ALL" $ROOT/tools/gpu_perf_ep.py 65536 set1
+want lvl2 && prof lvl2 "$ALL" $ROOT/tools/gpu_perf.py 4096 lvl2
+want ks && prof ks "$ALL" $ROOT/tools/gpu_perf_ks.py 4096 lvl2 device
+want cb && prof cb "FETCH_SIZE;WRITE_SIZE;$SQ2" $ROOT/tools/gpu_perf_cb.py 1024
+for n in $ONLY; do echo "=== $n"; grep -E "kernel stats|calls=|per-dispatch" $ROOT/gpurun_out/prof_${TAG}_$n/summary.txt | head -60; done
