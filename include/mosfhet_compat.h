@@ -20,6 +20,7 @@
 #ifndef MOSFHET_COMPAT_H
 #define MOSFHET_COMPAT_H
 #include <stddef.h>
+#include <stdbool.h>
 #include <stdint.h>
 #include <stdio.h>
 #ifdef __cplusplus
@@ -278,6 +279,73 @@ void mosfhet_gen_bootstrap_key_flat(Torus *out /*[n][(k+1)l][k+1][N]*/, TRGSW_Ke
 void mosfhet_gen_tlwe_ks_key_flat(Torus *out /*[n_in][t][2^bb-1][n_out+1]*/, TLWE_Key out_key, TLWE_Key in_key,
                                   int t, int base_bit);
 void mosfhet_tlwe_sample_flat(Torus *out /*[n+1]*/, Torus m, TLWE_Key key);
+
+/* ---- single-object helpers either side of the path (csrc/host/mosfhet_compat_legacy.c) ----
+ * torus domain: host structs, exact arithmetic mod 2^64 (file:line = the reference function each one stands for) */
+void polynomial_zero_torus_polynomial(TorusPolynomial p);                                                   /* polynomial.c:139-141 */
+void polynomial_copy_torus_polynomial(TorusPolynomial out, TorusPolynomial in);                             /* :135-137 */
+void polynomial_negate_torus_polynomial(TorusPolynomial out, TorusPolynomial in);                           /* :144-148 */
+void polynomial_add_torus_polynomials(TorusPolynomial out, TorusPolynomial in1, TorusPolynomial in2);       /* :95-99 */
+void polynomial_addto_torus_polynomial(TorusPolynomial out, TorusPolynomial in);                            /* :156-160 */
+void polynomial_sub_torus_polynomials(TorusPolynomial out, TorusPolynomial in1, TorusPolynomial in2);       /* :163-177 */
+void polynomial_subto_torus_polynomial(TorusPolynomial out, TorusPolynomial in);                            /* :180-182 */
+TorusPolynomial *polynomial_new_array_of_torus_polynomials(int N, int size);                                /* :20-26; free_array_of_polynomials */
+void polynomial_torus_scale(TorusPolynomial out, TorusPolynomial in, int log_scale);                        /* :319-325 */
+void polynomial_torus_scale2(TorusPolynomial out, TorusPolynomial in, uint64_t scale);                      /* :327-332 */
+void polynomial_decompose(TorusPolynomial *out, TorusPolynomial in, int Bg_bit, int l);                     /* :55-72 (public_mux's digits) */
+void polynomial_decompose_i(TorusPolynomial out, TorusPolynomial in, int Bg_bit, int l, int i);             /* :74-89 (the external product's digits) */
+void trlwe_decompose(TorusPolynomial *out, TRLWE in, int Bg_bit, int l);                                    /* trlwe.c:636-660 */
+void torus_polynomial_mul_by_xai(TorusPolynomial out, TorusPolynomial in, int a);                           /* polynomial.c:184-199; out != in */
+void torus_polynomial_mul_by_xai_addto(TorusPolynomial out, TorusPolynomial in, int a);                     /* :202-217 */
+void torus_polynomial_mul_by_xai_minus_1(TorusPolynomial out, TorusPolynomial in, int a);                   /* :220-235 */
+void polynomial_naive_mul_torus(TorusPolynomial out, TorusPolynomial in1, TorusPolynomial in2);             /* :290-303: exact, O(N^2) */
+void polynomial_naive_mul_addto_torus(TorusPolynomial out, TorusPolynomial in1, TorusPolynomial in2);       /* :266-277 */
+void trlwe_mul_by_xai_addto(TRLWE out, TRLWE in, int a);                                                    /* trlwe.c:464-469 */
+void trlwe_mul_by_xai_minus_1(TRLWE out, TRLWE in, int a);                                                  /* trlwe.c:471-476 */
+void trlwe_scale(TRLWE out, TRLWE in, uint64_t scale);                                                      /* trlwe.c:269-274 */
+void trlwe_LUT_packing(TRLWE out, uint64_t *in, uint64_t in_prec, uint64_t out_prec);                       /* trlwe.c:669-675 */
+void trgsw_add(TRGSW out, TRGSW in1, TRGSW in2);                                                            /* trgsw.c:312-317 */
+void trgsw_addto(TRGSW out, TRGSW in);                                                                      /* :319-321 */
+void trgsw_sub(TRGSW out, TRGSW in1, TRGSW in2);                                                            /* :275-280 */
+void trgsw_copy(TRGSW out, TRGSW in);                                                                       /* :296-301 */
+void trgsw_mul_by_xai(TRGSW out, TRGSW in, int a);                                                          /* :324-329 */
+void trgsw_mul_by_xai_addto(TRGSW out, TRGSW in, int a);                                                    /* :331-336 */
+void trgsw_mul_by_xai_minus_1(TRGSW out, TRGSW in, int a);                                                  /* :338-343 */
+void trgsw_noiseless_trivial_sample(TRGSW out, Torus m, int l, int Bg_bit, int k, int N);                   /* :128-143 */
+TRGSW trgsw_new_noiseless_trivial_sample(Torus m, int l, int Bg_bit, int k, int N);                         /* :145-149 */
+TRGSW trgsw_new_monomial_sample(int64_t m, int e, TRGSW_Key key);                                           /* :178-184 */
+TRGSW trgsw_new_sample(Torus m, TRGSW_Key key);                                                             /* :186-188 */
+TRGSW trgsw_new_exp_sample(int e, TRGSW_Key key);                                                           /* :271-273 */
+/* DFT domain: device-resident objects (see trlwe_alloc_new_DFT_sample above); every call is a kernel launch */
+void polynomial_add_DFT_polynomials(DFT_Polynomial out, DFT_Polynomial in1, DFT_Polynomial in2);            /* polynomial.c:102-106 */
+void polynomial_sub_DFT_polynomials(DFT_Polynomial out, DFT_Polynomial in1, DFT_Polynomial in2);            /* :129-133 */
+void polynomial_scale_and_add_DFT_polynomials(DFT_Polynomial out, DFT_Polynomial in1, DFT_Polynomial in2, uint64_t scale);   /* :108-121 */
+void polynomial_mul_torus(TorusPolynomial out, TorusPolynomial in1, TorusPolynomial in2);                   /* :281-292: product through the transform */
+void polynomial_mul_addto_torus(TorusPolynomial out, TorusPolynomial in1, TorusPolynomial in2);             /* :294-303 */
+void trlwe_DFT_add(TRLWE_DFT out, TRLWE_DFT in1, TRLWE_DFT in2);                                            /* trlwe.c:443-448 */
+void trlwe_DFT_addto(TRLWE_DFT out, TRLWE_DFT in);                                                          /* :450-452 */
+void trlwe_DFT_sub(TRLWE_DFT out, TRLWE_DFT in1, TRLWE_DFT in2);                                            /* :454-459 */
+void trlwe_DFT_copy(TRLWE_DFT out, TRLWE_DFT in);                                                           /* :478-483 */
+void trlwe_DFT_mul_by_polynomial(TRLWE_DFT out, TRLWE_DFT in, DFT_Polynomial in2);                          /* :491-496 */
+void trlwe_DFT_mul_addto_by_polynomial(TRLWE_DFT out, TRLWE_DFT in, DFT_Polynomial in2);                    /* :498-505 */
+void trlwe_noiseless_trivial_DFT_sample(TRLWE_DFT out, DFT_Polynomial m);                                   /* :282-289 */
+TRLWE_DFT trlwe_new_noiseless_trivial_DFT_sample(DFT_Polynomial m, int k, int N);                           /* :291-295 */
+void trlwe_DFT_phase(TorusPolynomial out, TRLWE_DFT in, TRLWE_Key key);                                     /* :372-382 */
+void trgsw_DFT_add(TRGSW_DFT out, TRGSW_DFT in1, TRGSW_DFT in2);                                            /* trgsw.c:289-294 */
+void trgsw_DFT_sub(TRGSW_DFT out, TRGSW_DFT in1, TRGSW_DFT in2);                                            /* :282-287 */
+void trgsw_DFT_copy(TRGSW_DFT out, TRGSW_DFT in);                                                           /* :303-308 */
+void trgsw_DFT_mul_addto_by_polynomial(TRGSW_DFT out, TRGSW_DFT in1, DFT_Polynomial in2);                   /* :449-454 */
+void trgsw_from_DFT(TRGSW out, TRGSW_DFT in);                                                               /* :351-357 */
+void trgsw_mul_DFT(TRGSW_DFT out, TRGSW in1, TRGSW_DFT in2);                                                /* :425-431; out != in2 */
+void trgsw_mul_DFT2(TRGSW_DFT out, TRGSW_DFT in1, TRGSW_DFT in2);                                           /* :433-447 */
+void trgsw_mul_trlwe_DFT_prefetch(TRLWE_DFT out, TRLWE in1, TRGSW_DFT in2);                                 /* = trgsw_mul_trlwe_DFT */
+void trgsw_monomial_DFT_sample(TRGSW_DFT out, int64_t m, int e, TRGSW_Key key);                             /* :170-175 */
+/* unfolded blind rotation on caller-held key material, and the automorphism key sets */
+void blind_rotate_unfolded(TRLWE tv, Torus *a, TRGSW *s, int size, int unfolding);                          /* bootstrap.c:124-149; s in new_bootstrap_key's su layout */
+void multivalue_bootstrap_UBR_phase1(TRGSW_DFT *out, TLWE in, Bootstrap_Key key);                           /* bootstrap.c:151-175; out: n / unfolding samples */
+void multivalue_bootstrap_UBR_phase2(TLWE out, TRLWE tv, TLWE in, TRGSW_DFT *sa, Bootstrap_Key key, int torus_base);   /* bootstrap.c:177-190 */
+TRLWE_KS_Key *trlwe_new_automorphism_KS_keyset(TRLWE_Key key, bool skip_even, int t, int base_bit);         /* keyswitch.c:500-511; N (or 2N) headers over one device key set */
+TRLWE_KS_Key *trlwe_new_automorphism_KS_keyset_2(TRLWE_Key key, uint64_t *gens, uint64_t size, int t, int base_bit);   /* keyswitch.c:513-524 */
 
 #ifdef __cplusplus
 }

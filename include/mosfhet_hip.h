@@ -348,6 +348,9 @@ int mosfhet_hip_public_mux_dft_batch(mosfhet_hip_ctx_t ctx, uint64_t *d_out /*[c
 /* blind_rotate_ga (src/bootstrap_ga.c:35-60) in place on d_acc [count][2][N]; d_in [count][n+1] (mask words) */
 int mosfhet_hip_blind_rotate_ga_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, mosfhet_hip_gak_t gak, uint64_t *d_acc, const uint64_t *d_in, int count,
                                       void *stream);
+/* polynomial_add_DFT_polynomials / _sub_ / _scale_and_add_ (src/polynomial.c:102-128) and the TRLWE_DFT / TRGSW_DFT sums built on them, over flat
+ * device arrays: d_out[i] = (d_a ? d_a[i] : 0) + cb * d_b[i] (d_out may alias d_a or d_b) */
+int mosfhet_hip_dft_lincomb_batch(mosfhet_hip_ctx_t ctx, double *d_out, const double *d_a, const double *d_b, double cb, size_t n_doubles, void *stream);
 /* trlwe_eval_automorphism (src/trlwe.c:775-781) with key-set entry `entry` (the batch entry point above uses entry (gen - 1) / 2) */
 int mosfhet_hip_trlwe_eval_automorphism_entry_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_gak_t gak, int entry, uint64_t *d_out, const uint64_t *d_in, int gen,
                                                     int count, void *stream);

@@ -1141,6 +1141,39 @@ TRLWE_KS_Key *trlwe_new_priv_KS_key(TRLWE_Key out_key, TRLWE_Key in_key, int t, 
   return res;
 }
 
+/* src/keyswitch.c:500-524: key sets for the automorphisms X -> X^gen: entry j switches from key(X^gens[j]) back to key.  One device key set behind
+ * `count` headers (header 0 owns it: free the headers with free_trlwe_ks_key, header 0 last or first -- the set goes with it). */
+static TRLWE_KS_Key *automorphism_keyset(TRLWE_Key key, const uint64_t *gens, int count, int t, int base_bit, const char *who) {
+  const int N = key->s[0]->N;
+  if (key->k != 1) { fprintf(stderr, "mosfhet_amd: %s: k = 1 only\n", who); abort(); }
+  Torus *msgs = (Torus *)mc_xmalloc(sizeof(Torus) * (size_t)count * N);
+  TorusPolynomial perm = polynomial_new_torus_polynomial(N);
+  for (int j = 0; j < count; j++) {
+    if (gens[j] & 1) polynomial_permute(perm, key->s[0], gens[j]);
+    else memset(perm->coeffs, 0, sizeof(Torus) * (size_t)N);   /* even "generators" are no automorphisms of the ring: a key from 0, never usable */
+    memcpy(msgs + (size_t)j * N, perm->coeffs, sizeof(Torus) * (size_t)N);
+  }
+  free_polynomial(perm);
+  mosfhet_hip_gak_t dev = fft_ks_keys_new(key, msgs, count, t, base_bit, who);
+  free(msgs);
+  TRLWE_KS_Key *res = (TRLWE_KS_Key *)mc_xmalloc(sizeof(TRLWE_KS_Key) * (size_t)count);
+  for (int j = 0; j < count; j++) res[j] = trlwe_ks_header(dev, j, j == 0, t, base_bit);
+  return res;
+}
+
+TRLWE_KS_Key *trlwe_new_automorphism_KS_keyset(TRLWE_Key key, bool skip_even, int t, int base_bit) {
+  const int N = key->s[0]->N, count = skip_even ? N : 2 * N;
+  uint64_t *gens = (uint64_t *)mc_xmalloc(sizeof(uint64_t) * (size_t)count);
+  for (int j = 0; j < count; j++) gens[j] = skip_even ? (uint64_t)(2 * j + 1) : (uint64_t)j;
+  TRLWE_KS_Key *res = automorphism_keyset(key, gens, count, t, base_bit, "trlwe_new_automorphism_KS_keyset");
+  free(gens);
+  return res;
+}
+
+TRLWE_KS_Key *trlwe_new_automorphism_KS_keyset_2(TRLWE_Key key, uint64_t *gens, uint64_t size, int t, int base_bit) {
+  return automorphism_keyset(key, gens, (int)size, t, base_bit, "trlwe_new_automorphism_KS_keyset_2");
+}
+
 void free_trlwe_ks_key(TRLWE_KS_Key key) {
   if (!key) return;
   if (key->owner) mosfhet_hip_gak_destroy((mosfhet_hip_gak_t)key->device);

@@ -768,6 +768,190 @@ static void case_dft_level_api(void) {
   free_polynomial(pa); free_polynomial(pb); free_polynomial(pc);
 }
 
+/* The single-object helpers around the path (csrc/host/mosfhet_compat_legacy.c): DFT-domain arithmetic on device objects, TRGSW products, the
+ * automorphism key sets and the unfolded blind rotation on caller-held samples, each checked by decryption or against the exact integer result. */
+static void poly_phase_check_key(TRLWE c, TorusPolynomial want, uint64_t tol, const char *what, TRLWE_Key key) {
+  TorusPolynomial ph = polynomial_new_torus_polynomial(N);
+  trlwe_phase(ph, c, key);
+  uint64_t worst = 0;
+  for (int i = 0; i < N; i++) { const uint64_t d = tdist(want->coeffs[i], ph->coeffs[i]); if (d > worst) worst = d; }
+  CHECK(worst < tol, "%s: worst phase error %016llx", what, (unsigned long long)worst);
+  free_polynomial(ph);
+}
+static void poly_phase_check(TRLWE c, TorusPolynomial want, uint64_t tol, const char *what) { poly_phase_check_key(c, want, tol, what, rlwe_key); }
+static void case_legacy_helpers(void) {
+  TorusPolynomial m1 = polynomial_new_torus_polynomial(N), m2 = polynomial_new_torus_polynomial(N), sm = polynomial_new_torus_polynomial(N);
+  TorusPolynomial want = polynomial_new_torus_polynomial(N), got = polynomial_new_torus_polynomial(N);
+  generate_random_bytes(sizeof(Torus) * N, (uint8_t *)m1->coeffs);
+  generate_random_bytes(sizeof(Torus) * N, (uint8_t *)m2->coeffs);
+  for (int i = 0; i < N; i++) sm->coeffs[i] = (Torus)((int64_t)((i * 7) % 13) - 6);
+  /* --- products through the transform against the exact schoolbook product (test_poly_DFT_mul, test/tests.c:244-276: 2^40) */
+  polynomial_naive_mul_torus(want, m1, sm);
+  polynomial_mul_torus(got, m1, sm);
+  for (int i = 0; i < N; i++) WITHIN(1ULL << 40, want->coeffs[i], got->coeffs[i], "polynomial_mul_torus");
+  polynomial_copy_torus_polynomial(got, m2);
+  polynomial_mul_addto_torus(got, m1, sm);
+  polynomial_addto_torus_polynomial(want, m2);
+  for (int i = 0; i < N; i++) WITHIN(1ULL << 40, want->coeffs[i], got->coeffs[i], "polynomial_mul_addto_torus");
+  /* --- DFT polynomials: a + b, a - b, a + 3 b */
+  DFT_Polynomial *f = polynomial_new_array_of_polynomials_DFT(N, 3);
+  polynomial_torus_to_DFT(f[0], m1);
+  polynomial_torus_to_DFT(f[1], m2);
+  polynomial_add_DFT_polynomials(f[2], f[0], f[1]);
+  polynomial_DFT_to_torus(got, f[2]);
+  for (int i = 0; i < N; i++) WITHIN(1ULL << 16, m1->coeffs[i] + m2->coeffs[i], got->coeffs[i], "polynomial_add_DFT_polynomials");
+  polynomial_sub_DFT_polynomials(f[2], f[0], f[1]);
+  polynomial_DFT_to_torus(got, f[2]);
+  for (int i = 0; i < N; i++) WITHIN(1ULL << 16, m1->coeffs[i] - m2->coeffs[i], got->coeffs[i], "polynomial_sub_DFT_polynomials");
+  polynomial_scale_and_add_DFT_polynomials(f[2], f[0], f[1], 3);
+  polynomial_DFT_to_torus(got, f[2]);
+  for (int i = 0; i < N; i++) WITHIN(1ULL << 16, m1->coeffs[i] + 3 * m2->coeffs[i], got->coeffs[i], "polynomial_scale_and_add_DFT_polynomials");
+  /* --- TRLWE_DFT arithmetic, by decryption */
+  TRLWE c1 = trlwe_new_sample(m1, rlwe_key), c2 = trlwe_new_sample(m2, rlwe_key), r = trlwe_alloc_new_sample(k, N);
+  TRLWE_DFT *d = trlwe_alloc_new_DFT_sample_array(3, k, N);
+  TRLWE_DFT lone = trlwe_alloc_new_DFT_sample(k, N);
+  trlwe_to_DFT(d[0], c1);
+  trlwe_to_DFT(d[1], c2);
+  trlwe_DFT_add(d[2], d[0], d[1]);
+  trlwe_from_DFT(r, d[2]);
+  polynomial_add_torus_polynomials(want, m1, m2);
+  poly_phase_check(r, want, 1ULL << 45, "trlwe_DFT_add");
+  trlwe_DFT_sub(lone, d[0], d[1]);
+  trlwe_from_DFT(r, lone);
+  polynomial_sub_torus_polynomials(want, m1, m2);
+  poly_phase_check(r, want, 1ULL << 45, "trlwe_DFT_sub");
+  trlwe_DFT_copy(lone, d[0]);
+  trlwe_DFT_addto(lone, d[0]);
+  trlwe_from_DFT(r, lone);
+  polynomial_torus_scale2(want, m1, 2);
+  poly_phase_check(r, want, 1ULL << 45, "trlwe_DFT_copy + trlwe_DFT_addto");
+  trlwe_DFT_phase(got, d[1], rlwe_key);
+  for (int i = 0; i < N; i++) WITHIN(1ULL << 45, m2->coeffs[i], got->coeffs[i], "trlwe_DFT_phase");
+  polynomial_torus_to_DFT(f[2], sm);
+  trlwe_DFT_mul_by_polynomial(d[2], d[0], f[2]);
+  trlwe_DFT_mul_addto_by_polynomial(d[2], d[1], f[2]);
+  trlwe_from_DFT(r, d[2]);
+  polynomial_add_torus_polynomials(got, m1, m2);
+  polynomial_naive_mul_torus(want, got, sm);
+  poly_phase_check(r, want, 1ULL << 50, "trlwe_DFT_mul_by_polynomial + _mul_addto_by_polynomial");
+  TRLWE_DFT triv = trlwe_new_noiseless_trivial_DFT_sample(f[0], k, N);
+  trlwe_from_DFT(r, triv);
+  int mask_zero = 1;
+  for (int i = 0; i < N; i++) mask_zero &= r->a[0]->coeffs[i] == 0;
+  CHECK(mask_zero, "trlwe_new_noiseless_trivial_DFT_sample: mask is not zero");
+  for (int i = 0; i < N; i++) WITHIN(1ULL << 16, m1->coeffs[i], r->b->coeffs[i], "trlwe_new_noiseless_trivial_DFT_sample");
+  free_trlwe(triv);
+  /* --- TRGSW: constructors, DFT round trip, sums and products; checked through external products on a sample under the low-noise key of
+   * wide_setup (l = 4, Bg = 2^9: a product of two encrypted TRGSW samples needs that headroom, as in the reference's own TRGSW tests) */
+  wide_setup();
+  TRLWE cw = trlwe_new_sample(m1, wkey);
+#define WCHECK(tol, what) poly_phase_check_key(r, want, tol, what, wkey)
+  TRGSW_DFT *g = trgsw_alloc_new_DFT_sample_array(4, wl, wBg, k, N);
+  TRGSW e3 = trgsw_new_exp_sample(3, wgkey), e5 = trgsw_new_exp_sample(5, wgkey), one = trgsw_new_sample(1, wgkey);
+  TRGSW tr = trgsw_new_noiseless_trivial_sample(1, wl, wBg, k, N), gt = trgsw_alloc_new_sample(wl, wBg, k, N);
+  trgsw_to_DFT(g[0], e3);
+  trgsw_from_DFT(gt, g[0]);
+  for (int row = 0; row < 2 * wl; row++)
+    for (int i = 0; i < N; i += 37) WITHIN(1ULL << 14, e3->samples[row]->b->coeffs[i], gt->samples[row]->b->coeffs[i], "trgsw_to_DFT / trgsw_from_DFT");
+  trgsw_to_DFT(g[1], e5);
+  trgsw_mul_DFT(g[2], e3, g[1]);                       /* TRGSW(X^3) x TRGSW_DFT(X^5) = TRGSW_DFT(X^8) */
+  trgsw_mul_trlwe_DFT(d[2], cw, g[2]);
+  trlwe_from_DFT(r, d[2]);
+  torus_polynomial_mul_by_xai(want, m1, 8);
+  WCHECK(1ULL << 50, "trgsw_mul_DFT");
+  trgsw_mul_DFT2(g[3], g[0], g[1]);
+  trgsw_mul_trlwe_DFT_prefetch(d[2], cw, g[3]);
+  trlwe_from_DFT(r, d[2]);
+  WCHECK(1ULL << 50, "trgsw_mul_DFT2");
+  trgsw_DFT_add(g[3], g[0], g[1]);                      /* TRGSW_DFT(X^3 + X^5) */
+  trgsw_mul_trlwe_DFT(d[2], cw, g[3]);
+  trlwe_from_DFT(r, d[2]);
+  torus_polynomial_mul_by_xai(want, m1, 3);
+  torus_polynomial_mul_by_xai_addto(want, m1, 5);
+  WCHECK(1ULL << 50, "trgsw_DFT_add");
+  trgsw_DFT_sub(g[3], g[3], g[1]);                      /* back to X^3 */
+  trgsw_DFT_copy(g[2], g[3]);
+  trgsw_mul_trlwe_DFT(d[2], cw, g[2]);
+  trlwe_from_DFT(r, d[2]);
+  torus_polynomial_mul_by_xai(want, m1, 3);
+  WCHECK(1ULL << 50, "trgsw_DFT_sub + trgsw_DFT_copy");
+  trgsw_monomial_DFT_sample(g[2], 1, N + 7, wgkey); /* X^(N+7) = -X^7 */
+  trgsw_mul_trlwe_DFT(d[2], cw, g[2]);
+  trlwe_from_DFT(r, d[2]);
+  torus_polynomial_mul_by_xai(want, m1, N + 7);
+  WCHECK(1ULL << 50, "trgsw_monomial_DFT_sample");
+  trgsw_to_DFT(g[2], tr);                               /* the noise-free gadget of 1: an identity up to the digits' rounding */
+  trgsw_mul_trlwe_DFT(d[2], cw, g[2]);
+  trlwe_from_DFT(r, d[2]);
+  poly_phase_check_key(r, m1, 1ULL << 40, "trgsw_new_noiseless_trivial_sample", wkey);
+  trgsw_to_DFT(g[2], one);
+  polynomial_torus_to_DFT(f[2], sm);
+  trgsw_DFT_copy(g[3], g[2]);
+  trgsw_DFT_mul_addto_by_polynomial(g[3], g[2], f[2]);  /* TRGSW_DFT(1 + sm) */
+  trgsw_mul_trlwe_DFT(d[2], cw, g[3]);
+  trlwe_from_DFT(r, d[2]);
+  polynomial_naive_mul_torus(want, m1, sm);
+  polynomial_addto_torus_polynomial(want, m1);
+  WCHECK(1ULL << 50, "trgsw_DFT_mul_addto_by_polynomial");
+  free_trgsw(e3); free_trgsw(e5); free_trgsw(one); free_trgsw(tr); free_trgsw(gt); free_trgsw_array(g, 4);
+  /* --- automorphism key set: X -> X^5 through entry 2 of the odd-generator set (test_trlwe_ks tolerance, test/tests.c:794-830) */
+  TRLWE_KS_Key *aks = trlwe_new_automorphism_KS_keyset(wkey, true, 3, 12);
+  trlwe_eval_automorphism(r, cw, 5, aks[2]);
+  polynomial_permute(want, m1, 5);
+  WCHECK(1ULL << 50, "trlwe_new_automorphism_KS_keyset + trlwe_eval_automorphism");
+  uint64_t gens[2] = {2 * N - 1, 9};
+  TRLWE_KS_Key *aks2 = trlwe_new_automorphism_KS_keyset_2(wkey, gens, 2, 3, 12);
+  trlwe_eval_automorphism(r, cw, 2 * N - 1, aks2[0]);
+  polynomial_permute(want, m1, 2 * N - 1);
+  WCHECK(1ULL << 50, "trlwe_new_automorphism_KS_keyset_2");
+  for (int j = N - 1; j >= 0; j--) free_trlwe_ks_key(aks[j]);
+  free(aks);
+  free_trlwe_ks_key(aks2[1]); free_trlwe_ks_key(aks2[0]); free(aks2);
+  /* --- unfolded blind rotation: the legacy entry points on caller-held objects */
+  Torus lut[4] = {int2torus(3, 4), int2torus(7, 4), int2torus(11, 4), int2torus(15, 4)};
+  TRLWE tv = trlwe_alloc_new_sample(k, N), acc = trlwe_alloc_new_sample(k, N);
+  trlwe_torus_packing(tv, lut, 4);
+  Bootstrap_Key ubk = new_bootstrap_key(wgkey, lwe_key, 2);
+  TLWE in = tlwe_new_sample(double2torus(2 / 8.), lwe_key), out = tlwe_alloc_sample(N), ref = tlwe_alloc_sample(N);
+  TRGSW_DFT *sa = trgsw_alloc_new_DFT_sample_array(n / 2, wl, wBg, k, N);
+  multivalue_bootstrap_UBR_phase1(sa, in, ubk);
+  multivalue_bootstrap_UBR_phase2(out, tv, in, sa, ubk, 4);
+  WITHIN(1ULL << 58, lut[2], tlwe_phase(out, wkey_extracted), "multivalue_bootstrap_UBR_phase1 + _phase2");
+  functional_bootstrap(ref, tv, in, ubk, 4);
+  WITHIN(1ULL << 58, lut[2], tlwe_phase(ref, wkey_extracted), "functional_bootstrap (unfolded key)");
+  TRGSW_DFT *sb = (TRGSW_DFT *)safe_malloc(sizeof(TRGSW_DFT) * (n / 2));   /* the same through samples allocated one by one */
+  for (int i = 0; i < n / 2; i++) sb[i] = trgsw_alloc_new_DFT_sample(wl, wBg, k, N);
+  multivalue_bootstrap_UBR_phase1(sb, in, ubk);
+  multivalue_bootstrap_UBR_phase2(ref, tv, in, sb, ubk, 4);
+  CHECK(ref->b == out->b && !memcmp(ref->a, out->a, sizeof(Torus) * N), "UBR phases through separately allocated samples differ from the array form");
+  for (int i = 0; i < n / 2; i++) free_trgsw(sb[i]);
+  free(sb);
+  free_trgsw_array(sa, n / 2);
+  /* blind_rotate_unfolded with the torus-domain samples held by the caller (new_bootstrap_key's su layout) */
+  const int entries = n * 4 / 2;
+  Torus *flat = (Torus *)safe_malloc(sizeof(Torus) * (size_t)entries * 2 * wl * 2 * N);
+  mosfhet_gen_bootstrap_key_unfolded_flat(flat, wgkey, lwe_key, 2);
+  TRGSW *su = trgsw_alloc_new_sample_array(entries, wl, wBg, k, N);
+  for (int e = 0; e < entries; e++)
+    for (int row = 0; row < 2 * wl; row++) {
+      const Torus *src = flat + ((size_t)e * 2 * wl + row) * 2 * N;
+      memcpy(su[e]->samples[row]->a[0]->coeffs, src, sizeof(Torus) * N);
+      memcpy(su[e]->samples[row]->b->coeffs, src + N, sizeof(Torus) * N);
+    }
+  free(flat);
+  const uint64_t bt = torus2int(in->b + double2torus(1. / 16), 11);
+  trlwe_mul_by_xai(acc, tv, (int)((2 * N - bt) & (2 * N - 1)));
+  blind_rotate_unfolded(acc, in->a, su, n, 2);
+  trlwe_extract_tlwe(out, acc, 0);
+  WITHIN(1ULL << 58, lut[2], tlwe_phase(out, wkey_extracted), "blind_rotate_unfolded");
+  free_trgsw_array(su, entries);
+  free_bootstrap_key(ubk);
+  free_tlwe(in); free_tlwe(out); free_tlwe(ref); free_trlwe(tv); free_trlwe(acc);
+  free_trlwe(c1); free_trlwe(c2); free_trlwe(r); free_trlwe(lone); free_trlwe_array(d, 3);
+  free_array_of_polynomials(f, 3);
+  free_polynomial(m1); free_polynomial(m2); free_polynomial(sm); free_polynomial(want); free_polynomial(got);
+}
+
 int main(int argc, char **argv) {
   setvbuf(stdout, NULL, _IOLBF, 0);
   mosfhet_seed(0x4D4F5346);
@@ -786,7 +970,7 @@ int main(int argc, char **argv) {
     {"circuit_2+mux+trgsw", case_circuit_2_mux_trgsw},   {"radix_integer_add", case_radix_integer_add},
     {"key_files", case_key_files},                       {"threads", case_threads},
     {"other_rings", case_other_rings},                   {"big_batch", case_big_batch},
-    {"dft_level_api", case_dft_level_api},
+    {"dft_level_api", case_dft_level_api},                {"legacy_helpers", case_legacy_helpers},
   };
   for (unsigned i = 0; i < sizeof(cases) / sizeof(cases[0]); i++) {
     if (argc > 1 && strcmp(argv[1], cases[i].name)) continue;
