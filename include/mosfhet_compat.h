@@ -340,6 +340,12 @@ void trgsw_mul_DFT(TRGSW_DFT out, TRGSW in1, TRGSW_DFT in2);                    
 void trgsw_mul_DFT2(TRGSW_DFT out, TRGSW_DFT in1, TRGSW_DFT in2);                                           /* :433-447 */
 void trgsw_mul_trlwe_DFT_prefetch(TRLWE_DFT out, TRLWE in1, TRGSW_DFT in2);                                 /* = trgsw_mul_trlwe_DFT */
 void trgsw_monomial_DFT_sample(TRGSW_DFT out, int64_t m, int e, TRGSW_Key key);                             /* :170-175 */
+void trlwe_save_DFT_sample(FILE *fd, TRLWE_DFT c);                                                          /* trlwe.c:66-71: (k+1) N doubles, this engine's slot order */
+void trlwe_load_DFT_sample(FILE *fd, TRLWE_DFT c);                                                          /* :79-85 */
+TRLWE_DFT trlwe_load_new_DFT_sample(FILE *fd, int k, int N);                                                /* :73-77 */
+void trgsw_save_DFT_sample(FILE *fd, TRGSW_DFT c);                                                          /* trgsw.c:80-84 */
+void trgsw_load_DFT_sample(FILE *fd, TRGSW_DFT out);                                                        /* :94-98 */
+TRGSW_DFT trgsw_load_new_DFT_sample(FILE *fd, int l, int Bg_bit, int k, int N);                             /* :86-92 */
 /* unfolded blind rotation on caller-held key material, and the automorphism key sets */
 void blind_rotate_unfolded(TRLWE tv, Torus *a, TRGSW *s, int size, int unfolding);                          /* bootstrap.c:124-149; s in new_bootstrap_key's su layout */
 void multivalue_bootstrap_UBR_phase1(TRGSW_DFT *out, TLWE in, Bootstrap_Key key);                           /* bootstrap.c:151-175; out: n / unfolding samples */

@@ -15,6 +15,7 @@
  * k = 1 wherever a device object is involved (every parameter set of the reference, test/tests.c:37-62).
  */
 #define _GNU_SOURCE
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -436,4 +437,45 @@ void multivalue_bootstrap_UBR_phase2(TLWE out, TRLWE tv, TLWE in, TRGSW_DFT *sa,
   out->b = h[N];
   mc_hstage_free(h);
   if (!contiguous) hipFree(src);
+}
+
+/* ================================================================== DFT-domain samples on disk (src/trlwe.c:66-85, src/trgsw.c:80-98) */
+/* The reference writes the (k+1) N doubles of a sample as they sit in memory, no header -- element order is whatever its FFT back-end uses, so such a
+ * file never moved between its own builds either.  Same shape here: the engine's slot order, read back by this library only. */
+static void dft_poly_io(FILE *fd, DFT_Polynomial p, int write, const char *who) {
+  const size_t n = (size_t)p->N;
+  double *h = (double *)mc_xmalloc(sizeof(double) * n);
+  mc_use_device();
+  if (write) {
+    mc_dev_copy(h, poly_dev(p, kNotOurs), sizeof(double) * n, HIP_D2H);
+    if (fwrite(h, sizeof(double), n, fd) != n) { fprintf(stderr, "mosfhet_amd: %s: write failed\n", who); abort(); }
+  } else {
+    if (fread(h, sizeof(double), n, fd) != n) { fprintf(stderr, "mosfhet_amd: %s: short read\n", who); abort(); }
+    mc_dev_copy(poly_dev(p, kNotOurs), h, sizeof(double) * n, HIP_H2D);
+  }
+  free(h);
+}
+void trlwe_save_DFT_sample(FILE *fd, TRLWE_DFT c) {
+  for (int i = 0; i < c->k; i++) dft_poly_io(fd, c->a[i], 1, "trlwe_save_DFT_sample");
+  dft_poly_io(fd, c->b, 1, "trlwe_save_DFT_sample");
+}
+void trlwe_load_DFT_sample(FILE *fd, TRLWE_DFT c) {
+  for (int i = 0; i < c->k; i++) dft_poly_io(fd, c->a[i], 0, "trlwe_load_DFT_sample");
+  dft_poly_io(fd, c->b, 0, "trlwe_load_DFT_sample");
+}
+TRLWE_DFT trlwe_load_new_DFT_sample(FILE *fd, int k, int N) {
+  TRLWE_DFT c = trlwe_alloc_new_DFT_sample(k, N);
+  trlwe_load_DFT_sample(fd, c);
+  return c;
+}
+void trgsw_save_DFT_sample(FILE *fd, TRGSW_DFT c) {
+  for (int r = 0; r < trgsw_dft_rows(c); r++) trlwe_save_DFT_sample(fd, c->samples[r]);
+}
+void trgsw_load_DFT_sample(FILE *fd, TRGSW_DFT out) {
+  for (int r = 0; r < trgsw_dft_rows(out); r++) trlwe_load_DFT_sample(fd, out->samples[r]);
+}
+TRGSW_DFT trgsw_load_new_DFT_sample(FILE *fd, int l, int Bg_bit, int k, int N) {
+  TRGSW_DFT g = trgsw_alloc_new_DFT_sample(l, Bg_bit, k, N);
+  trgsw_load_DFT_sample(fd, g);
+  return g;
 }

@@ -870,6 +870,15 @@ static void case_legacy_helpers(void) {
   torus_polynomial_mul_by_xai_addto(want, m1, 5);
   WCHECK(1ULL << 50, "trgsw_DFT_add");
   trgsw_DFT_sub(g[3], g[3], g[1]);                      /* back to X^3 */
+  {   /* ... through a file and back (trgsw_save_DFT_sample / trgsw_load_new_DFT_sample, trlwe_*_DFT_sample inside) */
+    FILE *fd = tmpfile();
+    trgsw_save_DFT_sample(fd, g[3]);
+    rewind(fd);
+    TRGSW_DFT back = trgsw_load_new_DFT_sample(fd, wl, wBg, k, N);
+    fclose(fd);
+    trgsw_DFT_copy(g[3], back);
+    free_trgsw(back);
+  }
   trgsw_DFT_copy(g[2], g[3]);
   trgsw_mul_trlwe_DFT(d[2], cw, g[2]);
   trlwe_from_DFT(r, d[2]);

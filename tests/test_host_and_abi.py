@@ -55,6 +55,50 @@ def test_must_keep_symbols_are_exported(native_lib):
     assert '#include "mosfhet_compat.h"' in open(os.path.join(ROOT, "include", "mosfhet.h")).read()
 
 
+NOT_PROVIDED = """_debug_trgsw_decrypt_exp_DFT_sample _debug_trgsw_decrypt_exp_sample _debug_trlwe_decrypt_exp_sample free_trgsw_reg free_trgsw_reg_array
+free_trlwe_packing_ks_key polynomial_full_mul_with_scale polynomial_naive_mul_addto_torus_binary polynomial_naive_mul_binary polynomial_new_binary_polynomial
+print_trlwe_msg tlwe_keyswitch_no_precomp tlwe_new_KS_key_no_precomp tlwe_new_bounded_key trgsw_from_gadget trgsw_naive_mul trgsw_naive_mul_trlwe trgsw_reg_add
+trgsw_reg_addto trgsw_reg_alloc trgsw_reg_alloc_array trgsw_reg_copy trgsw_reg_negate trgsw_reg_sample trgsw_reg_sub trgsw_reg_subto trlwe_RLWE_priv_keyswitch
+trlwe_compressed_DFT_mul_addto trlwe_compressed_DFT_sample trlwe_compressed_subto trlwe_full_packing_keyswitch trlwe_load_compressed_sample
+trlwe_load_new_compressed_sample trlwe_load_new_packing_KS_key trlwe_new_RLWE_priv_KS_key trlwe_new_bounded_key trlwe_new_compressed_DFT_sample
+trlwe_new_compressed_sample trlwe_new_full_packing_KS_key trlwe_new_gadget_to_RGSW_KS trlwe_new_gaussian_key trlwe_new_packing1_KS_key_CDKS21
+trlwe_new_packing_KS_key trlwe_new_sparse_binary_key trlwe_new_sparse_gaussian_key trlwe_new_sparse_generic_key trlwe_new_sparse_ternary_key
+trlwe_new_ternary_key trlwe_packing1_keyswitch_CDKS21 trlwe_packing_keyswitch trlwe_save_compressed_sample trlwe_save_packing_KS_key trlwe_tensor_prod""".split()
+
+
+def _prototypes(path):
+    """name -> (return type, [argument types]) of every function a C header declares, parameter names and spacing removed"""
+    import re
+    text = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    scalars = {"int", "double", "void", "uint64_t", "bool", "char", "uint8_t", "uint16_t", "int64_t", "uint32_t", "FILE", "size_t"}
+    out = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_ \*]*?)\b([A-Za-z_][A-Za-z0-9_]*)\s*\(([^;{()]*)\)\s*;", text):
+        ret, name, args = re.sub(r"\s+", "", m.group(1)).replace("const", ""), m.group(2), m.group(3).strip()
+        types = []
+        for a in ([] if args in ("", "void") else args.split(",")):
+            toks = re.sub(r"\[\d*\]", "*", a).replace("*", " * ").split()
+            if len(toks) > 1 and re.match(r"^[A-Za-z_]\w*$", toks[-1]) and toks[-1] not in scalars and not toks[-1][0].isupper():
+                toks = toks[:-1]          # the parameter's name
+            types.append("".join(toks).replace("const", ""))
+        out[name] = (ret, types)
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/include/mosfhet.h"), reason="the reference tree exists in the build container only")
+def test_header_matches_the_reference_prototypes():
+    """Drop-in means: what include/mosfhet.h declares has the reference's prototypes, argument by argument, and what it does not declare is the
+    list INTEGRATION.md gives (anything else missing is a regression)."""
+    ref = _prototypes("/root/reference/include/mosfhet.h")
+    ours = _prototypes(os.path.join(ROOT, "include", "mosfhet_compat.h"))
+    common = sorted(set(ref) & set(ours))
+    different = [(n, ref[n], ours[n]) for n in common if ref[n] != ours[n]]
+    assert not different, different[:5]
+    missing = sorted(set(ref) - set(ours))
+    assert missing == sorted(NOT_PROVIDED), (sorted(set(missing) - set(NOT_PROVIDED)), sorted(set(NOT_PROVIDED) - set(missing)))
+    assert len(common) >= 222
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/applications"), reason="the reference tree exists in the build container only")
 def test_reference_application_relinks_unchanged(native_lib):
     """The reference's own applications/leveled_lut/vertical_packing.c compiles UNCHANGED against include/mosfhet.h and links to the product library
