@@ -239,6 +239,10 @@ int mosfhet_hip_full_domain_functional_bootstrap_CLOT21_batch(mosfhet_hip_ctx_t 
 int mosfhet_hip_bsk_unfolded_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t *out, const uint64_t *h_su, int n, int N, int l, int Bg_bit,
                                     int unfolding);
 
+/* the same key encrypted on the device (torus-domain samples, generator and secrets as mosfhet_hip_bsk_generate) */
+int mosfhet_hip_bsk_unfolded_generate(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t *out, const uint64_t *h_s_rlwe /*[N]*/, int N, const uint64_t *h_s_lwe /*[n]*/, int n,
+                                      int l, int Bg_bit, double sigma, uint64_t seed, int unfolding);
+
 /* multivalue_bootstrap_UBR_phase1 / phase2 (src/bootstrap.c:151-190) with an unfolded key: d_sa = [count][n/u][2l][2][N/2] complex
  * (the per-group TRGSW_DFT of each input); phase 2 evaluates tv_count shared test vectors per ciphertext: d_out = [count][tv_count][N+1]. */
 int mosfhet_hip_multivalue_bootstrap_UBR_phase1_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, double *d_sa, const uint64_t *d_in, int count,

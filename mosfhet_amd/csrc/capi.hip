@@ -63,7 +63,7 @@ struct DevBuf {
 // handle: handles are read-only after creation, so any number of host threads may share them, as the reference's callers share its keys
 // (re-entrant through thread-local scratch, src/polynomial.c:269-352).  A thread's launches are ordered by the stream it passes; buffers are
 // released at thread exit (hipFree waits for work in flight).
-enum { POOL_BSK = 0, POOL_EXT0 = 1, POOL_EXT1 = 2, POOL_CTX0 = 3, POOL_SLOTS = 6 };
+enum { POOL_BSK = 0, POOL_EXT0 = 1, POOL_EXT1 = 2, POOL_CTX0 = 3, POOL_UNFOLD = 6, POOL_SLOTS = 7 };
 struct ThreadPool {
   struct Dev {
     int device = -1;

@@ -655,11 +655,10 @@ Bootstrap_Key new_bootstrap_key(TRGSW_Key out_key, TLWE_Key in_key, int unfoldin
                                  out_key->trlwe_key->sigma, mc_rnd64(), 0))
       mc_die("new_bootstrap_key");
   } else {
-    const size_t words = (size_t)n * ((size_t)1 << unfolding) / unfolding * 2 * l * 2 * N;
-    Torus *flat = (Torus *)mc_xmalloc(sizeof(Torus) * words);
-    mosfhet_gen_bootstrap_key_unfolded_flat(flat, out_key, in_key, unfolding);
-    if (mosfhet_hip_bsk_unfolded_create((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, flat, n, N, l, out_key->Bg_bit, unfolding)) mc_die("new_bootstrap_key (unfolded)");
-    free(flat);
+    /* the 2^u / u * n torus-domain samples are encrypted on the device too (u = 8 at lvl2: 5 GB of them) */
+    if (mosfhet_hip_bsk_unfolded_generate((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, out_key->trlwe_key->s[0]->coeffs, N, in_key->s, n, l, out_key->Bg_bit,
+                                          out_key->trlwe_key->sigma, mc_rnd64(), unfolding))
+      mc_die("new_bootstrap_key (unfolded)");
   }
   res->device = dev;
   res->s = key_views(dev, n, l, out_key->Bg_bit, N);

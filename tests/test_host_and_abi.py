@@ -111,6 +111,17 @@ def test_reference_application_relinks_unchanged(native_lib):
     undefined = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True, check=True).stdout
     for name in ("trgsw_mul_trlwe_DFT", "trlwe_from_DFT", "trgsw_to_DFT", "blind_rotate", "trgsw_alloc_new_DFT_sample_array"):
         assert name in undefined, "the application does not import %s?" % name
+    # the same for its leveled-LUT example and its two benchmark programs (test/benchmark.c is the reference's headline benchmark)
+    exported = set(line.split()[-1] for line in
+                   subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "mosfhet_amd", "libmosfhet_hip.so")], capture_output=True, text=True, check=True).stdout.splitlines() if line.strip())
+    for prog, needs in (("leveled_lut_hip", ("trgsw_monomial_sample", "trgsw_mul_trlwe_DFT")), ("benchmark_arith_hip", ("polynomial_naive_mul_addto_torus", "polynomial_add_DFT_polynomials")),
+                        ("benchmark_hip", ("multivalue_bootstrap_UBR_phase2", "functional_bootstrap_trgsw_phase1", "new_bootstrap_key_ga"))):
+        exe = os.path.join(ROOT, "oracle", "_ref", prog)
+        ldd = subprocess.run(["ldd", exe], capture_output=True, text=True, check=True).stdout
+        assert "libmosfhet_hip.so" in ldd and "not found" not in ldd, (prog, ldd)
+        und = [line.split()[-1] for line in subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True, check=True).stdout.splitlines() if line.strip()]
+        for name in needs:
+            assert name in und and name in exported, (prog, name)
 
 
 def test_no_cpu_fallback(native_lib):
