@@ -239,6 +239,9 @@ int mosfhet_hip_full_domain_functional_bootstrap_CLOT21_batch(mosfhet_hip_ctx_t 
 int mosfhet_hip_bsk_unfolded_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t *out, const uint64_t *h_su, int n, int N, int l, int Bg_bit,
                                     int unfolding);
 
+/* Bootstraps of few ciphertexts with an unfolded key assemble the selectors of all key groups side by side first (two launches per chunk of `max_batch`
+ * ciphertexts, up to 8 chunks; same results bit for bit); larger batches run one fused kernel.  -1: default (64, capped by 2 GiB of selectors), 0: never. */
+int mosfhet_hip_set_unfold_split_max(int max_batch);
 /* the same key encrypted on the device (torus-domain samples, generator and secrets as mosfhet_hip_bsk_generate) */
 int mosfhet_hip_bsk_unfolded_generate(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t *out, const uint64_t *h_s_rlwe /*[N]*/, int N, const uint64_t *h_s_lwe /*[n]*/, int n,
                                       int l, int Bg_bit, double sigma, uint64_t seed, int unfolding);

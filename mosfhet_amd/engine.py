@@ -617,6 +617,11 @@ class Engine:
         self.torch.cuda.current_stream(self.device).synchronize()
 
 
+def set_unfold_split_max(max_batch):
+    """chunk size of the two-phase unfolded bootstrap (-1 default, 0 = always the fused kernel)"""
+    _check(lib().mosfhet_hip_set_unfold_split_max(int(max_batch)))
+
+
 def set_team_max_batch(max_batch):
     """Batches up to this size use the latency-oriented bootstrap kernel at N = 1024 (0 disables it)."""
     _check(lib().mosfhet_hip_set_team_max_batch(int(max_batch)))
