@@ -346,6 +346,14 @@ TRLWE_DFT trlwe_load_new_DFT_sample(FILE *fd, int k, int N);                    
 void trgsw_save_DFT_sample(FILE *fd, TRGSW_DFT c);                                                          /* trgsw.c:80-84 */
 void trgsw_load_DFT_sample(FILE *fd, TRGSW_DFT out);                                                        /* :94-98 */
 TRGSW_DFT trgsw_load_new_DFT_sample(FILE *fd, int l, int Bg_bit, int k, int N);                             /* :86-92 */
+/* LUT-packing key switch (src/keyswitch.c:214-366; the encrypted lookup tables of applications/multi-ciphertext-arith): device-resident table key */
+typedef struct _LUT_Packing_KS_Key { TRLWE ****s; int base_bit, t, torus_base, n;          /* mosfhet.h:95-98 */
+                                     void *device; } *LUT_Packing_KS_Key;                  /* + engine handle (appended); s is NULL */
+LUT_Packing_KS_Key trlwe_new_packing_KS_key(TRLWE_Key out_key, TLWE_Key in_key, int t, int base_bit, int torus_base);   /* keyswitch.c:214-241 */
+void trlwe_packing_keyswitch(TRLWE out, TLWE *in, LUT_Packing_KS_Key ks_key);                                /* :346-366; in: torus_base samples */
+void trlwe_save_packing_KS_key(FILE *fd, LUT_Packing_KS_Key key);                                            /* :243-262 (uncompressed rows) */
+LUT_Packing_KS_Key trlwe_load_new_packing_KS_key(FILE *fd);                                                  /* :264-296 */
+void free_trlwe_packing_ks_key(LUT_Packing_KS_Key key);                                                      /* :298-316 */
 /* unfolded blind rotation on caller-held key material, and the automorphism key sets */
 void blind_rotate_unfolded(TRLWE tv, Torus *a, TRGSW *s, int size, int unfolding);                          /* bootstrap.c:124-149; s in new_bootstrap_key's su layout */
 void multivalue_bootstrap_UBR_phase1(TRGSW_DFT *out, TLWE in, Bootstrap_Key key);                           /* bootstrap.c:151-175; out: n / unfolding samples */

@@ -272,6 +272,13 @@ int mosfhet_hip_ksk_export_rows(mosfhet_hip_ksk_t ksk, size_t first_row, size_t 
  * kernel from (seed, row, word).  Results are bit-identical to the uncompressed key's.  ksk_export_rows expands the rows. */
 int mosfhet_hip_trlwe_table_ksk_generate_compressed(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t *out, int kind, const uint64_t *h_s_out, int N,
                                                     const uint64_t *h_s_in, int n, int t, int base_bit, double sigma, uint64_t seed);
+/* LUT-packing key switch (trlwe_new_packing_KS_key / trlwe_packing_keyswitch, src/keyswitch.c:214-241,346-366): `torus_base` LWE samples into the `torus_base`
+ * slots of one TRLWE sample.  The key is a table key with n * torus_base digit sources (ksk kind 2: export / import / alloc as such);
+ * d_in [count][torus_base][n + 1], d_out [count][2][N]. */
+int mosfhet_hip_trlwe_lut_packing_ksk_generate(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t *out, const uint64_t *h_s_out /*[N]*/, int N, const uint64_t *h_s_in /*[n]*/,
+                                               int n, int t, int base_bit, int torus_base, double sigma, uint64_t seed);
+int mosfhet_hip_trlwe_lut_packing_keyswitch_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t ksk, int torus_base, uint64_t *d_out, const uint64_t *d_in, int count,
+                                                  void *stream);
 size_t mosfhet_hip_ksk_bytes(mosfhet_hip_ksk_t ksk);                     /* device bytes of a key-switch table */
 /* On-device generation of the bootstrap key (new_bootstrap_key without unfolding, src/bootstrap.c:3-21: BK_i = TRGSW(s_i); ga != 0: the
  * TRGSW(X^{s_i}) samples of new_bootstrap_key_ga, src/bootstrap_ga.c:5-24) from the binary TRLWE key h_s_rlwe[N] and LWE key h_s_lwe[n]:

@@ -63,7 +63,7 @@ struct DevBuf {
 // handle: handles are read-only after creation, so any number of host threads may share them, as the reference's callers share its keys
 // (re-entrant through thread-local scratch, src/polynomial.c:269-352).  A thread's launches are ordered by the stream it passes; buffers are
 // released at thread exit (hipFree waits for work in flight).
-enum { POOL_BSK = 0, POOL_EXT0 = 1, POOL_EXT1 = 2, POOL_CTX0 = 3, POOL_UNFOLD = 6, POOL_SLOTS = 7 };
+enum { POOL_BSK = 0, POOL_EXT0 = 1, POOL_EXT1 = 2, POOL_CTX0 = 3, POOL_UNFOLD = 6, POOL_PACK = 7, POOL_SLOTS = 8 };
 struct ThreadPool {
   struct Dev {
     int device = -1;
@@ -248,7 +248,7 @@ static int check_params(const char *who, int k, int N, int l, int Bg_bit) {
   if (k != 1) return fail(MOSFHET_HIP_EINVAL, "%s: only k = 1 is supported (got %d)", who, k);
   if (!ring_ok(N)) return fail(MOSFHET_HIP_EINVAL, "%s: ring degree N = %d not supported (1024, 2048, 4096)", who, N);
   if (l < 1 || Bg_bit < 1 || Bg_bit > 31 || l * Bg_bit >= 64) return fail(MOSFHET_HIP_EINVAL, "%s: bad gadget l=%d Bg_bit=%d (Bg_bit <= 31, l*Bg_bit < 64)", who, l, Bg_bit);
-  if (l != 1 && l != 2 && l != 3 && l != 4) return fail(MOSFHET_HIP_EINVAL, "%s: l = %d not instantiated (1..4)", who, l);
+  if (l > 6) return fail(MOSFHET_HIP_EINVAL, "%s: l = %d not instantiated (1..6: the reference's own programs go up to l = 6, applications/multi-ciphertext-arith/src/ufhe.c:19)", who, l);
   return MOSFHET_HIP_OK;
 }
 
@@ -359,7 +359,9 @@ static void launch_external_product(int l, int Bg_bit, hipStream_t s, const d2 *
   else if (l == 1) EP_GO(1, 0);
   else if (l == 2) EP_GO(2, 0);
   else if (l == 3) EP_GO(3, 0);
-  else EP_GO(4, 0);
+  else if (l == 4) EP_GO(4, 0);
+  else if (l == 5) EP_GO(5, 0);
+  else EP_GO(6, 0);
 #undef EP_GO
 }
 
@@ -410,6 +412,8 @@ static int launch_pbs_f(int l, int Bg_bit, const PbsParams &p, int count, hipStr
   else if (l == 2) launch_pbs<F, 2, 0>(p, count, s);
   else if (l == 3) launch_pbs<F, 3, 0>(p, count, s);
   else if (l == 4) launch_pbs<F, 4, 0>(p, count, s);
+  else if (l == 5) launch_pbs<F, 5, 0>(p, count, s);
+  else if (l == 6) launch_pbs<F, 6, 0>(p, count, s);
   else return fail(MOSFHET_HIP_EINVAL, "l = %d not instantiated", l);
   HIP_TRY(hipGetLastError());
   return MOSFHET_HIP_OK;
@@ -710,6 +714,8 @@ static int launch_ga_f(int l, int Bg_bit, const GaParams &g, int count, hipStrea
   else if (l == 2) launch_ga<F, 2, 0>(g, count, s);
   else if (l == 3) launch_ga<F, 3, 0>(g, count, s);
   else if (l == 4) launch_ga<F, 4, 0>(g, count, s);
+  else if (l == 5) launch_ga<F, 5, 0>(g, count, s);
+  else if (l == 6) launch_ga<F, 6, 0>(g, count, s);
   else return fail(MOSFHET_HIP_EINVAL, "l = %d not instantiated", l);
   HIP_TRY(hipGetLastError());
   return MOSFHET_HIP_OK;

@@ -1679,3 +1679,85 @@ Bootstrap_Key load_new_bootstrap_key(FILE *fd) {
   remember_key(res);
   return res;
 }
+
+/* ------------------------------------------------------------------ LUT-packing key switch (src/keyswitch.c:214-366): torus_base LWE samples into the slots of
+ * one TRLWE sample -- what the reference's radix-integer application builds its encrypted lookup tables with (applications/multi-ciphertext-arith/src/
+ * lut.c).  Device-resident table key like the others: `s` is NULL. */
+LUT_Packing_KS_Key trlwe_new_packing_KS_key(TRLWE_Key out_key, TLWE_Key in_key, int t, int base_bit, int torus_base) {
+  if (out_key->k != 1) { fprintf(stderr, "mosfhet_amd: trlwe_new_packing_KS_key: k = 1 only\n"); abort(); }
+  LUT_Packing_KS_Key res = (LUT_Packing_KS_Key)mc_xmalloc(sizeof(*res));
+  res->s = NULL; res->base_bit = base_bit; res->t = t; res->torus_base = torus_base; res->n = in_key->n;
+  mosfhet_hip_ksk_t dev = NULL;
+  if (mosfhet_hip_trlwe_lut_packing_ksk_generate((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, out_key->s[0]->coeffs, out_key->s[0]->N, in_key->s, in_key->n, t, base_bit,
+                                                 torus_base, out_key->sigma, mc_rnd64()))
+    mc_die("trlwe_new_packing_KS_key");
+  res->device = dev;
+  return res;
+}
+
+void free_trlwe_packing_ks_key(LUT_Packing_KS_Key key) {
+  if (!key) return;
+  mosfhet_hip_ksk_destroy((mosfhet_hip_ksk_t)key->device);
+  free(key);
+}
+
+void trlwe_packing_keyswitch(TRLWE out, TLWE *in, LUT_Packing_KS_Key ks) {
+  mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
+  const int N = out->b->N, n = ks->n, tb = ks->torus_base;
+  const size_t in_w = (size_t)tb * (n + 1), out_w = (size_t)2 * N;
+  Torus *h = (Torus *)mc_hstage_alloc(sizeof(Torus) * (in_w + out_w));
+  tlwe_array_to_flat(h, in, tb, n);
+  Torus *d = (Torus *)mc_stage_alloc(sizeof(Torus) * (in_w + out_w));
+  mc_dev_copy(d, h, sizeof(Torus) * in_w, HIP_H2D);
+  if (mosfhet_hip_trlwe_lut_packing_keyswitch_batch(ctx, (mosfhet_hip_ksk_t)ks->device, tb, d + in_w, d, 1, NULL) || mosfhet_hip_ctx_sync(ctx, NULL))
+    mc_die("trlwe_packing_keyswitch");
+  mc_dev_copy(h + in_w, d + in_w, sizeof(Torus) * out_w, HIP_D2H);
+  mc_trlwe_from_flat(out, h + in_w);
+  stage_free(d);
+  mc_hstage_free(h);
+}
+
+/* file = the reference's: base_bit, t, torus_base, n, k, N, then the n * torus_base * t * (2^base_bit - 1) TRLWE samples in key order (uncompressed rows) */
+void trlwe_save_packing_KS_key(FILE *fd, LUT_Packing_KS_Key key) {
+  int info[6];
+  if (mosfhet_hip_ksk_info((mosfhet_hip_ksk_t)key->device, info)) mc_die("trlwe_save_packing_KS_key");
+  const int N = info[1] / 2, k = 1;
+  xwrite(&key->base_bit, sizeof(int), 1, fd);
+  xwrite(&key->t, sizeof(int), 1, fd);
+  xwrite(&key->torus_base, sizeof(int), 1, fd);
+  xwrite(&key->n, sizeof(int), 1, fd);
+  xwrite(&k, sizeof(int), 1, fd);
+  xwrite(&N, sizeof(int), 1, fd);
+  const size_t rows = (size_t)info[0] * key->t * ((1 << key->base_bit) - 1), row_bytes = (size_t)info[1] * sizeof(Torus);
+  size_t chunk = KS_IO_CHUNK_BYTES / row_bytes;
+  if (chunk < 1) chunk = 1;
+  Torus *buf = (Torus *)mc_xmalloc(chunk * row_bytes);
+  for (size_t r = 0; r < rows; r += chunk) {
+    const size_t c = rows - r < chunk ? rows - r : chunk;
+    if (mosfhet_hip_ksk_export_rows((mosfhet_hip_ksk_t)key->device, r, c, buf)) mc_die("trlwe_save_packing_KS_key");
+    xwrite(buf, row_bytes, c, fd);
+  }
+  free(buf);
+}
+
+LUT_Packing_KS_Key trlwe_load_new_packing_KS_key(FILE *fd) {
+  int v[6];  /* base_bit, t, torus_base, n, k, N */
+  read_ints(fd, v, 6);
+  if (v[4] != 1 || v[2] < 1 || v[3] < 1) { fprintf(stderr, "mosfhet_amd: trlwe_load_new_packing_KS_key: k = 1 keys only\n"); abort(); }
+  LUT_Packing_KS_Key res = (LUT_Packing_KS_Key)mc_xmalloc(sizeof(*res));
+  res->s = NULL; res->base_bit = v[0]; res->t = v[1]; res->torus_base = v[2]; res->n = v[3];
+  mosfhet_hip_ksk_t dev = NULL;   /* a table with n * torus_base digit sources and no b word: ksk kind 2 counts one source more than its `n` argument */
+  if (mosfhet_hip_ksk_alloc((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, 2, v[3] * v[2] - 1, v[5], v[1], v[0])) mc_die("trlwe_load_new_packing_KS_key");
+  const size_t rows = (size_t)v[3] * v[2] * v[1] * ((1 << v[0]) - 1), row_bytes = (size_t)2 * v[5] * sizeof(Torus);
+  size_t chunk = KS_IO_CHUNK_BYTES / row_bytes;
+  if (chunk < 1) chunk = 1;
+  Torus *buf = (Torus *)mc_xmalloc(chunk * row_bytes);
+  for (size_t r = 0; r < rows; r += chunk) {
+    const size_t c = rows - r < chunk ? rows - r : chunk;
+    xread(buf, row_bytes, c, fd);
+    if (mosfhet_hip_ksk_import_rows(dev, r, c, buf)) mc_die("trlwe_load_new_packing_KS_key");
+  }
+  free(buf);
+  res->device = dev;
+  return res;
+}

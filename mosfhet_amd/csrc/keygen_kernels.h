@@ -56,10 +56,12 @@ __device__ __forceinline__ uint64_t keygen_noise(const NoiseKey &key, uint64_t m
 
 // kind 0 (packing): rows (i < n, j < t, v in 1..2^bb-1), message = s_in[i] v 2^(64-(j+1)bb) on X^0
 // kind 1 (private): rows (i <= n, ...), message polynomial = -s_out * (s_i v 2^(64-(j+1)bb)), s_n = -1
+// kind 2 (LUT packing, trlwe_new_packing_KS_key, src/keyswitch.c:214-241): rows ((i, e) with i < n, e < slots; j; v), message = s_in[i] v 2^(64-(j+1)bb) on
+//         the N / slots coefficients of slot e
 // One workgroup of 256 threads per row; the mask lives in LDS while the key's set bits are walked.
 __global__ __launch_bounds__(256) void trlwe_table_keygen_kernel(uint64_t *__restrict__ rows, const uint64_t *__restrict__ s_out,
                                                                const uint64_t *__restrict__ s_in, int n, int N, int t, int base_bit, double sigma,
-                                                               uint64_t seed, int kind, size_t first_row, int compressed, NoiseKey nkey) {
+                                                               uint64_t seed, int kind, size_t first_row, int compressed, NoiseKey nkey, int slots = 1) {
   extern __shared__ uint64_t sh[];   // a[N], then the indices of the set key bits (uint16) packed behind it
   uint64_t *a = sh;
   uint16_t *ones = reinterpret_cast<uint16_t *>(sh + N);
@@ -83,7 +85,8 @@ __global__ __launch_bounds__(256) void trlwe_table_keygen_kernel(uint64_t *__res
     if (!compressed) dst[x] = ax;
   }
   __syncthreads();
-  const uint64_t s_i = i < n ? s_in[i] : ~0ull;
+  const int slot = kind == 2 ? i % slots : 0, span = N / slots;
+  const uint64_t s_i = kind == 2 ? s_in[i / slots] : (i < n ? s_in[i] : ~0ull);
   const uint64_t dec = s_i * (uint64_t)v * (1ull << (64 - (j + 1) * base_bit));
   const int cnt = n_ones;
   for (int x = tid; x < N; x += 256) {
@@ -95,6 +98,7 @@ __global__ __launch_bounds__(256) void trlwe_table_keygen_kernel(uint64_t *__res
     }
     acc += keygen_noise(nkey, seed, r, (uint64_t)x, sigma);
     if (kind == 0) { if (x == 0) acc += dec; }
+    else if (kind == 2) { if (x / span == slot) acc += dec; }
     else acc += ((uint64_t)0 - s_out[x]) * dec;
     dst_b[x] = acc;
   }

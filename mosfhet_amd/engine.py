@@ -365,6 +365,24 @@ class Engine:
                                                           s_in.ctypes.data_as(C.c_void_p), s_in.size, t, base_bit, C.c_double(sigma), C.c_uint64(seed)))
         return KeySwitchKey(self, h, s_in.size + kind, 2 * s_out.size - 1, t, base_bit)
 
+    def generate_lut_packing_key(self, s_out, s_in, t, base_bit, torus_base, sigma, seed):
+        """On-device LUT-packing key (trlwe_new_packing_KS_key, src/keyswitch.c:214-241): rows (i, e, j, v), n * torus_base digit sources."""
+        s_out = np.ascontiguousarray(s_out, dtype=np.uint64)
+        s_in = np.ascontiguousarray(s_in, dtype=np.uint64)
+        h = C.c_void_p()
+        _check(lib().mosfhet_hip_trlwe_lut_packing_ksk_generate(self.h, C.byref(h), s_out.ctypes.data_as(C.c_void_p), s_out.size, s_in.ctypes.data_as(C.c_void_p),
+                                                                s_in.size, t, base_bit, torus_base, C.c_double(sigma), C.c_uint64(seed)))
+        return KeySwitchKey(self, h, s_in.size * torus_base, 2 * s_out.size - 1, t, base_bit)
+
+    def trlwe_lut_packing_keyswitch(self, ksk, torus_base, cts, out=None):
+        """trlwe_packing_keyswitch (src/keyswitch.c:346-366) for a batch: cts [count][torus_base][n + 1] -> [count][2][N]"""
+        count = cts.shape[0]
+        N = (ksk.n_out + 1) // 2
+        if out is None:
+            out = self.empty(count, 2, N)
+        _check(lib().mosfhet_hip_trlwe_lut_packing_keyswitch_batch(self.h, ksk.h, int(torus_base), _ptr(out), _ptr(cts), count, self._stream()))
+        return out
+
     def generate_bootstrap_key(self, s_rlwe, s_lwe, l, Bg_bit, sigma, seed, ga=False):
         """On-device bootstrap key BK_i = TRGSW(s_lwe[i]) (ga: TRGSW(X^{s_lwe[i]})) under the binary TRLWE key s_rlwe."""
         s_rlwe = np.ascontiguousarray(s_rlwe, dtype=np.uint64)

@@ -198,4 +198,7 @@ void orc_gen_tlwe_ks_key(orc_rng *r, Torus *ksk, const Torus *s_in, int n_in, co
 #ifdef __cplusplus
 }
 #endif
+/* LUT-packing key switch (src/keyswitch.c:214-241,346-366) */
+void orc_trlwe_lut_packing_keyswitch(Torus *out, const Torus *in, const Torus *ksk, int n, int N, int t, int base_bit, int torus_base);
+void orc_gen_lut_packing_ks_key(orc_rng *r, Torus *ksk, const Torus *s_in, int n, const Torus *s_out, int N, int t, int base_bit, int torus_base, double sigma);
 #endif

@@ -397,6 +397,22 @@ def gen_packing1_ks_key(rng, s_in, s_out, t, base_bit, sigma):
     return ksk
 
 
+def gen_lut_packing_ks_key(rng, s_in, s_out, t, base_bit, torus_base, sigma):
+    """trlwe_new_packing_KS_key (src/keyswitch.c:214-241): rows [n][torus_base][t][2^base_bit - 1][2][N]"""
+    n, N = s_in.size, s_out.size
+    ksk = np.empty((n, torus_base, t, (1 << base_bit) - 1, 2, N), dtype=np.uint64)
+    lib().orc_gen_lut_packing_ks_key(rng.ref(), _u(ksk), _u(s_in), n, _u(s_out), N, t, base_bit, torus_base, C.c_double(sigma))
+    return ksk
+
+
+def trlwe_lut_packing_keyswitch(cts, ksk, base_bit):
+    """trlwe_packing_keyswitch (src/keyswitch.c:346-366): cts [torus_base][n + 1] -> TRLWE [2][N]"""
+    n, torus_base, t, _, _, N = ksk.shape
+    out = np.empty((2, N), dtype=np.uint64)
+    lib().orc_trlwe_lut_packing_keyswitch(_u(out), _u(np.ascontiguousarray(cts)), _u(ksk), n, N, t, base_bit, torus_base)
+    return out
+
+
 def gen_priv_ks_key(rng, s_out, s_in, t, base_bit, sigma):
     N = s_out.size
     ks0, ks1 = np.empty((t, 2, N), dtype=np.uint64), np.empty((t, 2, N), dtype=np.uint64)

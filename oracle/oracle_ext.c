@@ -167,6 +167,46 @@ void orc_trlwe_priv_keyswitch(Torus *out, const Torus *in, const Torus *ksk, int
   }
 }
 
+/* src/keyswitch.c:346-366  trlwe_packing_keyswitch: torus_base LWE samples (in: [torus_base][n + 1]) into the torus_base slots of one TRLWE sample.
+ * out = (0, b_e on the N / torus_base coefficients of slot e), then for every mask word i, sample e and digit position j the row KS[i][e][j][digit - 1] is
+ * subtracted; ksk rows in the order (i, e, j, v), 2N words each; rounding offset 2^(W - 1 - t base_bit). */
+void orc_trlwe_lut_packing_keyswitch(Torus *out, const Torus *in, const Torus *ksk, int n, int N, int t, int base_bit, int torus_base) {
+  const Torus prec_offset = (Torus)1 << (W - (1 + base_bit * t));
+  const Torus mask = ((Torus)1 << base_bit) - 1;
+  const int base = 1 << base_bit, span = N / torus_base;
+  const size_t row = (size_t)2 * N;
+  for (int q = 0; q < N; q++) {
+    out[q] = 0;
+    out[N + q] = in[(size_t)(q / span) * (n + 1) + n];
+  }
+  for (int i = 0; i < n; i++)
+    for (int e = 0; e < torus_base; e++) {
+      const Torus aibar = in[(size_t)e * (n + 1) + i] + prec_offset;
+      for (int j = 0; j < t; j++) {
+        const Torus aij = (aibar >> (W - (j + 1) * base_bit)) & mask;
+        if (aij != 0) {
+          const Torus *src = ksk + ((((size_t)i * torus_base + e) * t + j) * (base - 1) + (aij - 1)) * row;
+          for (size_t c = 0; c < row; c++) out[c] -= src[c];
+        }
+      }
+    }
+}
+
+/* src/keyswitch.c:214-241  trlwe_new_packing_KS_key: KS[i][e][j][v-1] = TRLWE(0) + s_i v 2^(W - (j+1) base_bit) on the b coefficients of slot e */
+void orc_gen_lut_packing_ks_key(orc_rng *r, Torus *ksk, const Torus *s_in, int n, const Torus *s_out, int N, int t, int base_bit, int torus_base, double sigma) {
+  const int base = 1 << base_bit, span = N / torus_base;
+  const size_t row = (size_t)2 * N;
+  for (int i = 0; i < n; i++)
+    for (int e = 0; e < torus_base; e++)
+      for (int j = 0; j < t; j++)
+        for (int v = 1; v < base; v++) {
+          Torus *dst = ksk + ((((size_t)i * torus_base + e) * t + j) * (base - 1) + (v - 1)) * row;
+          orc_trlwe_sample(r, dst, NULL, s_out, 1, N, sigma);
+          const Torus dec = s_in[i] * (Torus)v * ((Torus)1 << (W - (j + 1) * base_bit));
+          for (int q = e * span; q < (e + 1) * span; q++) dst[N + q] += dec;
+        }
+}
+
 /* src/bootstrap.c:309-322 (variant 0, circuit_bootstrap) and :324-344 (variant 1, circuit_bootstrap_2) */
 void orc_circuit_bootstrap(const orc_fft_plan *p, Torus *out, const Torus *in, const double *bk_dft, const Torus *kska, int ta, int bba,
                            const Torus *kskb, int tb, int bbb, int n, int l, int Bg_bit, int variant) {
