@@ -306,6 +306,70 @@ inline hipError_t launch_tlwe_keyswitch_nw(const uint64_t *ksk, uint64_t *out, s
   return hipGetLastError();
 }
 
+// ---- few ciphertexts (single calls of the legacy API, small batches): the tiled kernel above would walk the whole table for a tile with one live lane
+// (1.7 ms for one lvl2-sized switch).  Here a ciphertext's switch is spread over the chip instead: workgroup (slice, split, ct) owns 256 output words and
+// a range of the input words, reads ONLY the rows the digits select (coalesced, 2 KiB per row and workgroup) and leaves a partial sum; a second small
+// kernel adds the partial sums and the b word.  62 MB of rows per lvl2-sized switch instead of the 186 MB table, on ~1000 workgroups instead of one lane.
+template <bool MASKGEN>
+__global__ __launch_bounds__(256) void tlwe_keyswitch_small_kernel(const uint64_t *__restrict__ ksk, const uint64_t *__restrict__ in, size_t in_stride,
+                                                                  uint64_t *__restrict__ part, int count, int n_in, int row, int t, int base_bit, int i_per_split,
+                                                                  uint64_t seed, int mask_words) {
+  const int w = blockIdx.x * 256 + threadIdx.x, split = blockIdx.y, ct = blockIdx.z;
+  const int cands = (1 << base_bit) - 1;
+  const uint32_t mask = (1u << base_bit) - 1;
+  const uint64_t round_off = 1ull << (63 - base_bit * t);
+  const int i_begin = split * i_per_split, i_end = (i_begin + i_per_split < n_in) ? i_begin + i_per_split : n_in;
+  const uint64_t *__restrict__ a_words = in + (size_t)ct * in_stride;
+  const int b_stride = row - mask_words;
+  uint64_t acc = 0;
+  if (w < row)
+    for (int i = i_begin; i < i_end; i++) {
+      const uint64_t a = a_words[i] + round_off;
+      for (int j = 0; j < t; j++) {
+        const uint32_t v = (uint32_t)(a >> (64 - (j + 1) * base_bit)) & mask;
+        if (!v) continue;
+        const size_t r = ((size_t)i * t + j) * cands + (v - 1);
+        if constexpr (MASKGEN) acc -= w < mask_words ? keygen_mix(seed, r, (uint64_t)w, 0) : ksk[r * (size_t)b_stride + (size_t)(w - mask_words)];
+        else acc -= ksk[r * (size_t)row + w];
+      }
+    }
+  if (w < row) part[((size_t)split * count + ct) * row + w] = acc;
+}
+
+__global__ __launch_bounds__(256) void tlwe_keyswitch_small_reduce_kernel(uint64_t *__restrict__ out, size_t out_stride, const uint64_t *__restrict__ part,
+                                                                         const uint64_t *__restrict__ in, size_t in_stride, int count, int n_in, int row, int b_word,
+                                                                         int splits) {
+  const int w = blockIdx.x * 256 + threadIdx.x, ct = blockIdx.y;
+  if (w >= row) return;
+  uint64_t acc = (w == b_word) ? in[(size_t)ct * in_stride + n_in] : 0;
+  for (int sp = 0; sp < splits; sp++) acc += part[((size_t)sp * count + ct) * row + w];
+  out[(size_t)ct * out_stride + w] = acc;
+}
+
+inline hipError_t launch_tlwe_keyswitch_small(const uint64_t *ksk, uint64_t *out, size_t out_stride, const uint64_t *in, size_t in_stride, int count, int n_in, int row,
+                                              int b_word, int t, int base_bit, KsWorkspace &ws, hipStream_t s, bool compressed, uint64_t seed, int mask_words) {
+  const int slices = (row + 255) / 256;
+  int splits = (1024 + slices * count - 1) / (slices * count);
+  if (splits > n_in / 4) splits = n_in / 4;
+  if (splits < 1) splits = 1;
+  const int i_per_split = (n_in + splits - 1) / splits;
+  splits = (n_in + i_per_split - 1) / i_per_split;
+  const size_t need_out = (size_t)splits * count * row;
+  hipError_t e;
+  if (ws.words_out < need_out) {
+    if (ws.outT) (void)hipFree(ws.outT);
+    if ((e = hipMalloc((void **)&ws.outT, need_out * sizeof(uint64_t))) != hipSuccess) return e;
+    ws.words_out = need_out;
+  }
+  const dim3 grid(slices, splits, count);
+  if (compressed)
+    hipLaunchKernelGGL(tlwe_keyswitch_small_kernel<true>, grid, dim3(256), 0, s, ksk, in, in_stride, ws.outT, count, n_in, row, t, base_bit, i_per_split, seed, mask_words);
+  else
+    hipLaunchKernelGGL(tlwe_keyswitch_small_kernel<false>, grid, dim3(256), 0, s, ksk, in, in_stride, ws.outT, count, n_in, row, t, base_bit, i_per_split, seed, mask_words);
+  hipLaunchKernelGGL(tlwe_keyswitch_small_reduce_kernel, dim3(slices, count), dim3(256), 0, s, out, out_stride, ws.outT, in, in_stride, count, n_in, row, b_word, splits);
+  return hipGetLastError();
+}
+
 // Tile of 256 ciphertexts per workgroup for small digit sets (the table is cache resident), 512 for base_bit >= 3, where the
 // multi-gigabyte table is re-read once per tile (packing switch 5.3 -> 4.9 ms, lvl2 LWE switch 4.45 -> 4.16 ms; SET_1 prefers 256).
 inline hipError_t launch_tlwe_keyswitch(const uint64_t *ksk, uint64_t *out, size_t out_stride, const uint64_t *in, size_t in_stride, int count,
@@ -313,6 +377,10 @@ inline hipError_t launch_tlwe_keyswitch(const uint64_t *ksk, uint64_t *out, size
                                         uint64_t seed = 0) {
   // compressed keys: TRLWE rows (b_word = N or none) keep their b polynomial, LWE rows (b_word = row - 1) their one b word
   const int mask_words = !compressed ? 0 : (b_word == row - 1 ? row - 1 : row / 2);
+  // up to this many ciphertexts take the direct form (MOSFHET_KS_SMALL_MAX overrides, 0 disables): beyond it the tiled kernel's one pass over the table wins
+  static const int small_max = getenv("MOSFHET_KS_SMALL_MAX") ? atoi(getenv("MOSFHET_KS_SMALL_MAX")) : 16;
+  if (count <= small_max)
+    return launch_tlwe_keyswitch_small(ksk, out, out_stride, in, in_stride, count, n_in, row, b_word, t, base_bit, ws, s, compressed, seed, mask_words);
   static const int tile_env = getenv("MOSFHET_KS_TILE") ? atoi(getenv("MOSFHET_KS_TILE")) : 0;   // tuning: 256 or 512 ciphertexts per workgroup
   if (tile_env == 512 || (tile_env != 256 && base_bit >= 3))
     return launch_tlwe_keyswitch_nw<8>(ksk, out, out_stride, in, in_stride, count, n_in, row, b_word, t, base_bit, ws, s, compressed, seed, mask_words);
