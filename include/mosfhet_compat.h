@@ -354,6 +354,56 @@ void trlwe_packing_keyswitch(TRLWE out, TLWE *in, LUT_Packing_KS_Key ks_key);   
 void trlwe_save_packing_KS_key(FILE *fd, LUT_Packing_KS_Key key);                                            /* :243-262 (uncompressed rows) */
 LUT_Packing_KS_Key trlwe_load_new_packing_KS_key(FILE *fd);                                                  /* :264-296 */
 void free_trlwe_packing_ks_key(LUT_Packing_KS_Key key);                                                      /* :298-316 */
+/* ---- beyond the path: what the reference's own test-suite needs to link (csrc/host/mosfhet_compat_extra.c; compositions of the calls above) ---- */
+typedef struct _TRGSW_REG { TRGSW_DFT positive, negative; } *TRGSW_REG;                                      /* mosfhet.h:123-125 */
+TRGSW_REG trgsw_reg_alloc(int l, int Bg_bit, int k, int N);                                                  /* register.c:18-24 */
+TRGSW_REG *trgsw_reg_alloc_array(int count, int l, int Bg_bit, int k, int N);
+void trgsw_reg_sample(TRGSW_REG out, Torus m, TRGSW_Key key);
+void trgsw_reg_copy(TRGSW_REG out, TRGSW_REG in);
+void trgsw_reg_add(TRGSW_REG out, TRGSW_REG in1, TRGSW_REG in2);
+void trgsw_reg_negate(TRGSW_REG reg);
+void trgsw_reg_sub(TRGSW_REG out, TRGSW_REG in1, TRGSW_REG in2);
+void trgsw_reg_subto(TRGSW_REG out, TRGSW_REG in);
+void trgsw_reg_addto(TRGSW_REG out, TRGSW_REG in1);
+void free_trgsw_reg(TRGSW_REG p);
+void free_trgsw_reg_array(TRGSW_REG *p, int count);
+uint64_t _debug_trgsw_decrypt_exp_sample(TRGSW c, TRGSW_Key key);                                            /* trgsw.c:190-221 */
+uint64_t _debug_trgsw_decrypt_exp_DFT_sample(TRGSW_DFT c, TRGSW_Key key);                                    /* trgsw.c:243-268 */
+void trgsw_naive_mul_trlwe(TRLWE out, TRLWE in1, TRGSW in2);                                                 /* trgsw.c:456-473: exact */
+void trgsw_naive_mul(TRGSW out, TRGSW in1, TRGSW in2);                                                       /* trgsw.c:475-480 */
+TLWE_Key tlwe_new_bounded_key(int n, uint64_t bound, double sigma);                                          /* tlwe.c:70-78 */
+TRLWE_Key trlwe_new_bounded_key(int N, int k, uint64_t bound, double sigma);                                 /* trlwe.c:119-130 */
+TRLWE trlwe_new_compressed_sample(TorusPolynomial m, TRLWE_Key key);                                         /* here: an ordinary sample */
+void trlwe_compressed_subto(TRLWE out, TRLWE in);
+TRLWE_KS_Key trlwe_new_full_packing_KS_key(TRLWE_Key out_key, TLWE_Key in_key, int t, int base_bit);         /* keyswitch.c:98-106 */
+void trlwe_full_packing_keyswitch(TRLWE out, TLWE *in, uint64_t size, TRLWE_KS_Key ks_key);                  /* keyswitch.c:195-227 */
+TRLWE_KS_Key *trlwe_new_packing1_KS_key_CDKS21(TRLWE_Key out_key, TLWE_Key in_key, int t, int base_bit);     /* keyswitch.c:476-497 */
+void trlwe_packing1_keyswitch_CDKS21(TRLWE out, TLWE in, TRLWE_KS_Key *ks_key);                              /* keyswitch.c:526-546 */
+
+typedef int16_t Binary;                                                                                      /* mosfhet.h:29 */
+typedef struct _BinaryPolynomial { Binary *coeffs; int N; } *BinaryPolynomial;                               /* mosfhet.h:42-45 */
+BinaryPolynomial polynomial_new_binary_polynomial(int N);
+void polynomial_naive_mul_binary(BinaryPolynomial out, BinaryPolynomial in1, BinaryPolynomial in2);
+void polynomial_naive_mul_addto_torus_binary(TorusPolynomial out, TorusPolynomial in1, BinaryPolynomial in2);
+TRLWE_Key trlwe_new_ternary_key(int N, int k, int h, double sigma);                                          /* trlwe.c:158-165 */
+TRLWE_Key trlwe_new_sparse_ternary_key(int N, int k, int h, double sigma);
+TRLWE_Key trlwe_new_sparse_binary_key(int N, int k, int h, double sigma);
+TRLWE_Key trlwe_new_gaussian_key(int N, int k, double key_sigma, double noise_sigma);
+TRLWE_Key trlwe_new_sparse_gaussian_key(int N, int k, int h, double key_sigma, double noise_sigma);
+TRLWE_Key trlwe_new_sparse_generic_key(int N, int k, int h, uint64_t key_bound, double noise_sigma);
+TRLWE trlwe_load_new_compressed_sample(FILE *fd, int k, int N);
+void trlwe_load_compressed_sample(FILE *fd, TRLWE c);
+void trlwe_save_compressed_sample(FILE *fd, TRLWE c);
+void trlwe_compressed_DFT_sample(TRLWE_DFT out, TorusPolynomial m, TRLWE_Key key);
+TRLWE_DFT trlwe_new_compressed_DFT_sample(TorusPolynomial m, TRLWE_Key key);
+void trlwe_compressed_DFT_mul_addto(TRLWE_DFT out, DFT_Polynomial in1, TRLWE_DFT in2);
+void print_trlwe_msg(TRLWE in, uint64_t prec, TRLWE_Key key);                                                /* trlwe.c:333-342 */
+uint64_t _debug_trlwe_decrypt_exp_sample(TRLWE c, uint64_t prec, TRLWE_Key key);                             /* trlwe.c:344-370 */
+TRLWE_KS_Key trlwe_new_RLWE_priv_KS_key(TRLWE_Key out_key, TRLWE_Key in_key, TorusPolynomial v, int t, int base_bit);   /* keyswitch.c:574-608 */
+void trlwe_RLWE_priv_keyswitch(TRLWE out, TRLWE in, TRLWE_KS_Key ks_key);                                    /* keyswitch.c:64-96 */
+TRLWE_KS_Key *trlwe_new_gadget_to_RGSW_KS(TRLWE_Key key, int t, int base_bit);                               /* keyswitch.c:548-557 */
+void trgsw_from_gadget(TRGSW_DFT out, TRLWE *gadget, TRLWE_KS_Key *ksk);                                     /* keyswitch.c:559-571 */
+
 /* unfolded blind rotation on caller-held key material, and the automorphism key sets */
 void blind_rotate_unfolded(TRLWE tv, Torus *a, TRGSW *s, int size, int unfolding);                          /* bootstrap.c:124-149; s in new_bootstrap_key's su layout */
 void multivalue_bootstrap_UBR_phase1(TRGSW_DFT *out, TLWE in, Bootstrap_Key key);                           /* bootstrap.c:151-175; out: n / unfolding samples */

@@ -1761,3 +1761,131 @@ LUT_Packing_KS_Key trlwe_load_new_packing_KS_key(FILE *fd) {
   res->device = dev;
   return res;
 }
+
+/* ------------------------------------------------------------------ packing key switches built on the FFT key switch (src/keyswitch.c:98-106,195-227,476-546): needed
+ * by the reference's test-suite only; compositions of trlwe_keyswitch calls, one device key set behind the reference's key shapes */
+TRLWE_KS_Key trlwe_new_full_packing_KS_key(TRLWE_Key out_key, TLWE_Key in_key, int t, int base_bit) {
+  /* entry i switches the constant polynomial s_i: KS[i][j] = TRLWE(s_i 2^(64 - (j+1) base_bit)) */
+  const int N = out_key->s[0]->N, n = in_key->n;
+  if (out_key->k != 1) { fprintf(stderr, "mosfhet_amd: trlwe_new_full_packing_KS_key: k = 1 only\n"); abort(); }
+  Torus *msgs = (Torus *)mc_xmalloc(sizeof(Torus) * (size_t)n * N);
+  memset(msgs, 0, sizeof(Torus) * (size_t)n * N);
+  for (int i = 0; i < n; i++) msgs[(size_t)i * N] = in_key->s[i];
+  mosfhet_hip_gak_t dev = fft_ks_keys_new(out_key, msgs, n, t, base_bit, "trlwe_new_full_packing_KS_key");
+  free(msgs);
+  TRLWE_KS_Key res = trlwe_ks_header(dev, 0, 1, t, base_bit);
+  res->k = n;   /* the reference's key has k = n input "polynomials" (mosfhet.h:90-93) */
+  return res;
+}
+
+/* out = (0, sum_j in[j].b X^j) - sum_i KeySwitch_i(a_i(X)),  a_i(X) = sum_{j < size} in[j].a[i] X^j */
+void trlwe_full_packing_keyswitch(TRLWE out, TLWE *in, uint64_t size, TRLWE_KS_Key ks_key) {
+  const int N = out->b->N, n = ks_key->k;
+  TRLWE ai = trlwe_alloc_new_sample(1, N), part = trlwe_alloc_new_sample(1, N);
+  TRLWE_KS_Key entry = trlwe_ks_header(ks_key->device, 0, 0, ks_key->t, ks_key->base_bit);
+  trlwe_noiseless_trivial_sample(out, NULL);
+  for (int i = 0; i < n; i++) {
+    trlwe_noiseless_trivial_sample(ai, NULL);
+    for (uint64_t j = 0; j < size; j++) ai->a[0]->coeffs[j] = in[j]->a[i];
+    entry->entry = i;
+    trlwe_keyswitch(part, ai, entry);          /* (0, 0) - sum_j DFT(dec_j(a_i)) (.) KS[i][j] */
+    trlwe_addto(out, part);
+  }
+  for (uint64_t j = 0; j < size; j++) out->b->coeffs[j] += in[j]->b;
+  free(entry);
+  free_trlwe(ai);
+  free_trlwe(part);
+}
+
+TRLWE_KS_Key *trlwe_new_packing1_KS_key_CDKS21(TRLWE_Key out_key, TLWE_Key in_key, int t, int base_bit) {
+  const int N = out_key->s[0]->N;
+  int log_N = 0;
+  while ((1 << log_N) < N) log_N++;
+  TorusPolynomial padded = polynomial_new_torus_polynomial(N), perm = polynomial_new_torus_polynomial(N);
+  memset(padded->coeffs, 0, sizeof(Torus) * (size_t)N);
+  memcpy(padded->coeffs, in_key->s, sizeof(Torus) * (size_t)(in_key->n < N ? in_key->n : N));
+  Torus *msgs = (Torus *)mc_xmalloc(sizeof(Torus) * (size_t)log_N * N);
+  for (int j = 0; j < log_N; j++) {
+    polynomial_permute(perm, padded, ((uint64_t)1 << (log_N - j)) + 1);
+    memcpy(msgs + (size_t)j * N, perm->coeffs, sizeof(Torus) * (size_t)N);
+  }
+  mosfhet_hip_gak_t dev = fft_ks_keys_new(out_key, msgs, log_N, t, base_bit, "trlwe_new_packing1_KS_key_CDKS21");
+  free(msgs);
+  free_polynomial(padded);
+  free_polynomial(perm);
+  TRLWE_KS_Key *res = (TRLWE_KS_Key *)mc_xmalloc(sizeof(TRLWE_KS_Key) * (size_t)log_N);
+  for (int j = 0; j < log_N; j++) res[j] = trlwe_ks_header(dev, j, j == 0, t, base_bit);
+  return res;
+}
+
+void trlwe_packing1_keyswitch_CDKS21(TRLWE out, TLWE in, TRLWE_KS_Key *ks_key) {
+  const int N = out->b->N;
+  TRLWE tmp = trlwe_alloc_new_sample(1, N);
+  trlwe_noiseless_trivial_sample(out, NULL);
+  for (int i = 1; i < N; i++) out->a[0]->coeffs[N - i] = (Torus)0 - in->a[i];   /* the LWE mask as the polynomial whose constant term pairs with the key */
+  out->a[0]->coeffs[0] = in->a[0];
+  out->b->coeffs[0] = in->b;
+  for (int i = 1, j = 0; i < N; i <<= 1, j++) {   /* trace: sum over the automorphisms X -> X^(N / 2^j + 1) */
+    const uint64_t gen = (uint64_t)(N >> j) + 1;
+    polynomial_permute(tmp->a[0], out->a[0], gen);
+    polynomial_permute(tmp->b, out->b, gen);
+    trlwe_keyswitch(tmp, tmp, ks_key[j]);
+    trlwe_addto(out, tmp);
+  }
+  free_trlwe(tmp);
+}
+
+/* TRLWE(m) -> TRLWE(m v) for a fixed polynomial v (src/keyswitch.c:64-96,574-608): entry 0 switches from s_in v, entry 1 from v; then
+ * out = sum_j dec_j(in.b) KS1_j - sum_j dec_j(in.a) KS0_j, each sum one FFT key switch of a sample whose mask is the polynomial being decomposed */
+TRLWE_KS_Key trlwe_new_RLWE_priv_KS_key(TRLWE_Key out_key, TRLWE_Key in_key, TorusPolynomial v, int t, int base_bit) {
+  const int N = out_key->s[0]->N;
+  if (out_key->k != 1 || in_key->k != 1 || in_key->s[0]->N != N) { fprintf(stderr, "mosfhet_amd: trlwe_new_RLWE_priv_KS_key: k = 1 and one ring only\n"); abort(); }
+  Torus *msgs = (Torus *)mc_xmalloc(sizeof(Torus) * (size_t)2 * N);
+  memset(msgs, 0, sizeof(Torus) * (size_t)N);
+  negacyclic_mul_addto(msgs, v->coeffs, in_key->s[0]->coeffs, N);
+  memcpy(msgs + N, v->coeffs, sizeof(Torus) * (size_t)N);
+  mosfhet_hip_gak_t dev = fft_ks_keys_new(out_key, msgs, 2, t, base_bit, "trlwe_new_RLWE_priv_KS_key");
+  free(msgs);
+  return trlwe_ks_header(dev, 0, 1, t, base_bit);
+}
+
+void trlwe_RLWE_priv_keyswitch(TRLWE out, TRLWE in, TRLWE_KS_Key ks_key) {
+  const int N = out->b->N;
+  TRLWE src = trlwe_alloc_new_sample(1, N), as = trlwe_alloc_new_sample(1, N);
+  TRLWE_KS_Key entry = trlwe_ks_header(ks_key->device, 0, 0, ks_key->t, ks_key->base_bit);
+  trlwe_noiseless_trivial_sample(src, NULL);
+  memcpy(src->a[0]->coeffs, in->a[0]->coeffs, sizeof(Torus) * (size_t)N);
+  trlwe_keyswitch(as, src, entry);                 /* - sum_j dec_j(in.a) KS0_j */
+  memcpy(src->a[0]->coeffs, in->b->coeffs, sizeof(Torus) * (size_t)N);
+  entry->entry = 1;
+  trlwe_keyswitch(out, src, entry);                /* - sum_j dec_j(in.b) KS1_j */
+  trlwe_negate(out, out);
+  trlwe_addto(out, as);
+  free(entry);
+  free_trlwe(src);
+  free_trlwe(as);
+}
+
+TRLWE_KS_Key *trlwe_new_gadget_to_RGSW_KS(TRLWE_Key key, int t, int base_bit) {   /* one key per mask component: v = -s_i */
+  TRLWE_KS_Key *res = (TRLWE_KS_Key *)mc_xmalloc(sizeof(TRLWE_KS_Key) * (size_t)key->k);
+  TorusPolynomial neg = polynomial_new_torus_polynomial(key->s[0]->N);
+  for (int i = 0; i < key->k; i++) {
+    for (int j = 0; j < neg->N; j++) neg->coeffs[j] = (Torus)0 - key->s[i]->coeffs[j];
+    res[i] = trlwe_new_RLWE_priv_KS_key(key, key, neg, t, base_bit);
+  }
+  free_polynomial(neg);
+  return res;
+}
+
+/* the l gadget rows TRLWE(m 2^(64 - (i+1) Bg)) become a TRGSW_DFT(m): rows of component j through the key of -s_j, rows of b as they are */
+void trgsw_from_gadget(TRGSW_DFT out, TRLWE *gadget, TRLWE_KS_Key *ksk) {
+  const int k = out->samples[0]->k, N = out->samples[0]->b->N;
+  TRLWE tmp = trlwe_alloc_new_sample(k, N);
+  for (int j = 0; j < k; j++)
+    for (int i = 0; i < out->l; i++) {
+      trlwe_RLWE_priv_keyswitch(tmp, gadget[i], ksk[j]);
+      trlwe_to_DFT(out->samples[i + j * out->l], tmp);
+    }
+  for (int i = 0; i < out->l; i++) trlwe_to_DFT(out->samples[i + k * out->l], gadget[i]);
+  free_trlwe(tmp);
+}

@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256) void trlwe_table_keygen_kernel(uint64_t *__res
   extern __shared__ uint64_t sh[];   // a[N], then the indices of the set key bits (uint16) packed behind it
   uint64_t *a = sh;
   uint16_t *ones = reinterpret_cast<uint16_t *>(sh + N);
-  __shared__ int n_ones;
+  int16_t *vals = reinterpret_cast<int16_t *>(ones + N);   // the key's nonzero coefficients (binary keys: all 1; bounded keys: small integers)
+  __shared__ int n_ones, key_is_binary;
   const int tid = threadIdx.x;
   const size_t r = first_row + blockIdx.x;
   const int cands = (1 << base_bit) - 1;
@@ -74,10 +75,11 @@ __global__ __launch_bounds__(256) void trlwe_table_keygen_kernel(uint64_t *__res
   uint64_t *dst = compressed ? rows + r * (size_t)N : rows + r * 2 * (size_t)N;
   uint64_t *dst_b = compressed ? dst : dst + N;
   if (tid == 0) {
-    int c = 0;
+    int c = 0, binary = 1;
     for (int x = 0; x < N; x++)
-      if (s_out[x] & 1) ones[c++] = (uint16_t)x;
+      if (s_out[x]) { vals[c] = (int16_t)(int64_t)s_out[x]; binary &= s_out[x] == 1; ones[c++] = (uint16_t)x; }
     n_ones = c;
+    key_is_binary = binary;
   }
   for (int x = tid; x < N; x += 256) {
     const uint64_t ax = keygen_mix(seed, r, x, 0);
@@ -91,10 +93,18 @@ __global__ __launch_bounds__(256) void trlwe_table_keygen_kernel(uint64_t *__res
   const int cnt = n_ones;
   for (int x = tid; x < N; x += 256) {
     uint64_t acc = 0;
-    for (int q = 0; q < cnt; q++) {       // (a * s)[x] = sum over set bits p of +-a[x - p]  (negacyclic wrap)
-      const int p = ones[q], src = x - p;
-      const uint64_t w = a[src & (N - 1)];
-      acc += src < 0 ? (uint64_t)0 - w : w;
+    if (key_is_binary) {
+      for (int q = 0; q < cnt; q++) {       // (a * s)[x] = sum over set bits p of +-a[x - p]  (negacyclic wrap)
+        const int p = ones[q], src = x - p;
+        const uint64_t w = a[src & (N - 1)];
+        acc += src < 0 ? (uint64_t)0 - w : w;
+      }
+    } else {
+      for (int q = 0; q < cnt; q++) {       // general small coefficients (tlwe / trlwe_new_bounded_key)
+        const int p = ones[q], src = x - p;
+        const uint64_t w = a[src & (N - 1)] * (uint64_t)(int64_t)vals[q];
+        acc += src < 0 ? (uint64_t)0 - w : w;
+      }
     }
     acc += keygen_noise(nkey, seed, r, (uint64_t)x, sigma);
     if (kind == 0) { if (x == 0) acc += dec; }
@@ -112,30 +122,42 @@ __global__ __launch_bounds__(256) void trgsw_bk_keygen_kernel(uint64_t *__restri
   extern __shared__ uint64_t sh[];
   uint64_t *a = sh;
   uint16_t *ones = reinterpret_cast<uint16_t *>(sh + N);
-  __shared__ int n_ones;
+  int16_t *vals = reinterpret_cast<int16_t *>(ones + N);   // the key's nonzero coefficients (binary keys: all 1; bounded keys: small integers)
+  __shared__ int n_ones, key_is_binary;
   const int tid = threadIdx.x;
   const size_t r = blockIdx.x;
   const int q = (int)(r % (2 * l)), c = q / l, j = q % l;
   const size_t i = r / (2 * l);
   uint64_t *dst = rows + r * 2 * (size_t)N;
   if (tid == 0) {
-    int cnt = 0;
+    int cnt = 0, binary = 1;
     for (int x = 0; x < N; x++)
-      if (s_out[x] & 1) ones[cnt++] = (uint16_t)x;
+      if (s_out[x]) { vals[cnt] = (int16_t)(int64_t)s_out[x]; binary &= s_out[x] == 1; ones[cnt++] = (uint16_t)x; }
     n_ones = cnt;
+    key_is_binary = binary;
   }
   for (int x = tid; x < N; x += 256) a[x] = keygen_mix(seed, r, x, 0);
   __syncthreads();
   const uint64_t h = 1ull << (64 - (j + 1) * Bg_bit);
-  const int e = ga ? (int)(s_in[i] & 1) : 0;
-  const uint64_t val = ga ? h : s_in[i] * h;
+  // ga: TRGSW(X^{s_i}) for ANY integer key coefficient (bounded keys, src/bootstrap_ga.c:17-20 with tlwe_new_bounded_key): exponent mod 2N, X^N = -1
+  const int e_full = ga ? (int)(s_in[i] & (uint64_t)(2 * N - 1)) : 0;
+  const int e = e_full & (N - 1);
+  const uint64_t val = ga ? ((e_full & N) ? (uint64_t)0 - h : h) : s_in[i] * h;
   const int cnt = n_ones;
   for (int x = tid; x < N; x += 256) {
     uint64_t acc = 0;
-    for (int k = 0; k < cnt; k++) {
-      const int p = ones[k], src = x - p;
-      const uint64_t w = a[src & (N - 1)];
-      acc += src < 0 ? (uint64_t)0 - w : w;
+    if (key_is_binary) {
+      for (int k = 0; k < cnt; k++) {
+        const int p = ones[k], src = x - p;
+        const uint64_t w = a[src & (N - 1)];
+        acc += src < 0 ? (uint64_t)0 - w : w;
+      }
+    } else {
+      for (int k = 0; k < cnt; k++) {
+        const int p = ones[k], src = x - p;
+        const uint64_t w = a[src & (N - 1)] * (uint64_t)(int64_t)vals[k];
+        acc += src < 0 ? (uint64_t)0 - w : w;
+      }
     }
     acc += keygen_noise(nkey, seed, r, (uint64_t)x, sigma);
     dst[x] = a[x] + ((c == 0 && x == e) ? val : 0);     // the gadget goes on the mask AFTER b = a * s + e was formed from the plain mask
@@ -151,17 +173,19 @@ __global__ __launch_bounds__(256) void trlwe_poly_keygen_kernel(uint64_t *__rest
   extern __shared__ uint64_t sh[];
   uint64_t *a = sh;
   uint16_t *ones = reinterpret_cast<uint16_t *>(sh + N);
-  __shared__ int n_ones;
+  int16_t *vals = reinterpret_cast<int16_t *>(ones + N);   // the key's nonzero coefficients (binary keys: all 1; bounded keys: small integers)
+  __shared__ int n_ones, key_is_binary;
   const int tid = threadIdx.x;
   const size_t r = blockIdx.x;
   const int j = (int)(r % t);
   const size_t e = r / t;
   uint64_t *dst = rows + r * 2 * (size_t)N;
   if (tid == 0) {
-    int cnt = 0;
+    int cnt = 0, binary = 1;
     for (int x = 0; x < N; x++)
-      if (s_out[x] & 1) ones[cnt++] = (uint16_t)x;
+      if (s_out[x]) { vals[cnt] = (int16_t)(int64_t)s_out[x]; binary &= s_out[x] == 1; ones[cnt++] = (uint16_t)x; }
     n_ones = cnt;
+    key_is_binary = binary;
   }
   for (int x = tid; x < N; x += 256) {
     const uint64_t ax = keygen_mix(seed, r, x, 0);
@@ -172,10 +196,18 @@ __global__ __launch_bounds__(256) void trlwe_poly_keygen_kernel(uint64_t *__rest
   const int shift = 64 - (j + 1) * base_bit, cnt = n_ones;
   for (int x = tid; x < N; x += 256) {
     uint64_t acc = 0;
-    for (int k = 0; k < cnt; k++) {
-      const int p = ones[k], src = x - p;
-      const uint64_t w = a[src & (N - 1)];
-      acc += src < 0 ? (uint64_t)0 - w : w;
+    if (key_is_binary) {
+      for (int k = 0; k < cnt; k++) {
+        const int p = ones[k], src = x - p;
+        const uint64_t w = a[src & (N - 1)];
+        acc += src < 0 ? (uint64_t)0 - w : w;
+      }
+    } else {
+      for (int k = 0; k < cnt; k++) {
+        const int p = ones[k], src = x - p;
+        const uint64_t w = a[src & (N - 1)] * (uint64_t)(int64_t)vals[k];
+        acc += src < 0 ? (uint64_t)0 - w : w;
+      }
     }
     acc += keygen_noise(nkey, seed, r, (uint64_t)x, sigma);
     dst[N + x] = acc + (msgs[e * (size_t)N + x] << shift);
