@@ -404,6 +404,13 @@ void trlwe_RLWE_priv_keyswitch(TRLWE out, TRLWE in, TRLWE_KS_Key ks_key);       
 TRLWE_KS_Key *trlwe_new_gadget_to_RGSW_KS(TRLWE_Key key, int t, int base_bit);                               /* keyswitch.c:548-557 */
 void trgsw_from_gadget(TRGSW_DFT out, TRLWE *gadget, TRLWE_KS_Key *ksk);                                     /* keyswitch.c:559-571 */
 
+typedef struct _TLWE_KS_Key_m { TLWE **s; int base_bit, t, n;                                                /* mosfhet.h:67-70 */
+                                void *device; int n_out; } *TLWE_KS_Key_m;                                    /* + device rows (appended); s is NULL */
+TLWE_KS_Key_m tlwe_new_KS_key_no_precomp(TLWE_Key out_key, TLWE_Key in_key, int t, int base_bit);            /* tlwe.c:214-230 */
+void tlwe_keyswitch_no_precomp(TLWE out, TLWE in, TLWE_KS_Key_m ks_key);                                     /* tlwe.c:305-320 */
+void polynomial_full_mul_with_scale(TorusPolynomial out, TorusPolynomial in1, TorusPolynomial in2, int bit_size, int bit_scale);   /* polynomial.c:428-437: exact */
+void trlwe_tensor_prod(TRLWE out, TRLWE in1, TRLWE in2, int precision, TRLWE_KS_Key rl_key);                 /* trlwe.c:692-713 */
+
 /* unfolded blind rotation on caller-held key material, and the automorphism key sets */
 void blind_rotate_unfolded(TRLWE tv, Torus *a, TRGSW *s, int size, int unfolding);                          /* bootstrap.c:124-149; s in new_bootstrap_key's su layout */
 void multivalue_bootstrap_UBR_phase1(TRGSW_DFT *out, TLWE in, Bootstrap_Key key);                           /* bootstrap.c:151-175; out: n / unfolding samples */

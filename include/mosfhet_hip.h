@@ -272,6 +272,10 @@ int mosfhet_hip_ksk_export_rows(mosfhet_hip_ksk_t ksk, size_t first_row, size_t 
  * kernel from (seed, row, word).  Results are bit-identical to the uncompressed key's.  ksk_export_rows expands the rows. */
 int mosfhet_hip_trlwe_table_ksk_generate_compressed(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t *out, int kind, const uint64_t *h_s_out, int N,
                                                     const uint64_t *h_s_in, int n, int t, int base_bit, double sigma, uint64_t seed);
+/* tlwe_keyswitch_no_precomp (src/tlwe.c:305-320): key = plain device rows [n_in][t][n_out + 1], one sample per (input word, digit position), multiplied by the
+ * digit in the kernel (the reference's double rounding offset included) */
+int mosfhet_hip_tlwe_keyswitch_no_precomp_batch(mosfhet_hip_ctx_t ctx, const uint64_t *d_rows, uint64_t *d_out, const uint64_t *d_in, int count, int n_in, int n_out,
+                                                int t, int base_bit, void *stream);
 /* LUT-packing key switch (trlwe_new_packing_KS_key / trlwe_packing_keyswitch, src/keyswitch.c:214-241,346-366): `torus_base` LWE samples into the `torus_base`
  * slots of one TRLWE sample.  The key is a table key with n * torus_base digit sources (ksk kind 2: export / import / alloc as such);
  * d_in [count][torus_base][n + 1], d_out [count][2][N]. */

@@ -267,3 +267,76 @@ TRLWE_DFT trlwe_new_compressed_DFT_sample(TorusPolynomial m, TRLWE_Key key) {
   return out;
 }
 void trlwe_compressed_DFT_mul_addto(TRLWE_DFT out, DFT_Polynomial in1, TRLWE_DFT in2) { trlwe_DFT_mul_addto_by_polynomial(out, in2, in1); }
+
+/* ------------------------------------------------------------------ key switch without precomputed multiples (src/tlwe.c:214-230,305-320): one sample per (input
+ * word, digit position); the digit multiplies it on the device (mosfhet_hip_tlwe_keyswitch_no_precomp_batch).  The rows live in device memory: `s` is NULL. */
+TLWE_KS_Key_m tlwe_new_KS_key_no_precomp(TLWE_Key out_key, TLWE_Key in_key, int t, int base_bit) {
+  const int n_in = in_key->n, n_out = out_key->n;
+  TLWE_KS_Key_m key = (TLWE_KS_Key_m)mc_xmalloc(sizeof(*key));
+  key->s = NULL; key->base_bit = base_bit; key->t = t; key->n = n_in; key->n_out = n_out;
+  const size_t row = (size_t)n_out + 1, words = (size_t)n_in * t * row;
+  Torus *h = (Torus *)mc_xmalloc(sizeof(Torus) * words);
+  TLWE c = tlwe_alloc_sample(n_out);
+  for (int i = 0; i < n_in; i++)
+    for (int j = 0; j < t; j++) {
+      tlwe_sample(c, in_key->s[i] * ((Torus)1 << (W - (j + 1) * base_bit)), out_key);
+      memcpy(h + ((size_t)i * t + j) * row, c->a, sizeof(Torus) * (size_t)n_out);
+      h[((size_t)i * t + j) * row + n_out] = c->b;
+    }
+  free_tlwe(c);
+  (void)mosfhet_engine_ctx();
+  key->device = mc_dev_alloc(sizeof(Torus) * words);
+  mc_dev_copy(key->device, h, sizeof(Torus) * words, HIP_H2D);
+  free(h);
+  return key;
+}
+
+void tlwe_keyswitch_no_precomp(TLWE out, TLWE in, TLWE_KS_Key_m key) {
+  mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
+  const int n_in = key->n, n_out = key->n_out;
+  const size_t in_w = (size_t)n_in + 1, out_w = (size_t)n_out + 1;
+  Torus *h = (Torus *)mc_hstage_alloc(sizeof(Torus) * (in_w + out_w)), *d = (Torus *)mc_stage_alloc(sizeof(Torus) * (in_w + out_w));
+  memcpy(h, in->a, sizeof(Torus) * (size_t)n_in);
+  h[n_in] = in->b;
+  mc_dev_copy(d, h, sizeof(Torus) * in_w, HIP_H2D);
+  if (mosfhet_hip_tlwe_keyswitch_no_precomp_batch(ctx, (const uint64_t *)key->device, d + in_w, d, 1, n_in, n_out, key->t, key->base_bit, NULL) || mosfhet_hip_ctx_sync(ctx, NULL))
+    mc_die("tlwe_keyswitch_no_precomp");
+  mc_dev_copy(h + in_w, d + in_w, sizeof(Torus) * out_w, HIP_D2H);
+  memcpy(out->a, h + in_w, sizeof(Torus) * (size_t)n_out);
+  out->b = h[in_w + n_out];
+  mc_hstage_free(h);
+}
+
+/* ------------------------------------------------------------------ exact 128-bit products (src/polynomial.c:428-437, src/fft/karatsuba.c:92-102): the full product of the
+ * two coefficient vectors in arithmetic mod 2^128, every coefficient shifted right by bit_scale, THEN folded negacyclically.  The reference multiplies by
+ * Karatsuba; Karatsuba's identities hold in Z / 2^128, so the schoolbook product below gives the same words. */
+void polynomial_full_mul_with_scale(TorusPolynomial out, TorusPolynomial in1, TorusPolynomial in2, int bit_size, int bit_scale) {
+  (void)bit_size;
+  const int N = in1->N;
+  unsigned __int128 *prod = (unsigned __int128 *)mc_xmalloc(sizeof(unsigned __int128) * (size_t)2 * N);
+  memset(prod, 0, sizeof(unsigned __int128) * (size_t)2 * N);
+  for (int i = 0; i < N; i++) {
+    const unsigned __int128 x = in1->coeffs[i];
+    if (!x) continue;
+    for (int j = 0; j < N; j++) prod[i + j] += x * in2->coeffs[j];
+  }
+  for (int i = 0; i < N; i++) out->coeffs[i] = (Torus)(prod[i] >> bit_scale) - (Torus)(prod[N + i] >> bit_scale);
+  free(prod);
+}
+
+/* src/trlwe.c:692-713: tensor product of two samples with those exact products, relinearised by one FFT key switch */
+void trlwe_tensor_prod(TRLWE out, TRLWE in1, TRLWE in2, int precision, TRLWE_KS_Key rl_key) {
+  const int N = in1->b->N, scale = W - precision;
+  TorusPolynomial tmp = polynomial_new_torus_polynomial(N);
+  TRLWE t = trlwe_alloc_new_sample(1, N);
+  polynomial_full_mul_with_scale(t->a[0], in1->a[0], in2->a[0], W, scale);
+  memset(t->b->coeffs, 0, sizeof(Torus) * (size_t)N);
+  polynomial_full_mul_with_scale(out->a[0], in1->a[0], in2->b, W, scale);
+  polynomial_full_mul_with_scale(tmp, in1->b, in2->a[0], W, scale);
+  polynomial_addto_torus_polynomial(out->a[0], tmp);
+  polynomial_full_mul_with_scale(out->b, in1->b, in2->b, W, scale);
+  trlwe_keyswitch(t, t, rl_key);
+  trlwe_subto(out, t);
+  free_polynomial(tmp);
+  free_trlwe(t);
+}

@@ -370,6 +370,48 @@ inline hipError_t launch_tlwe_keyswitch_small(const uint64_t *ksk, uint64_t *out
   return hipGetLastError();
 }
 
+// tlwe_keyswitch_no_precomp (src/tlwe.c:305-320): the key holds ONE sample per (input word, digit position), TLWE(s_i 2^(64 - (j+1) bb)), and the digit
+// multiplies it:  out = (0, b) - sum_{i,j} digit_ij KS[i][j].  The reference adds the rounding offset 2^(63 - t bb) twice before it cuts the digits (:314,316);
+// so does this.  Same work split as tlwe_keyswitch_small_kernel; partial sums finished by tlwe_keyswitch_small_reduce_kernel.
+__global__ __launch_bounds__(256) void tlwe_keyswitch_scaled_kernel(const uint64_t *__restrict__ ksk, const uint64_t *__restrict__ in, size_t in_stride,
+                                                                   uint64_t *__restrict__ part, int count, int n_in, int row, int t, int base_bit, int i_per_split) {
+  const int w = blockIdx.x * 256 + threadIdx.x, split = blockIdx.y, ct = blockIdx.z;
+  const uint32_t mask = (1u << base_bit) - 1;
+  const uint64_t round_off = 2 * (1ull << (63 - base_bit * t));
+  const int i_begin = split * i_per_split, i_end = (i_begin + i_per_split < n_in) ? i_begin + i_per_split : n_in;
+  const uint64_t *__restrict__ a_words = in + (size_t)ct * in_stride;
+  uint64_t acc = 0;
+  if (w < row)
+    for (int i = i_begin; i < i_end; i++) {
+      const uint64_t a = a_words[i] + round_off;
+      for (int j = 0; j < t; j++) {
+        const uint64_t v = (uint32_t)(a >> (64 - (j + 1) * base_bit)) & mask;
+        acc -= v * ksk[((size_t)i * t + j) * (size_t)row + w];
+      }
+    }
+  if (w < row) part[((size_t)split * count + ct) * row + w] = acc;
+}
+
+inline hipError_t launch_tlwe_keyswitch_scaled(const uint64_t *ksk, uint64_t *out, size_t out_stride, const uint64_t *in, size_t in_stride, int count, int n_in, int row,
+                                               int t, int base_bit, KsWorkspace &ws, hipStream_t s) {
+  const int slices = (row + 255) / 256;
+  int splits = (1024 + slices * count - 1) / (slices * count);
+  if (splits > n_in / 4) splits = n_in / 4;
+  if (splits < 1) splits = 1;
+  const int i_per_split = (n_in + splits - 1) / splits;
+  splits = (n_in + i_per_split - 1) / i_per_split;
+  const size_t need_out = (size_t)splits * count * row;
+  hipError_t e;
+  if (ws.words_out < need_out) {
+    if (ws.outT) (void)hipFree(ws.outT);
+    if ((e = hipMalloc((void **)&ws.outT, need_out * sizeof(uint64_t))) != hipSuccess) return e;
+    ws.words_out = need_out;
+  }
+  hipLaunchKernelGGL(tlwe_keyswitch_scaled_kernel, dim3(slices, splits, count), dim3(256), 0, s, ksk, in, in_stride, ws.outT, count, n_in, row, t, base_bit, i_per_split);
+  hipLaunchKernelGGL(tlwe_keyswitch_small_reduce_kernel, dim3(slices, count), dim3(256), 0, s, out, out_stride, ws.outT, in, in_stride, count, n_in, row, row - 1, splits);
+  return hipGetLastError();
+}
+
 // Tile of 256 ciphertexts per workgroup for small digit sets (the table is cache resident), 512 for base_bit >= 3, where the
 // multi-gigabyte table is re-read once per tile (packing switch 5.3 -> 4.9 ms, lvl2 LWE switch 4.45 -> 4.16 ms; SET_1 prefers 256).
 inline hipError_t launch_tlwe_keyswitch(const uint64_t *ksk, uint64_t *out, size_t out_stride, const uint64_t *in, size_t in_stride, int count,

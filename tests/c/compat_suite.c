@@ -916,6 +916,36 @@ static void case_legacy_helpers(void) {
   for (int j = N - 1; j >= 0; j--) free_trlwe_ks_key(aks[j]);
   free(aks);
   free_trlwe_ks_key(aks2[1]); free_trlwe_ks_key(aks2[0]); free(aks2);
+  /* --- the exact tensor product next to the FFT one (test_trlwe_mul, test/tests.c:1334-1372: 4-bit messages on the constant terms, product mod 16) */
+  {
+    TRLWE_KS_Key rlk = trlwe_new_RL_key(wkey, 2, 20);
+    TRLWE p1 = trlwe_new_sample(NULL, wkey), p2 = trlwe_new_sample(NULL, wkey), po = trlwe_alloc_new_sample(k, N);
+    TLWE px = tlwe_alloc_sample(N);
+    for (int a = 3; a <= 13; a += 5) {
+      const int b = 7;
+      trlwe_sample(p1, NULL, wkey); trlwe_sample(p2, NULL, wkey);
+      p1->b->coeffs[0] += int2torus(a, 4);
+      p2->b->coeffs[0] += int2torus(b, 4);
+      trlwe_tensor_prod(po, p1, p2, 4, rlk);
+      trlwe_extract_tlwe(px, po, 0);
+      CHECK((int)torus2int(tlwe_phase(px, wkey_extracted), 4) == ((a * b) & 15), "trlwe_tensor_prod: %d * %d", a, b);
+      trlwe_tensor_prod_FFT(po, p1, p2, 4, rlk);
+      trlwe_extract_tlwe(px, po, 0);
+      CHECK((int)torus2int(tlwe_phase(px, wkey_extracted), 4) == ((a * b) & 15), "trlwe_tensor_prod_FFT: %d * %d", a, b);
+    }
+    free_trlwe(p1); free_trlwe(p2); free_trlwe(po); free_tlwe(px); free_trlwe_ks_key(rlk);
+  }
+  /* --- key switch without precomputed multiples (test_tlwe_ks's shape, test/tests.c:751-790, through tlwe_new_KS_key_no_precomp) */
+  {
+    TLWE_KS_Key_m mk = tlwe_new_KS_key_no_precomp(lwe_key, wkey_extracted, 8, 2);
+    TLWE big = tlwe_alloc_sample(N), small = tlwe_alloc_sample(n);
+    for (int j = 0; j < 4; j++) {
+      tlwe_sample(big, double2torus(j / 8.), wkey_extracted);
+      tlwe_keyswitch_no_precomp(small, big, mk);
+      WITHIN(1ULL << 58, double2torus(j / 8.), tlwe_phase(small, lwe_key), "tlwe_keyswitch_no_precomp");
+    }
+    free_tlwe(big); free_tlwe(small);
+  }
   /* --- unfolded blind rotation: the legacy entry points on caller-held objects */
   Torus lut[4] = {int2torus(3, 4), int2torus(7, 4), int2torus(11, 4), int2torus(15, 4)};
   TRLWE tv = trlwe_alloc_new_sample(k, N), acc = trlwe_alloc_new_sample(k, N);

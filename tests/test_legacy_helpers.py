@@ -237,3 +237,22 @@ def test_trgsw_torus_helpers_match_the_reference(libs, Bg_bit, l):
             return get_trgsw(out)
         got = both(libs, run)
         assert got[0, 0, 0] == np.uint64((m << (64 - Bg_bit)) % 2 ** 64) and not got[0, 1].any()
+
+
+def test_exact_128_bit_product_matches_the_reference(libs):
+    """polynomial_full_mul_with_scale (src/polynomial.c:428-437): the reference multiplies by Karatsuba in 128-bit arithmetic, this library by the
+    schoolbook product in the same ring -- identical words, for full-range 64-bit coefficients and every scale the tensor product uses.  Coefficient N - 1
+    is the exception: the reference subtracts product term 2N - 1, one element PAST its (2N - 1)-entry buffer (src/fft/karatsuba.c:55,100: whatever the heap
+    holds there); that term of a product of two degree-(N - 1) polynomials is 0, which is what this library subtracts and what exact arithmetic gives."""
+    rng = np.random.default_rng(5)
+    x, y = rnd(rng, N), rnd(rng, N)
+    xi, yi = [int(v) for v in x], [int(v) for v in y]
+    for scale in (0, 1, 32, 60, 63):
+        def run(lib):
+            out = lib.poly(np.zeros(N, dtype=np.uint64))
+            lib.l.polynomial_full_mul_with_scale(out, lib.poly(x), lib.poly(y), 64, scale)
+            return get_poly(out)
+        got, want = run(libs[0]), run(libs[1])
+        assert (got[:N - 1] == want[:N - 1]).all()
+        top = sum(xi[j] * yi[N - 1 - j] for j in range(N)) % 2 ** 128          # product term N - 1; term 2N - 1 is zero
+        assert int(got[N - 1]) == (top >> scale) % 2 ** 64
