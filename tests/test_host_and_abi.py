@@ -117,6 +117,22 @@ def test_reference_application_relinks_unchanged(native_lib):
             assert name in und and name in exported, (prog, name)
 
 
+def test_host_helpers_are_clean_under_sanitizers(native_lib, tmp_path):
+    """The host layer's sources compiled with -fsanitize=address,undefined (+ leak check) into a program that calls every host-only helper once
+    (tests/c/host_helpers.c): no report, every allocation freed."""
+    import subprocess
+    host = os.path.join(ROOT, "mosfhet_amd", "csrc", "host")
+    srcs = [os.path.join(host, f) for f in ("mosfhet_compat.c", "mosfhet_compat_dft.c", "mosfhet_compat_multi.c", "mosfhet_compat_legacy.c", "mosfhet_compat_extra.c", "csprng.c")]
+    exe = str(tmp_path / "host_helpers")
+    subprocess.check_call(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize=shift", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "mosfhet_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "c", "host_helpers.c")] + srcs +
+                          ["-o", exe, "-L" + os.path.join(ROOT, "mosfhet_amd"), "-lmosfhet_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lm", "-lpthread",
+                           "-Wl,-rpath," + os.path.join(ROOT, "mosfhet_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert r.returncode == 0 and "host helpers ok" in r.stdout and "ERROR" not in r.stdout and "runtime error" not in r.stdout, r.stdout[-3000:]
+    assert "exponent of TRGSW(X^5): 5" in r.stdout
+
+
 def test_no_cpu_fallback(native_lib):
     import torch
     import mosfhet_amd as ma
