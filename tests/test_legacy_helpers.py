@@ -256,3 +256,52 @@ def test_exact_128_bit_product_matches_the_reference(libs):
         assert (got[:N - 1] == want[:N - 1]).all()
         top = sum(xi[j] * yi[N - 1 - j] for j in range(N)) % 2 ** 128          # product term N - 1; term 2N - 1 is zero
         assert int(got[N - 1]) == (top >> scale) % 2 ** 64
+
+
+def test_oracle_lut_packing_keyswitch_is_the_references(libs, oracle):
+    """Pins oracle.trlwe_lut_packing_keyswitch (the checker of the device kernel, tests/test_gpu_parity.py::test_lut_packing_keyswitch_bit_exact) to the
+    reference's trlwe_packing_keyswitch (src/keyswitch.c:346-366): a key made by the REFERENCE's trlwe_new_packing_KS_key, its rows expanded through the
+    reference's own trlwe_compressed_subto (0 - row), the same LWE inputs through both: identical TRLWE samples, bit for bit."""
+    ref = libs[1]
+    L = ref.l
+    Nn, n, t, bb, tb = 256, 6, 3, 2, 4
+    cands = (1 << bb) - 1
+
+    class TlweKey(C.Structure):
+        _fields_ = [("s", C.POINTER(C.c_uint64)), ("n", C.c_int), ("sigma", C.c_double)]
+
+    class Tlwe(C.Structure):
+        _fields_ = [("a", C.POINTER(C.c_uint64)), ("b", C.c_uint64), ("n", C.c_int)]
+
+    class PackKey(C.Structure):
+        _fields_ = [("s", C.POINTER(C.POINTER(C.POINTER(C.POINTER(C.POINTER(Trlwe)))))), ("base_bit", C.c_int), ("t", C.c_int), ("torus_base", C.c_int), ("n", C.c_int)]
+
+    L.tlwe_new_binary_key.restype = C.POINTER(TlweKey)
+    L.tlwe_new_binary_key.argtypes = [C.c_int, C.c_double]
+    L.trlwe_new_binary_key.restype = C.c_void_p
+    L.trlwe_new_binary_key.argtypes = [C.c_int, C.c_int, C.c_double]
+    L.trlwe_new_packing_KS_key.restype = C.POINTER(PackKey)
+    L.trlwe_new_packing_KS_key.argtypes = [C.c_void_p, C.POINTER(TlweKey), C.c_int, C.c_int, C.c_int]
+    L.tlwe_new_sample.restype = C.POINTER(Tlwe)
+    L.tlwe_new_sample.argtypes = [C.c_uint64, C.POINTER(TlweKey)]
+    L.trlwe_packing_keyswitch.argtypes = [C.POINTER(Trlwe), C.POINTER(C.POINTER(Tlwe)), C.POINTER(PackKey)]
+    L.trlwe_compressed_subto.argtypes = [C.POINTER(Trlwe), C.POINTER(Trlwe)]
+    in_key = L.tlwe_new_binary_key(n, 1e-9)
+    out_key = L.trlwe_new_binary_key(Nn, 1, 1e-12)
+    key = L.trlwe_new_packing_KS_key(out_key, in_key, t, bb, tb)
+    rows = np.empty((n, tb, t, cands, 2, Nn), dtype=np.uint64)
+    for i in range(n):
+        for e in range(tb):
+            for j in range(t):
+                for v in range(cands):
+                    acc = ref.trlwe(np.zeros((2, Nn), dtype=np.uint64))
+                    L.trlwe_compressed_subto(acc, key.contents.s[i][e][j][v])
+                    rows[i, e, j, v] = (np.uint64(0) - get_trlwe(acc))
+    rng = np.random.default_rng(6)
+    for _ in range(3):
+        msgs = rnd(rng, tb)
+        cts = (C.POINTER(Tlwe) * tb)(*[L.tlwe_new_sample(C.c_uint64(int(m)), in_key) for m in msgs])
+        flat = np.stack([np.concatenate([np.ctypeslib.as_array(c.contents.a, (n,)).copy(), np.array([c.contents.b], dtype=np.uint64)]) for c in cts])
+        out = ref.trlwe(np.zeros((2, Nn), dtype=np.uint64))
+        L.trlwe_packing_keyswitch(out, cts, key)
+        assert (get_trlwe(out) == oracle.trlwe_lut_packing_keyswitch(flat, rows, bb)).all()
