@@ -349,7 +349,11 @@ int mosfhet_hip_time_programmable_bootstrap(mosfhet_hip_ctx_t ctx, mosfhet_hip_b
 
 /* Secret of the on-device key generators (bsk_generate, *_ksk_generate): the 256-bit ChaCha20 key their NOISE terms are drawn under.  It is independent
  * of the public 64-bit mask seed those calls take (masks are public and regenerable from that seed; noise is not).  Drawn from the operating system at
- * first use unless set here (32 bytes); process-wide. */
+ * first use unless set here (32 bytes); process-wide.
+ * Every generate call draws its noise under a ChaCha20 nonce no other call under this secret gets (a call counter and the generator kind), so the
+ * `seed` arguments need NOT be unique: two keys made with the same seed share their masks, never their noise.  Setting the secret restarts that
+ * sequence -- the same secret followed by the same generate calls reproduces the same keys (reproducible test runs; the host layer does this under
+ * mosfhet_seed).  Never install one secret twice for keys that go to different parties. */
 int mosfhet_hip_set_keygen_secret(const void *key32);
 
 /* ---- DFT-level entry points behind the reference's legacy signatures (mosfhet.h:179-182,263-264,342-344,454,296 of the reference; csrc/capi_dft.inc).

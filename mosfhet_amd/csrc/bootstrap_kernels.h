@@ -764,8 +764,8 @@ __device__ __forceinline__ void ks_rows_rt(const uint64_t (&dd_lo)[8], const uin
 // the overflow in the accumulation registers there is no scratch (two per SIMD: 388 bytes of it).  The kernel is 0.16 ms of a 38 ms circuit bootstrap.
 template <class F>
 __global__ __launch_bounds__(F::THREADS, 1) void trlwe_fft_keyswitch_kernel(const d2 *__restrict__ ks0, const d2 *__restrict__ ks1,
-                                                                          const d2 *__restrict__ tw, const uint64_t *__restrict__ in,
-                                                                          size_t in_stride, uint64_t *__restrict__ out, size_t out_stride,
+                                                                          const d2 *__restrict__ tw, const uint64_t *in,
+                                                                          size_t in_stride, uint64_t *out, size_t out_stride,   // in place is relied upon (src/trlwe.c:780): no __restrict__
                                                                           int t, int base_bit, int mode,
                                                                           const uint64_t *__restrict__ base = nullptr, size_t base_stride = 0) {
   constexpr int N = F::N, M = F::M, T = F::THREADS;
@@ -895,6 +895,9 @@ __global__ __launch_bounds__(F::THREADS) void dft_to_torus_kernel(const d2 *__re
 #ifndef EP_ONE_K
 #define EP_ONE_K false
 #endif
+#ifndef EP_PIPE_ALL
+#define EP_PIPE_ALL false   // experiment switch (tools/ab/ep_ab.hip): the software-pipelined unit loop on every ring
+#endif
 #ifdef MOSFHET_EP_NO_NT
 #define EP_NT_LOAD(p) (*(p))
 #define EP_NT_STORE(v, p) (*(p) = (v))
@@ -902,11 +905,14 @@ __global__ __launch_bounds__(F::THREADS) void dft_to_torus_kernel(const d2 *__re
 #define EP_NT_LOAD(p) __builtin_nontemporal_load(p)
 #define EP_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
 #endif
+#ifndef EP_MIN_WAVES
+#define EP_MIN_WAVES 2
+#endif
 template <class F, int L, int BG, bool CMUX>
-__global__ __launch_bounds__(F::THREADS, 2) void external_product_kernel(const d2 *__restrict__ bkrow0, const d2 *__restrict__ tw,
-                                                                       const uint64_t *__restrict__ in, uint64_t *__restrict__ out, int Bg_bit_rt, int count,
+__global__ __launch_bounds__(F::THREADS, EP_MIN_WAVES) void external_product_kernel(const d2 *__restrict__ bkrow0, const d2 *__restrict__ tw,
+                                                                       const uint64_t *__restrict__ in, uint64_t *out, int Bg_bit_rt, int count,
                                                                        size_t key_stride = 0, size_t in_stride = 2 * F::N,
-                                                                       const uint64_t *__restrict__ in0 = nullptr, d2 *__restrict__ out_dft = nullptr) {
+                                                                       const uint64_t *in0 = nullptr, d2 *__restrict__ out_dft = nullptr) {   // out may alias in0 (CMUX in place): neither is __restrict__
   constexpr int N = F::N, M = F::M, T = F::THREADS;
   using D = Digits<L, BG>;
   // rounding without the reduction mod 1 where the gadget bounds the sums (see pbs_kernel)
@@ -947,10 +953,16 @@ __global__ __launch_bounds__(F::THREADS, 2) void external_product_kernel(const d
 #pragma unroll
     for (int m = 0; m < 8; m++) D::pack(w_lo[m], w_hi[m], ext[m], raw_lo[m] + off, raw_hi[m] + off);
   };
-  if constexpr (T > 64) {
-    // Rings of two or four wavefronts per team keep the plain structure -- component loop rolled, each component requested where it is used.  (The
-    // pipelined form below gave intermittently wrong outputs at N = 4096 in the parity tests and is confined to the one-wavefront ring, where it is
-    // measured and where the team needs no workgroup barriers.)
+  if constexpr (T > 64 && !EP_PIPE_ALL) {
+    // Rings of two or four wavefronts per team keep the plain structure -- component loop rolled, each component requested where it is used.  The
+    // pipelined form below is (a) not faster there (lvl2: 0.509 vs 0.488 ms per 16,384 units, SET_2: 0.249-0.292 vs 0.237-0.243 ms: these teams are
+    // issue-bound, and the first key-row wait of a unit waits for the older ciphertext loads too) and (b) gave intermittently wrong units on every such
+    // ring at l = 1 (1-2 % of the units, whole units, never from the first workgroup of a CU).  Round-3 diagnosis (experiments/README.md): only builds
+    // whose register spills went to scratch fail (the spilled values are the in-flight ciphertext words); the same source with one wavefront per SIMD
+    // (no spills), with the next unit's request moved behind the rows (no spills) or with every wait forced to zero passes; the compiler's vmcnt
+    // counts are consistent with in-order completion (tools/ab/wcheck.py) and neither scratch integrity nor load order fail in isolation
+    // (tools/ubench/scratch_check.hip, vmcnt_order.hip).  Not root-caused further; the form stays confined to the one-wavefront ring, whose
+    // instantiations are checked unit by unit against the oracle at batch sizes beyond the grid (tests/test_gpu_parity.py).
     for (size_t u = blockIdx.x; u < (size_t)count; u += gridDim.x) {
       const d2 *__restrict__ bkrow = bkrow0 + u * key_stride;
       double o_re[2][8], o_im[2][8];
@@ -1033,8 +1045,8 @@ __global__ __launch_bounds__(F::THREADS, 2) void external_product_kernel(const d
 // ds_read_b128 instead of 64 KiB of L2 traffic per unit behind the HBM loads in the wavefront's in-order memory queue.  l <= 2.
 template <int L, int BG, bool CMUX>
 __global__ __launch_bounds__(512, 2) void external_product_ldskey_kernel(const d2 *__restrict__ bkrow0, const d2 *__restrict__ tw, const uint64_t *__restrict__ in,
-                                                                       uint64_t *__restrict__ out, int Bg_bit_rt, int count, size_t in_stride,
-                                                                       const uint64_t *__restrict__ in0, d2 *__restrict__ out_dft) {
+                                                                       uint64_t *out, int Bg_bit_rt, int count, size_t in_stride,
+                                                                       const uint64_t *in0, d2 *__restrict__ out_dft) {   // out may alias in0: no __restrict__
   using F = Fft1024;
   constexpr int N = F::N, M = F::M, T = 64, TEAMS = 8;
   using D = Digits<L, BG>;
@@ -1113,7 +1125,7 @@ __global__ __launch_bounds__(512, 2) void external_product_ldskey_kernel(const d
 }
 
 // polynomial_mul_DFT / polynomial_mul_addto_DFT on slot-ordered arrays [src/polynomial.c:379-426]
-__global__ void dft_mul_kernel(d2 *__restrict__ out, const d2 *__restrict__ a, const d2 *__restrict__ b, size_t count,
+__global__ void dft_mul_kernel(d2 *out, const d2 *a, const d2 *b, size_t count,   // out may be a or b
                                int addto) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;

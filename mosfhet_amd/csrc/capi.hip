@@ -327,7 +327,12 @@ static int resident_teams(int threads) {
 
 template <class F>
 static void launch_external_product(int l, int Bg_bit, hipStream_t s, const d2 *row, const d2 *tw, const uint64_t *d_in, uint64_t *d_out, int count, size_t key_stride,
-                                    size_t in_stride, const uint64_t *d_in0, d2 *d_out_dft) {
+                                    size_t in_stride, const uint64_t *d_in0, d2 *d_out_dft, bool bounded) {
+  // bounded: every key coefficient is the transform of torus words (|x| <= 2^63: keys this library transformed itself).  Only then may the compile-time
+  // 2 x 2^8 gadget skip the reduction mod 1 in its rounding (pbs_kernel: kReduce).  Caller-supplied DFT objects -- non-owning key views, TRGSW_DFT
+  // selectors, sums made with trgsw_DFT_add / _mul_addto -- carry no such bound and take the run-time-gadget instantiation, which reduces like
+  // the reference (fft_processor_spqlios.c:155-165 reduces any double).
+  if (!bounded && l == 2 && Bg_bit == 8 && std::is_same<F, Fft1024>::value) Bg_bit = -8;   // (negative: routed to the <2, 0> instantiation below)
   const int cap = resident_teams(F::THREADS);
   if constexpr (std::is_same<F, Fft1024>::value) {
     // one key entry for the whole batch at N = 1024, l <= 2: the entry fits LDS next to eight teams' transpose buffers (external_product_ldskey_kernel)
@@ -342,18 +347,20 @@ static void launch_external_product(int l, int Bg_bit, hipStream_t s, const d2 *
       if (l == 2 && Bg_bit == 8) EPL_GO(2, 8);
       else if (l == 1 && Bg_bit == 23) EPL_GO(1, 23);
       else if (l == 1) EPL_GO(1, 0);
-      else EPL_GO(2, 0);
+      else { if (Bg_bit < 0) Bg_bit = -Bg_bit; EPL_GO(2, 0); }
 #undef EPL_GO
       return;
     }
   }
+  const bool unbounded_2x8 = Bg_bit < 0;
+  if (unbounded_2x8) Bg_bit = -Bg_bit;
   const dim3 grid((unsigned)(count < cap ? count : cap)), block(F::THREADS);
 #define EP_GO(LL, BB)                                                                                                                                    \
   do {                                                                                                                                                   \
     if (d_in0) hipLaunchKernelGGL((external_product_kernel<F, LL, BB, true>), grid, block, 0, s, row, tw, d_in, d_out, Bg_bit, count, key_stride, in_stride, d_in0, d_out_dft);   \
     else hipLaunchKernelGGL((external_product_kernel<F, LL, BB, false>), grid, block, 0, s, row, tw, d_in, d_out, Bg_bit, count, key_stride, in_stride, d_in0, d_out_dft);      \
   } while (0)
-  if (l == 2 && Bg_bit == 8) EP_GO(2, 8);
+  if (l == 2 && Bg_bit == 8 && !unbounded_2x8) EP_GO(2, 8);
   else if (l == 4 && Bg_bit == 9) EP_GO(4, 9);
   else if (l == 1 && Bg_bit == 23) EP_GO(1, 23);
   else if (l == 1) EP_GO(1, 0);
@@ -401,10 +408,11 @@ static void launch_pbs(const PbsParams &p, int count, hipStream_t s) {
 }
 
 template <class F>
-static int launch_pbs_f(int l, int Bg_bit, const PbsParams &p, int count, hipStream_t s) {
+static int launch_pbs_f(int l, int Bg_bit, const PbsParams &p, int count, hipStream_t s, bool bounded) {
   // Gadget bases of the reference's parameter sets get a compile-time instantiation (test/benchmark.c:53-75,
-  // test/tests.c:37-62,967); anything else runs the run-time-Bg variant.
-  if (l == 2 && Bg_bit == 8) launch_pbs<F, 2, 8>(p, count, s);
+  // test/tests.c:37-62,967); anything else runs the run-time-Bg variant.  bounded: see launch_external_product -- a key view over caller-held
+  // TRGSW_DFT objects (blind_rotate(tv, a, TRGSW_DFT *s, size)) takes the reducing run-time-gadget kernel.
+  if (l == 2 && Bg_bit == 8 && (bounded || F::N != 1024)) launch_pbs<F, 2, 8>(p, count, s);
   else if (l == 4 && Bg_bit == 9) launch_pbs<F, 4, 9>(p, count, s);
   // l = 1: the transform grouping with a full last pass (negacyclic_fft.h, Fft2048T: same results, same key layout; +2 % at SET_2, +6 % at SET_3)
   else if (l == 1 && Bg_bit == 23) launch_pbs<typename WideTail<F>::type, 1, 23>(p, count, s);
@@ -473,7 +481,7 @@ static int bootstrap_common(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hip_
     hipStream_t s = pick(ctx, stream);
     const int l = bsk->l, Bg = bsk->Bg_bit;
 #define TEAM_LAUNCH(LL, BB) hipLaunchKernelGGL((pbs_team_kernel<LL, BB>), dim3((unsigned)count), dim3(64 * 2 * LL), 0, s, p)
-    if (l == 2 && Bg == 8) TEAM_LAUNCH(2, 8);
+    if (l == 2 && Bg == 8 && bsk->owns) TEAM_LAUNCH(2, 8);
     else if (l == 4 && Bg == 9) TEAM_LAUNCH(4, 9);
     else if (l == 1) TEAM_LAUNCH(1, 0);
     else if (l == 2) TEAM_LAUNCH(2, 0);
@@ -484,7 +492,7 @@ static int bootstrap_common(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hip_
     return MOSFHET_HIP_OK;
   }
   int rc_pbs = MOSFHET_HIP_OK;
-  RING_DISPATCH(ctx, bsk->N, rc_pbs = launch_pbs_f<F>(bsk->l, bsk->Bg_bit, p, count, pick(ctx, stream)));
+  RING_DISPATCH(ctx, bsk->N, rc_pbs = launch_pbs_f<F>(bsk->l, bsk->Bg_bit, p, count, pick(ctx, stream), bsk->owns));
   return rc_pbs;
 }
 
@@ -522,7 +530,7 @@ extern "C" int mosfhet_hip_external_product_batch(mosfhet_hip_ctx_t ctx, mosfhet
   HIP_TRY(hipSetDevice(ctx->device));
   const d2 *row = bsk->d_bk + (size_t)key_index * (2 * bsk->l * 2 * (bsk->N / 2));
   hipStream_t s = pick(ctx, stream);
-  RING_DISPATCH(ctx, bsk->N, launch_external_product<F>(bsk->l, bsk->Bg_bit, s, row, TW, d_in, d_out, count, (size_t)0, (size_t)2 * F::N, nullptr, nullptr));
+  RING_DISPATCH(ctx, bsk->N, launch_external_product<F>(bsk->l, bsk->Bg_bit, s, row, TW, d_in, d_out, count, (size_t)0, (size_t)2 * F::N, nullptr, nullptr, bsk->owns));
   HIP_TRY(hipGetLastError());
   return MOSFHET_HIP_OK;
 }

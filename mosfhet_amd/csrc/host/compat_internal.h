@@ -60,8 +60,14 @@ MC_HIDDEN void mc_chacha20_block(uint32_t out[16], const uint32_t key[8], uint64
 
 /* polynomial shells carry a hidden tag in front of the struct, so that free_polynomial / free_trlwe / free_trgsw -- which the reference
  * declares on void * and uses for torus-domain and DFT-domain objects alike -- know what they hold */
-enum { MC_POLY_TORUS = 0x544f5255, MC_POLY_DFT_OWNER = 0x4446544f, MC_POLY_DFT_VIEW = 0x44465456 };
+enum { MC_POLY_TORUS = 0x544f5255, MC_POLY_DFT_OWNER = 0x4446544f, MC_POLY_DFT_VIEW = 0x44465456, MC_POLY_DFT_SHARED = 0x44465453 };
 MC_HIDDEN void *mc_poly_shell(int kind, void *coeffs, int N);  /* allocates {tag | struct {coeffs, N}} and returns the struct */
+/* One device block behind an ARRAY of DFT-domain objects (polynomial_new_array_of_polynomials_DFT, trlwe_ / trgsw_alloc_new_DFT_sample_array): every
+ * element holds a reference, the block is released with the last one -- so elements may be freed one by one in any order, as in the reference, where
+ * each element is its own allocation (src/trgsw.c:82-88). */
+typedef struct { void *dev; long refs; } McShare;
+MC_HIDDEN McShare *mc_share_new(void *dev, long refs);
+MC_HIDDEN void *mc_poly_shell_shared(McShare *share, void *coeffs, int N);
 MC_HIDDEN int mc_poly_kind(const void *poly);
 
 /* mosfhet_compat_dft.c */

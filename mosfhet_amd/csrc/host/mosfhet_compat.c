@@ -112,6 +112,23 @@ void *mc_poly_shell(int kind, void *coeffs, int N) {
   return &b->p;
 }
 
+McShare *mc_share_new(void *dev, long refs) {
+  McShare *sh = (McShare *)mc_xmalloc(sizeof(*sh));
+  sh->dev = dev;
+  sh->refs = refs;
+  if (refs <= 0) {   /* an empty array: nothing will ever release the block */
+    mc_use_device();
+    hipFree(dev);
+    sh->dev = NULL;
+  }
+  return sh;
+}
+void *mc_poly_shell_shared(McShare *share, void *coeffs, int N) {
+  void *p = mc_poly_shell(MC_POLY_DFT_SHARED, coeffs, N);
+  POLY_BOX(p)->pad = (uint64_t)(uintptr_t)share;
+  return p;
+}
+
 int mc_poly_kind(const void *poly) { return (int)POLY_BOX(poly)->kind; }
 
 TorusPolynomial polynomial_new_torus_polynomial(int N) {
@@ -125,6 +142,15 @@ void free_polynomial(void *p) {
     case MC_POLY_TORUS: free(b->p.coeffs); break;
     case MC_POLY_DFT_OWNER: mc_use_device(); hipFree(b->p.coeffs); break;   /* the device block of a DFT-domain object hangs off its first polynomial */
     case MC_POLY_DFT_VIEW: break;
+    case MC_POLY_DFT_SHARED: {   /* one element of an array that shares a device block: the last reference releases it */
+      McShare *sh = (McShare *)(uintptr_t)b->pad;
+      if (__atomic_sub_fetch(&sh->refs, 1, __ATOMIC_ACQ_REL) == 0) {
+        mc_use_device();
+        hipFree(sh->dev);
+        free(sh);
+      }
+      break;
+    }
     default:
       fprintf(stderr, "mosfhet_amd: free_polynomial: %p was not allocated by this library\n", p);
       abort();

@@ -5,7 +5,8 @@
  * `coeffs` of a DFT-domain polynomial points to DEVICE memory in the engine's slot order.  One object = one device block:
  *     TRLWE_DFT      [k+1][N/2] complex            a[0] owns the block, b is a view at + N doubles
  *     TRGSW_DFT      [(k+1) l][k+1][N/2] complex   samples[0]->a[0] owns it; the layout of one bootstrap-key entry
- *     arrays of them one block for the whole array (element 0 owns it), so an array of TRGSW_DFT is directly a key for blind_rotate
+ *     arrays of them one block for the whole array (every element holds a reference: elements may be freed one by one, in any order, or through
+ *                    the *_array functions), so an array of TRGSW_DFT is directly a key for blind_rotate
  * Every function stages its torus-domain arguments through the calling thread's staging buffers and waits for its result; nothing here computes
  * on the host.  k = 1 (every parameter set of the reference, test/tests.c:37-62).
  */
@@ -45,7 +46,9 @@ DFT_Polynomial polynomial_new_DFT_polynomial(int N) {
 DFT_Polynomial *polynomial_new_array_of_polynomials_DFT(int N, int size) {
   DFT_Polynomial *r = (DFT_Polynomial *)mc_xmalloc(sizeof(DFT_Polynomial) * (size_t)(size > 0 ? size : 1));
   double *block = (double *)mc_dev_alloc(sizeof(double) * (size_t)N * (size_t)(size > 0 ? size : 1));
-  for (int i = 0; i < size; i++) r[i] = (DFT_Polynomial)mc_poly_shell(i ? MC_POLY_DFT_VIEW : MC_POLY_DFT_OWNER, block + (size_t)i * N, N);
+  McShare *share = mc_share_new(block, size);
+  for (int i = 0; i < size; i++) r[i] = (DFT_Polynomial)mc_poly_shell_shared(share, block + (size_t)i * N, N);
+  if (size <= 0) free(share);
   return r;
 }
 
@@ -83,10 +86,11 @@ void polynomial_copy_DFT_polynomial(DFT_Polynomial out, DFT_Polynomial in) {
 }
 
 /* ------------------------------------------------------------------ TRLWE_DFT */
-static TRLWE_DFT trlwe_dft_shell(double *base, int N, int owner) {
+/* owner: 1 = the object owns its block, 0 = a view; share != NULL: the object holds one reference to an array's block */
+static TRLWE_DFT trlwe_dft_shell(double *base, int N, int owner, McShare *share) {
   TRLWE_DFT c = (TRLWE_DFT)mc_xmalloc(sizeof(*c));
   c->a = (DFT_Polynomial *)mc_xmalloc(sizeof(DFT_Polynomial));
-  c->a[0] = (DFT_Polynomial)mc_poly_shell(owner ? MC_POLY_DFT_OWNER : MC_POLY_DFT_VIEW, base, N);
+  c->a[0] = share ? (DFT_Polynomial)mc_poly_shell_shared(share, base, N) : (DFT_Polynomial)mc_poly_shell(owner ? MC_POLY_DFT_OWNER : MC_POLY_DFT_VIEW, base, N);
   c->b = (DFT_Polynomial)mc_poly_shell(MC_POLY_DFT_VIEW, base + N, N);
   c->k = 1;
   return c;
@@ -100,14 +104,16 @@ static double *trlwe_dft_base(TRLWE_DFT c, const char *who) {
 
 TRLWE_DFT trlwe_alloc_new_DFT_sample(int k, int N) {
   need(k == 1, "trlwe_alloc_new_DFT_sample: k = 1 only");
-  return trlwe_dft_shell((double *)mc_dev_alloc(sizeof(double) * 2 * (size_t)N), N, 1);
+  return trlwe_dft_shell((double *)mc_dev_alloc(sizeof(double) * 2 * (size_t)N), N, 1, NULL);
 }
 
 TRLWE_DFT *trlwe_alloc_new_DFT_sample_array(int count, int k, int N) {
   need(k == 1, "trlwe_alloc_new_DFT_sample_array: k = 1 only");
   TRLWE_DFT *r = (TRLWE_DFT *)mc_xmalloc(sizeof(TRLWE_DFT) * (size_t)(count > 0 ? count : 1));
   double *block = (double *)mc_dev_alloc(sizeof(double) * 2 * (size_t)N * (size_t)(count > 0 ? count : 1));
-  for (int i = 0; i < count; i++) r[i] = trlwe_dft_shell(block + (size_t)i * 2 * N, N, i == 0);
+  McShare *share = mc_share_new(block, count);
+  for (int i = 0; i < count; i++) r[i] = trlwe_dft_shell(block + (size_t)i * 2 * N, N, 0, share);
+  if (count <= 0) free(share);
   return r;
 }
 
@@ -132,10 +138,10 @@ void trlwe_from_DFT(TRLWE out, TRLWE_DFT in) {
 }
 
 /* ------------------------------------------------------------------ TRGSW_DFT */
-static TRGSW_DFT trgsw_dft_shell(double *base, int l, int Bg_bit, int N, int owner) {
+static TRGSW_DFT trgsw_dft_shell(double *base, int l, int Bg_bit, int N, int owner, McShare *share) {
   TRGSW_DFT g = (TRGSW_DFT)mc_xmalloc(sizeof(*g));
   g->samples = (TRLWE_DFT *)mc_xmalloc(sizeof(TRLWE_DFT) * (size_t)2 * l);
-  for (int r = 0; r < 2 * l; r++) g->samples[r] = trlwe_dft_shell(base + (size_t)r * 2 * N, N, owner && r == 0);
+  for (int r = 0; r < 2 * l; r++) g->samples[r] = trlwe_dft_shell(base + (size_t)r * 2 * N, N, owner && r == 0, r == 0 ? share : NULL);
   g->l = l;
   g->Bg_bit = Bg_bit;
   return g;
@@ -153,7 +159,7 @@ static double *trgsw_dft_base(TRGSW_DFT g, const char *who) {
 
 TRGSW_DFT *mc_trgsw_dft_views(double *base, int n, int l, int Bg_bit, int N) {
   TRGSW_DFT *r = (TRGSW_DFT *)mc_xmalloc(sizeof(TRGSW_DFT) * (size_t)n);
-  for (int i = 0; i < n; i++) r[i] = trgsw_dft_shell(base + (size_t)i * trgsw_dft_doubles(l, N), l, Bg_bit, N, 0);
+  for (int i = 0; i < n; i++) r[i] = trgsw_dft_shell(base + (size_t)i * trgsw_dft_doubles(l, N), l, Bg_bit, N, 0, NULL);
   return r;
 }
 
@@ -164,14 +170,16 @@ void mc_trgsw_dft_views_free(TRGSW_DFT *views, int n) {
 
 TRGSW_DFT trgsw_alloc_new_DFT_sample(int l, int Bg_bit, int k, int N) {
   need(k == 1, "trgsw_alloc_new_DFT_sample: k = 1 only");
-  return trgsw_dft_shell((double *)mc_dev_alloc(sizeof(double) * trgsw_dft_doubles(l, N)), l, Bg_bit, N, 1);
+  return trgsw_dft_shell((double *)mc_dev_alloc(sizeof(double) * trgsw_dft_doubles(l, N)), l, Bg_bit, N, 1, NULL);
 }
 
 TRGSW_DFT *trgsw_alloc_new_DFT_sample_array(int count, int l, int Bg_bit, int k, int N) {
   need(k == 1, "trgsw_alloc_new_DFT_sample_array: k = 1 only");
   TRGSW_DFT *r = (TRGSW_DFT *)mc_xmalloc(sizeof(TRGSW_DFT) * (size_t)(count > 0 ? count : 1));
   double *block = (double *)mc_dev_alloc(sizeof(double) * trgsw_dft_doubles(l, N) * (size_t)(count > 0 ? count : 1));
-  for (int i = 0; i < count; i++) r[i] = trgsw_dft_shell(block + (size_t)i * trgsw_dft_doubles(l, N), l, Bg_bit, N, i == 0);
+  McShare *share = mc_share_new(block, count);
+  for (int i = 0; i < count; i++) r[i] = trgsw_dft_shell(block + (size_t)i * trgsw_dft_doubles(l, N), l, Bg_bit, N, 0, share);
+  if (count <= 0) free(share);
   return r;
 }
 

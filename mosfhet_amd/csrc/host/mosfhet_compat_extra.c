@@ -145,11 +145,21 @@ void trgsw_reg_subto(TRGSW_REG out, TRGSW_REG in) { trgsw_reg_sub(out, out, in);
  * The device key generators take any small-integer TRLWE key (keygen_kernels.h). */
 static void sparse_fill(Torus *out, int size, int h, int ternary, int gaussian, double key_sigma) {
   memset(out, 0, sizeof(Torus) * (size_t)size);
+  if (h > size) {   /* more nonzero coefficients than positions: the loop below would never end */
+    fprintf(stderr, "mosfhet_amd: key with Hamming weight %d over %d coefficients\n", h, size);
+    abort();
+  }
   Torus val = 1;
   for (int hw = 0; hw < h;) {
-    const int idx = (int)(mc_rnd64() & (uint64_t)(size - 1));
+    /* unbiased index for ANY size (k * N need not be a power of two): rejection below the largest multiple of size */
+    const uint64_t limit = UINT64_MAX - UINT64_MAX % (uint64_t)size, r = mc_rnd64();
+    if (r >= limit) continue;
+    const int idx = (int)(r % (uint64_t)size);
     if (out[idx]) continue;
-    if (gaussian) val = (Torus)(int64_t)mc_rnd_normal(key_sigma);
+    if (gaussian) {
+      val = (Torus)(int64_t)mc_rnd_normal(key_sigma);
+      if (!val) continue;                 /* a drawn 0 is not a nonzero coefficient: draw again */
+    }
     out[idx] = val;
     if (ternary) val = (Torus)0 - val;    /* +1, -1, +1, ... */
     hw++;

@@ -195,7 +195,7 @@ TRGSW trgsw_new_exp_sample(int e, TRGSW_Key key) { return trgsw_new_monomial_sam
 
 /* ================================================================== DFT domain (device) */
 static double *poly_dev(DFT_Polynomial p, const char *who) {
-  need(p && (mc_poly_kind(p) == MC_POLY_DFT_OWNER || mc_poly_kind(p) == MC_POLY_DFT_VIEW), who);
+  need(p && (mc_poly_kind(p) == MC_POLY_DFT_OWNER || mc_poly_kind(p) == MC_POLY_DFT_VIEW || mc_poly_kind(p) == MC_POLY_DFT_SHARED), who);
   return p->coeffs;
 }
 static void lincomb(double *out, const double *a, const double *b, double cb, size_t n, const char *who) {

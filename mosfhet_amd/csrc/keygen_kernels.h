@@ -7,8 +7,11 @@
 //   * MASKS are public values and come from a counter-based generator on a PUBLIC 64-bit seed (keygen_mix: splitmix64 of (seed, row, word)), so that a
 //     seed-compressed key can regenerate them inside the key-switch kernel for a few integer operations per word;
 //   * NOISE is secret: it comes from ChaCha20 under a 256-bit key that is independent of the mask seed (NoiseKey: drawn from the operating system by the
-//     C ABI, or handed over by the host layer from its own ChaCha20 stream), counter = (row, coefficient), nonce = the mask seed.  Knowing every mask
-//     word and the mask seed says nothing about the noise terms.
+//     C ABI, or handed over by the host layer from its own ChaCha20 stream), counter = (row, coefficient), nonce = a value that is UNIQUE PER GENERATE
+//     CALL under that key (the library's call counter and a generator-kind tag: capi_ext.inc, noise_key_for_call) -- never the caller's mask seed.
+//     Knowing every mask word and the mask seed says nothing about the noise terms, and two keys generated with the same public seed (two kinds of
+//     table key, a plain and a Galois bootstrap key, the same key for two input keys ...) share their masks but not their noise, so the difference
+//     of two such rows is still an encryption, not the bare key-dependent message.
 // A 6 GB key takes milliseconds instead of minutes of host time.  The product a * s_out is exact (integer adds over the set bits of the key).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -23,7 +26,7 @@ __device__ __forceinline__ uint64_t keygen_mix(uint64_t seed, uint64_t row, uint
   return z ^ (z >> 31);
 }
 
-struct NoiseKey { uint32_t k[8]; };
+struct NoiseKey { uint32_t k[8]; uint64_t nonce; };   // nonce: unique per generate call under this key
 
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, 32 - n); }
 #define MOSFHET_QR(a, b, c, d) \
@@ -46,9 +49,9 @@ __device__ __forceinline__ void chacha20_uniforms(const NoiseKey &key, uint64_t 
 }
 
 // Gaussian noise term of coefficient x of row r on the torus: Box-Muller on two uniforms (src/misc.c:87-91), double2torus of sigma z (src/misc.c:13-15)
-__device__ __forceinline__ uint64_t keygen_noise(const NoiseKey &key, uint64_t mask_seed, uint64_t row, uint64_t x, double sigma) {
+__device__ __forceinline__ uint64_t keygen_noise(const NoiseKey &key, uint64_t row, uint64_t x, double sigma) {
   uint64_t a, b;
-  chacha20_uniforms(key, (row << 16) | x, mask_seed, a, b);
+  chacha20_uniforms(key, (row << 16) | x, key.nonce, a, b);
   const double u1 = ((double)(a >> 11) + 0.5) * 0x1p-53, u2 = ((double)(b >> 11) + 0.5) * 0x1p-53;
   const double z = cos(6.283185307179586 * u1) * sqrt(-2.0 * log(u2)) * sigma;
   return (uint64_t)(int64_t)(18446744073709551616.0 * z);
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256) void trlwe_table_keygen_kernel(uint64_t *__res
         acc += src < 0 ? (uint64_t)0 - w : w;
       }
     }
-    acc += keygen_noise(nkey, seed, r, (uint64_t)x, sigma);
+    acc += keygen_noise(nkey, r, (uint64_t)x, sigma);
     if (kind == 0) { if (x == 0) acc += dec; }
     else if (kind == 2) { if (x / span == slot) acc += dec; }
     else acc += ((uint64_t)0 - s_out[x]) * dec;
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(256) void trgsw_bk_keygen_kernel(uint64_t *__restri
         acc += src < 0 ? (uint64_t)0 - w : w;
       }
     }
-    acc += keygen_noise(nkey, seed, r, (uint64_t)x, sigma);
+    acc += keygen_noise(nkey, r, (uint64_t)x, sigma);
     dst[x] = a[x] + ((c == 0 && x == e) ? val : 0);     // the gadget goes on the mask AFTER b = a * s + e was formed from the plain mask
     dst[N + x] = acc + ((c == 1 && x == e) ? val : 0);
   }
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(256) void trlwe_poly_keygen_kernel(uint64_t *__rest
         acc += src < 0 ? (uint64_t)0 - w : w;
       }
     }
-    acc += keygen_noise(nkey, seed, r, (uint64_t)x, sigma);
+    acc += keygen_noise(nkey, r, (uint64_t)x, sigma);
     dst[N + x] = acc + (msgs[e * (size_t)N + x] << shift);
   }
 }
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(64) void tlwe_ksk_keygen_kernel(uint64_t *__restric
   }
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
   if (lane == 0) {
-    acc += keygen_noise(nkey, seed, r, 0, sigma);
+    acc += keygen_noise(nkey, r, 0, sigma);
     acc += s_in[i] * (uint64_t)v * (1ull << (64 - (j + 1) * base_bit));
     dst[compressed ? 0 : n_out] = acc;
   }

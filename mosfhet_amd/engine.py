@@ -354,6 +354,14 @@ class Engine:
         _check(lib().mosfhet_hip_trlwe_mv_extract_batch(self.h, _ptr(out), _ptr(ct), N, mode, amount, count, self._stream()))
         return out
 
+    @staticmethod
+    def set_keygen_secret(key32):
+        """Install the 256-bit ChaCha20 key the on-device generators draw their NOISE under (process-wide; default: from the operating system) and
+        restart its per-call nonce sequence: the same secret followed by the same generate calls reproduces the same keys (tests, mosfhet_seed)."""
+        key32 = bytes(key32)
+        assert len(key32) == 32
+        _check(lib().mosfhet_hip_set_keygen_secret(key32))
+
     def generate_table_key(self, kind, s_out, s_in, t, base_bit, sigma, seed, compressed=False):
         """On-device packing (kind 0) / private (kind 1) key-switch key; returns a KeySwitchKey.  compressed: keep only the b halves in HBM and
         regenerate the masks inside the key-switch kernels (same rows, same results)."""

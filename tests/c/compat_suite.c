@@ -725,6 +725,30 @@ static void case_dft_level_api(void) {
           "blind_rotate over scattered selectors differs from the contiguous array");
     free_trgsw(lone[0]); free_trgsw(lone[1]); free_trlwe(t1); free_trlwe(t2);
   }
+  /* elements of a DFT-domain array are freed ONE BY ONE, element 0 first, as callers of the reference may (each element is its own allocation there,
+   * src/trgsw.c:82-88): the array's device block has to stay until its last element goes */
+  {
+    TRGSW_DFT *arr = trgsw_alloc_new_DFT_sample_array(3, l, Bg_bit, k, N);
+    TRGSW_DFT single = trgsw_alloc_new_DFT_sample(l, Bg_bit, k, N);
+    TRLWE t0 = trlwe_new_sample(pa, rlwe_key), t1 = trlwe_alloc_new_sample(k, N), t2 = trlwe_alloc_new_sample(k, N);
+    TRLWE_DFT td = trlwe_alloc_new_DFT_sample(k, N);
+    free_trgsw(arr[0]);
+    trgsw_monomial_sample(bit, 1, 3, trgsw_key);
+    trgsw_to_DFT(arr[2], bit);
+    trgsw_to_DFT(single, bit);
+    free_trgsw(arr[1]);
+    trgsw_mul_trlwe_DFT(td, t0, arr[2]); trlwe_from_DFT(t1, td);
+    trgsw_mul_trlwe_DFT(td, t0, single); trlwe_from_DFT(t2, td);
+    CHECK(!memcmp(t1->a[0]->coeffs, t2->a[0]->coeffs, sizeof(Torus) * N) && !memcmp(t1->b->coeffs, t2->b->coeffs, sizeof(Torus) * N),
+          "an array element used after element 0 was freed differs from a lone sample");
+    free_trgsw(arr[2]); free(arr); free_trgsw(single); free_trlwe(td); free_trlwe(t0); free_trlwe(t1); free_trlwe(t2);
+    DFT_Polynomial *pd = polynomial_new_array_of_polynomials_DFT(N, 2);
+    free_polynomial(pd[0]);
+    polynomial_torus_to_DFT(pd[1], pa);
+    polynomial_DFT_to_torus(pc, pd[1]);
+    for (int i = 0; i < N; i++) WITHIN(1ULL << 14, pa->coeffs[i], pc->coeffs[i], "array element 1 after element 0 was freed");
+    free_polynomial(pd[1]); free(pd);
+  }
   /* blind_rotate over the bootstrap key's own entries = functional_bootstrap_wo_extract without the first rotation */
   {
     TLWE in = tlwe_new_sample(double2torus(3 / 8.), lwe_key);

@@ -1,13 +1,30 @@
 // ep_ab.hip -- one-kernel build of the external-product kernel for same-box A/B experiments (cf. pbs_ab.hip).
 #include "../../mosfhet_amd/csrc/bootstrap_kernels.h"
 using namespace mosfhet;
+#ifndef AB_N
+#define AB_N 1024
+#endif
+#ifndef AB_L
+#define AB_L 2
+#endif
+#ifndef AB_BG
+#define AB_BG 8
+#endif
+#if AB_N == 1024
+using ABF = Fft1024;
+#elif AB_N == 2048
+using ABF = Fft2048;
+#else
+using ABF = Fft4096;
+#endif
+extern "C" int ab_ep_bg_rt = 0;   // run-time gadget base of AB_BG = 0 builds
 extern "C" int ab_ep(const double *d_row, const double *d_tw, const uint64_t *d_in, uint64_t *d_out, int count, int grid, int reps, float *ms_per_launch) {
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1;
   hipEventRecord(e0, nullptr);
   for (int r = 0; r < reps; r++)
-    hipLaunchKernelGGL((external_product_kernel<Fft1024, 2, 8, false>), dim3((unsigned)grid), dim3(64), 0, nullptr, (const d2 *)d_row, (const d2 *)d_tw, d_in, d_out, 8, count,
-                       (size_t)0, (size_t)2048, (const uint64_t *)nullptr, (d2 *)nullptr);
+    hipLaunchKernelGGL((external_product_kernel<ABF, AB_L, AB_BG, false>), dim3((unsigned)grid), dim3(ABF::THREADS), 0, nullptr, (const d2 *)d_row, (const d2 *)d_tw, d_in, d_out,
+                       AB_BG ? AB_BG : ab_ep_bg_rt, count, (size_t)0, (size_t)(2 * ABF::N), (const uint64_t *)nullptr, (d2 *)nullptr);
   hipEventRecord(e1, nullptr);
   if (hipEventSynchronize(e1) != hipSuccess) return -2;
   float ms = 0.f;
@@ -18,6 +35,7 @@ extern "C" int ab_ep(const double *d_row, const double *d_tw, const uint64_t *d_
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+#if AB_N == 1024
 // LDS-key variant: one workgroup of 8 teams per CU
 extern "C" int ab_epl(const double *d_row, const double *d_tw, const uint64_t *d_in, uint64_t *d_out, int count, int grid, int reps, float *ms_per_launch) {
   hipEvent_t e0, e1;
@@ -35,3 +53,4 @@ extern "C" int ab_epl(const double *d_row, const double *d_tw, const uint64_t *d
   *ms_per_launch = ms / (float)reps;
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
+#endif

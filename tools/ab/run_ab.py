@@ -82,46 +82,74 @@ def run(pset, B, rounds):
         print("%-28s min %.3f  med %.3f ms  %s  bit-exact-vs-production=%s" % (name, min(t), sorted(t)[len(t) // 2], ("(%+.1f %% vs base)" % (100 * (min(t) / base - 1))) if base else "", exact[name]))
 
 
-def run_ep(B, rounds, grids):
-    """external-product variants (tools/ab/_build/ep_*.so) at SET_1: B units against one key entry, each at the grid sizes given"""
+def run_ep(B, rounds, grids, pset="set1", names=None):
+    """external-product variants (tools/ab/_build/ep_*.so): B units against one key entry, each at the grid sizes given"""
     sys.path.insert(0, ROOT)
     import numpy as np
     import torch
     import mosfhet_amd as ma
     from mosfhet_amd import host, engine
-    P = dict(ma.PARAMS_SET1)
+    if ":" in pset:   # N:l:Bg_bit
+        N_, l_, bg_ = (int(x) for x in pset.split(":"))
+        P = dict(ma.PARAMS_SET2, N=N_, l=l_, Bg_bit=bg_)
+    else:
+        P = dict({"set1": ma.PARAMS_SET1, "lvl2": ma.PARAMS_LVL2, "set2": ma.PARAMS_SET2, "set3": ma.PARAMS_SET3}[pset])
     host.seed(0x4D4F5346)
     lk = host.LweKey(4, P["lwe_sigma"])
     rk = host.RlweKey(P["N"], 1, P["rlwe_sigma"])
     eng = ma.Engine(0)
-    bsk = eng.load_bootstrap_key(host.gen_bootstrap_key(rk, lk, P["l"], P["Bg_bit"]), 1, P["l"], P["Bg_bit"])
+    host_bk = host.gen_bootstrap_key(rk, lk, P["l"], P["Bg_bit"])
+    bsk = eng.load_bootstrap_key(host_bk, 1, P["l"], P["Bg_bit"])
     g = torch.Generator(device="cpu").manual_seed(1)
     d_in = torch.randint(-2 ** 63, 2 ** 63 - 1, (B, 2, P["N"]), dtype=torch.int64, generator=g).to(eng.device)
     want = eng.external_product(bsk, 1, d_in)
+    # the truth for a sample of units: the oracle (production is itself under test when a variant disagrees with it)
+    from oracle import oracle as O
+    O.build()
+    bkd = O.bk_to_dft(host_bk, 1, P["l"])
+    sample = sorted(set([0, 1, min(B - 1, grids[0]), min(B - 1, grids[0] + 1), B // 2, B - 1]))
+    h_in = ma.to_numpy(d_in)
+    truth = {b: O.external_product(h_in[b], bkd[1], P["l"], P["Bg_bit"]) for b in sample}
+    w = ma.to_numpy(want)
+    print("production vs oracle on units %s: %s" % (sample, all((w[b] == truth[b]).all() for b in sample)))
     L = engine.lib()
     L.mosfhet_hip_bsk_device_dft.restype = C.c_void_p
     d_row = L.mosfhet_hip_bsk_device_dft(bsk.h) + 1 * (2 * P["l"] * 2 * P["N"]) * 8
     tw = np.zeros(2 * (P["N"] // 2 - 1), dtype=np.float64)
     L.mosfhet_hip_twiddles(P["N"], tw.ctypes.data_as(C.c_void_p))
     d_tw = torch.from_numpy(tw).to(eng.device)
-    libs = {os.path.basename(p)[3:-3]: C.CDLL(p) for p in sorted(glob.glob(os.path.join(OUT, "ep_*.so")))}
+    libs = {os.path.basename(p)[3:-3]: C.CDLL(p) for p in sorted(glob.glob(os.path.join(OUT, "ep_*.so"))) if not names or os.path.basename(p)[3:-3] in names}
+    for lib in libs.values():
+        C.c_int.in_dll(lib, "ab_ep_bg_rt").value = P["Bg_bit"]
     out = eng.empty(B, 2, P["N"])
+    unit_bytes = 2 * 2 * P["N"] * 8
     res = {}
     reps = int(os.environ.get("AB_REPS", "5"))
     for r in range(rounds):
         for name, lib in libs.items():
-            for fn, gr in (("ab_ep", grids), ("ab_epl", [256, 512])):
+            for fn, gr in (("ab_ep", grids),) + ((("ab_epl", [256, 512]),) if P["N"] == 1024 else ()):
                 for grid in gr:
                     ms = C.c_float()
                     out.zero_()
                     rc = getattr(lib, fn)(C.c_void_p(d_row), C.c_void_p(d_tw.data_ptr()), C.c_void_p(d_in.data_ptr()), C.c_void_p(out.data_ptr()), B, grid, reps, C.byref(ms))
                     assert rc == 0, (name, fn, rc)
                     ok = bool((out == want).all())
+                    if not ok:
+                        o = ma.to_numpy(out)
+                        bad = np.nonzero((o != w).any(axis=(1, 2)))[0]
+                        if r == 0:
+                            print("   %s grid %d: bad units by iteration (unit // grid): %s; by block %% 8: %s" % (name, grid, np.bincount(bad // grid, minlength=B // grid).tolist(), np.bincount((bad % grid) % 8, minlength=8).tolist()))
+                            b0 = bad[0]
+                            dw = (o[b0] != w[b0])
+                            dd = (o[b0] - w[b0]).astype(np.int64)
+                            print("   %s grid %d: unit %d: %d of %d words differ, per component %s, max |diff| 2^%.1f, first positions %s" % (
+                                name, grid, b0, dw.sum(), dw.size, dw.sum(axis=1).tolist(), np.log2(np.abs(dd.astype(np.float64)).max() + 1), np.nonzero(dw.reshape(-1))[0][:8].tolist()))
+                        ok = "False: %d units differ from production (first %s); vs oracle on the sample: %s" % (len(bad), bad[:6].tolist(), {b: bool((o[b] == truth[b]).all()) for b in sample})
                     res.setdefault((name + ":" + fn, grid), []).append((ms.value, ok))
     for (name, grid), v in res.items():
         t = [x[0] for x in v]
-        print("%-20s grid %5d  min %.3f  med %.3f ms  -> %.0f GB/s (%.1f %% of 8 TB/s)  bit-exact=%s" % (name, grid, min(t), sorted(t)[len(t) // 2], B * 32768 / min(t) / 1e6,
-                                                                                                       B * 32768 / min(t) / 1e6 / 80, all(x[1] for x in v)))
+        print("%-20s grid %5d  min %.3f  med %.3f ms  -> %.0f GB/s (%.1f %% of 8 TB/s)  bit-exact=%s" % (name, grid, min(t), sorted(t)[len(t) // 2], B * unit_bytes / min(t) / 1e6,
+                                                                                                       B * unit_bytes / min(t) / 1e6 / 80, [x[1] for x in v] if any(x[1] is not True for x in v) else True))
 
 
 if __name__ == "__main__":
@@ -131,6 +159,7 @@ if __name__ == "__main__":
         build(sys.argv[2:], "ep_ab.hip", "ep_")
     elif sys.argv[1] == "run_ep":
         run_ep(int(sys.argv[2]) if len(sys.argv) > 2 else 65536, int(sys.argv[3]) if len(sys.argv) > 3 else 5,
-               [int(x) for x in (sys.argv[4] if len(sys.argv) > 4 else "2048").split(",")])
+               [int(x) for x in (sys.argv[4] if len(sys.argv) > 4 else "2048").split(",")], sys.argv[5] if len(sys.argv) > 5 else "set1",
+               sys.argv[6].split(",") if len(sys.argv) > 6 else None)
     else:
         run(sys.argv[2] if len(sys.argv) > 2 else "set1", int(sys.argv[3]) if len(sys.argv) > 3 else 4096, int(sys.argv[4]) if len(sys.argv) > 4 else 5)
