@@ -15,7 +15,12 @@ Prints ONE JSON line (rank 0) with the contract fields plus
                  per ciphertext) is kept as `hbm_algorithmic`, labelled: it is NOT a bound, the key is shared by the batch through L2;
                  `traffic` = PMC-measured memory-side bytes per launch, only when profiles/latest_traffic.json was taken from THIS build;
   roofline_external_product : the kernel BASELINE.json's target names (trgsw_mul_trlwe_DFT + trlwe_from_DFT over a large batch against one
-                 key entry, 32 KiB of ciphertext I/O per unit) against HBM bandwidth, timed live the same way;
+                 key entry, 32 KiB of ciphertext I/O per unit) against HBM bandwidth, timed live the same way; a sample of its outputs is checked
+                 by phase (BK_i = TRGSW(s_i): phase(BK_i (.) c) = s_i phase(c), within the reference's 2^54);
+  roofline_external_product_lvl2 : the same at N = 2048, l = 4 (64 KiB per unit, 256 KiB key entry);
+  value_regime : how `value` was launched (steps alternate over --streams HIP streams) next to roofline.kernel_ms (one launch alone);
+  sustained    : the same step back to back for >= 2.5 s (N = 1);
+  replicas     : N > 1 only -- every rank holds the same key (same seed), different ciphertexts, and its outputs decrypt;
   cpu_baseline : the reference's own programmable_bootstrap (oracle/_ref, built from /root/reference) timed on
                  this box's host cores on a bounded sample (N=1 only), plus config 1 (one FFNT pure-C bootstrap).
 """
@@ -108,6 +113,64 @@ def cpu_baseline(P, bk, tv, cts, target_seconds):
                        "%.1f s wall; one call alone takes %.2f ms" % (total, backend, threads, dt, 1e3 * t1))
 
 
+def trlwe_phase(ct, s):
+    """b - a * s of TRLWE samples [B][2][N] under a binary key s (negacyclic product as a sum of signed rotations; checker for the external-product
+    legs: BK_i = TRGSW(s_i), so phase(BK_i (.) c) = s_i * phase(c) + noise, test_trgsw_trlwe_mul's property, test/tests.c:400-436)"""
+    a, b = ct[:, 0], ct[:, 1]
+    N = a.shape[1]
+    acc = np.zeros_like(a)
+    for p_ in np.nonzero(s)[0]:
+        rot = np.roll(a, int(p_), axis=1)
+        rot[:, :p_] = np.uint64(0) - rot[:, :p_]
+        acc += rot
+    return b - acc
+
+
+def external_product_leg(eng, ma, host, P, B_ep, measured_traffic, traffic_file, kernel_name, torch):
+    """The external-product kernel on its own (BASELINE.json's HBM target): B_ep TRLWE samples against ONE key entry, inputs and outputs in HBM.
+    Timed with events on the launch stream; a sample of the outputs is checked by phase (no oracle in the measured path)."""
+    N_, l_ = P["N"], P["l"]
+    host.seed(SEED + 77)
+    lk4 = host.LweKey(4, P["lwe_sigma"])
+    rk4 = host.RlweKey(N_, P["k"], P["rlwe_sigma"])
+    bsk4 = eng.load_bootstrap_key(host.gen_bootstrap_key(rk4, lk4, l_, P["Bg_bit"]), P["k"], l_, P["Bg_bit"])
+    g = torch.Generator(device="cpu").manual_seed(SEED)
+    d_ep_in = torch.randint(-2 ** 63, 2 ** 63 - 1, (B_ep, 2, N_), dtype=torch.int64, generator=g).to(eng.device)
+    d_ep_out = eng.empty(B_ep, 2, N_)
+    key_index = int(np.nonzero(lk4.s)[0][0]) if lk4.s.any() else 0       # an entry that encrypts 1: the product has to reproduce the phase
+    eng.external_product(bsk4, key_index, d_ep_in, out=d_ep_out)
+    torch.cuda.synchronize()
+    pick = np.unique(np.concatenate([[0, 1, B_ep // 2, B_ep - 1], np.random.default_rng(5).integers(0, B_ep, 12)]))
+    want = trlwe_phase(ma.to_numpy(d_ep_in[pick]), rk4.s[0]) * lk4.s[key_index]
+    got = trlwe_phase(ma.to_numpy(d_ep_out[pick]), rk4.s[0])
+    ep_err = np.abs((got - want).astype(np.int64).astype(np.float64)).max()
+    if not ep_err < 2.0 ** 54:          # the reference's tolerance for this product (test/tests.c:424)
+        sys.exit("bench.py: external-product outputs are wrong (max phase error 2^%.1f)" % np.log2(ep_err + 1))
+    for _ in range(100):    # this kernel's own steady state: the clock the chip holds depends on the load of the last tenths of a second
+        eng.external_product(bsk4, key_index, d_ep_in, out=d_ep_out)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    reps, groups = 20, []
+    for _ in range(5):      # five groups of 20 back-to-back launches; the MEDIAN group is reported (min and max beside it)
+        ev[0].record(torch.cuda.current_stream())      # the engine launches on torch's current stream (mosfhet_amd/engine.py: _stream)
+        for _ in range(reps):
+            eng.external_product(bsk4, key_index, d_ep_in, out=d_ep_out)
+        ev[1].record(torch.cuda.current_stream())
+        ev[1].synchronize()
+        groups.append(ev[0].elapsed_time(ev[1]) / reps)
+    groups.sort()
+    ep_ms = groups[len(groups) // 2]
+    ep_bytes = B_ep * 2 * (2 * N_ * 8) + (2 * l_) * 2 * N_ * 8        # SURVEY 8(d): TRLWE in + TRLWE out per unit, the key entry once
+    ep_gbs = ep_bytes / (ep_ms * 1e-3) / 1e9
+    flops = flops_per_cmux(P) * B_ep
+    bsk4.free()
+    return {"bound": "hbm", "achieved": ep_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ep_gbs / HBM_PEAK_GBS, "traffic": measured_traffic(traffic_file, B_ep),
+            "kernel": kernel_name, "kernel_ms": ep_ms, "kernel_ms_min_max": [groups[0], groups[-1]], "units_per_launch": B_ep,
+            "algorithmic_bytes_per_launch": ep_bytes, "external_products_per_s": B_ep / (ep_ms * 1e-3),
+            "fp64_model_tflops": flops / (ep_ms * 1e-3) / 1e12, "fp64_frac": flops / (ep_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+            "max_phase_error_log2": float(np.log2(ep_err + 1)),
+            "workload": "%d x trgsw_mul_trlwe_DFT + trlwe_from_DFT at N=%d l=%d against one TRGSW_DFT (src/trgsw.c:385-423)" % (B_ep, N_, l_)}
+
+
 def usable_cores():
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -142,10 +205,18 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: mosfhet_amd has no CPU path")
-    torch.cuda.set_device(local_rank)
+    # Test hooks for the N > 1 path on a box with fewer GPUs than ranks (tests/test_gpu_parity.py::test_bench_two_ranks_on_one_gpu): every rank on
+    # device 0 and gloo for the barrier / max-reduction.  The driver never sets them: one rank per GPU over RCCL ("nccl").
+    share_gpu = os.environ.get("MOSFHET_BENCH_SHARE_GPU", "0") == "1"
+    backend = os.environ.get("MOSFHET_BENCH_BACKEND", "nccl")
+    dev_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     import mosfhet_amd as ma
     from mosfhet_amd import host, build, shard
@@ -158,13 +229,18 @@ def main():
     lk = host.LweKey(P["n"], P["lwe_sigma"])
     rk = host.RlweKey(P["N"], P["k"], P["rlwe_sigma"])
     bk = host.gen_bootstrap_key(rk, lk, P["l"], P["Bg_bit"])
-    eng = ma.Engine(local_rank)
+    eng = ma.Engine(dev_index)
     bsk = eng.load_bootstrap_key(bk, P["k"], P["l"], P["Bg_bit"])
     host.seed(SEED + 1 + rank)  # different ciphertexts per rank
     lut = np.array([host.double2torus(x) for x in (0.0625, 0.3125, -0.1875, 0.4375)], dtype=np.uint64)
     tv = host.torus_packing(lut, P["k"], P["N"])
     msgs = [host.double2torus((b % 4) / 8.0) for b in range(B)]
     cts = host.tlwe_samples(msgs, lk)
+    # the CPU leg runs FIRST (rank 0, N = 1): the GPU legs then form one contiguous block at the end of the run
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(P, bk, tv, cts[:64], args.cpu_seconds)
+        cpu["ffnt_single_ms"] = ffnt_single_ms(P, bk, tv, cts[0])      # BASELINE.json configs[0]
     d_tv = ma.to_device(tv[None], eng.device)
     d_ct = ma.to_device(cts, eng.device)
     d_out = eng.empty(B, P["k"] * P["N"] + 1)
@@ -198,7 +274,22 @@ def main():
     torch.cuda.synchronize()
 
     # timed region: barrier + synchronize on both sides, MAX over ranks (mosfhet_amd/shard.py)
-    elapsed = shard.timed_region(step, args.steps, sync=torch.cuda.synchronize, device=eng.device)
+    elapsed = shard.timed_region(step, args.steps, sync=torch.cuda.synchronize, device=eng.device if backend == "nccl" else "cpu")
+
+    # N > 1: what makes the ranks replicas of one job -- the SAME bootstrap key on every GPU (same seed), DIFFERENT ciphertexts per rank, every rank's
+    # outputs decrypting -- gathered once, outside the timed region
+    replicas = None
+    if world > 1:
+        import zlib
+        mine = torch.tensor([zlib.crc32(bk.tobytes()), zlib.crc32(cts.tobytes()), int(np.log2(err + 1) * 1000)], dtype=torch.int64,
+                            device=eng.device if backend == "nccl" else "cpu")
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        every = torch.stack(every).cpu().numpy()
+        replicas = {"keys_identical": bool((every[:, 0] == every[0, 0]).all()), "inputs_distinct": len(set(every[:, 1].tolist())) == world,
+                    "max_phase_error_log2_per_rank": (every[:, 2] / 1000.0).tolist()}
+        if rank == 0 and not (replicas["keys_identical"] and replicas["inputs_distinct"]):
+            sys.exit("bench.py: the ranks are not replicas of one job: %s" % replicas)
 
     # the same step with the ciphertexts handed over in HOST buffers (pinned): H2D of the inputs + kernel + D2H of the results.  Reported
     # beside `value` for reference only (the contract's `value` has the inputs resident in HBM).
@@ -247,41 +338,29 @@ def main():
 
     traffic = measured_traffic("latest_traffic.json", 4096) if B == 4096 else None
 
-    # the external-product kernel on its own (BASELINE.json's HBM target): B_ep TRLWE samples against ONE key entry, inputs and outputs in HBM
-    ep = None
+    # the external-product kernel on its own (BASELINE.json's HBM target), at SET_1 and at the TFHEpp lvl2 set (N = 2048, l = 4: four of BASELINE's five
+    # configs): arithmetic intensity 5.2 FLOP/B at SET_1, 9.8 at lvl2 = the FP64 ridge, where the instruction-mix ceiling of the transforms (DESIGN.md
+    # 4.1) caps the HBM fraction near 0.45
+    ep = ep2 = None
     if rank == 0:
-        import torch
-        B_ep, N_, l_ = args.ep_batch, P["N"], P["l"]
-        g = torch.Generator(device="cpu").manual_seed(SEED)
-        d_ep_in = torch.randint(-2 ** 63, 2 ** 63 - 1, (B_ep, 2, N_), dtype=torch.int64, generator=g).to(eng.device)
-        d_ep_out = eng.empty(B_ep, 2, N_)
-        eng.external_product(bsk, 1, d_ep_in, out=d_ep_out)
-        torch.cuda.synchronize()
-        for _ in range(100):    # this kernel's own steady state: the clock the chip holds depends on the load of the last tenths of a second
-            eng.external_product(bsk, 1, d_ep_in, out=d_ep_out)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        reps, groups = 20, []
-        for _ in range(5):      # five groups of 20 back-to-back launches; the MEDIAN group is reported (min and max beside it)
-            ev[0].record(torch.cuda.current_stream())      # the engine launches on torch's current stream (mosfhet_amd/engine.py: _stream)
-            for _ in range(reps):
-                eng.external_product(bsk, 1, d_ep_in, out=d_ep_out)
-            ev[1].record(torch.cuda.current_stream())
-            ev[1].synchronize()
-            groups.append(ev[0].elapsed_time(ev[1]) / reps)
-        groups.sort()
-        ep_ms = groups[len(groups) // 2]
-        ep_bytes = B_ep * 2 * (2 * N_ * 8) + (2 * l_) * 2 * N_ * 8        # TRLWE in + TRLWE out per unit, the key entry once
-        ep_gbs = ep_bytes / (ep_ms * 1e-3) / 1e9
-        ep = {"bound": "hbm", "achieved": ep_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ep_gbs / HBM_PEAK_GBS, "traffic": measured_traffic("latest_traffic_ep.json", B_ep),
-              "kernel": "mosfhet::external_product_ldskey_kernel<2, 8, false>", "kernel_ms": ep_ms, "kernel_ms_min_max": [groups[0], groups[-1]], "units_per_launch": B_ep,
-              "algorithmic_bytes_per_launch": ep_bytes, "external_products_per_s": B_ep / (ep_ms * 1e-3),
-              "workload": "%d x trgsw_mul_trlwe_DFT + trlwe_from_DFT at SET_1 against one TRGSW_DFT (src/trgsw.c:385-423)" % B_ep}
-        del d_ep_in, d_ep_out
+        ep = external_product_leg(eng, ma, host, P, args.ep_batch, measured_traffic, "latest_traffic_ep.json",
+                                  "mosfhet::external_product_ldskey_kernel<2, 8, false>", torch)
+        ep2 = external_product_leg(eng, ma, host, dict(ma.PARAMS_LVL2), max(64, args.ep_batch // 4), measured_traffic, "latest_traffic_ep_lvl2.json",
+                                   "mosfhet::external_product_kernel<mosfhet::Fft2048T<false>, 4, 9, false>", torch)
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(P, bk, tv, cts[:64], args.cpu_seconds)
-        cpu["ffnt_single_ms"] = ffnt_single_ms(P, bk, tv, cts[0])      # BASELINE.json configs[0]
+    # sustained rate: the same step back to back for >= 2.5 s (the contract's timed region is K steps = a fraction of a second; this is the figure a
+    # long-running caller sees, and it keeps the GPU visibly busy for a utilisation sampler)
+    sustained = None
+    if world == 1:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_sus = 0
+        while time.perf_counter() - t0 < 2.5:
+            for _ in range(8):
+                step()
+            n_sus += 8
+            torch.cuda.synchronize()
+        sustained = {"bootstraps_per_s": n_sus * B / (time.perf_counter() - t0), "steps": n_sus, "seconds": time.perf_counter() - t0}
 
     if rank == 0:
         total = world * args.steps * B
@@ -293,6 +372,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            "value_regime": "%d HIP stream(s): consecutive steps are independent batches and %s; roofline.kernel_ms is ONE launch timed alone, so ms_per_step "
+                            "may be below it" % (len(streams), "overlap at launch boundaries" if len(streams) > 1 else "run strictly back to back"),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -310,6 +391,9 @@ def main():
                                              "note": "SURVEY 8(d) byte model (bootstrap key streamed once per ciphertext): not a bound, the "
                                                      "key is shared by the batch through L2 (see `traffic` for measured memory-side bytes)"}},
             "roofline_external_product": ep,
+            "roofline_external_product_lvl2": ep2,
+            "sustained": sustained,
+            "replicas": replicas,
             "cpu_baseline": cpu,
             "max_phase_error_log2": float(np.log2(err + 1)),
             "host_buffer_rate_per_gpu": host_rate,

@@ -515,20 +515,107 @@ void mc_trlwe_from_flat(TRLWE c, const Torus *flat) {
   memcpy(c->b->coeffs, flat + (size_t)c->k * N, sizeof(Torus) * (size_t)N);
 }
 
+/* ------------------------------------------------------------------ marshalling pool
+ * The reference's callers hold batches as arrays of separately allocated TLWE structs (applications/multi-ciphertext-arith/src/lut.c:12-17); turning
+ * 4096 of them into the flat device layout and back is 53 MB of pointer-chasing copies -- 2.5 ms on one core next to a 15.5 ms kernel.  A small pool
+ * of helper threads (plain memcpy workers: they never touch HIP) splits those loops; the calling thread takes part.  One job at a time: a second
+ * caller thread that finds the pool busy simply copies on its own.  MOSFHET_HIP_MARSHAL_THREADS = helpers (default 3, 0 disables). */
+typedef void (*mc_range_fn)(void *arg, int lo, int hi);
+static struct {
+  pthread_mutex_t user, lock;
+  pthread_cond_t go, done;
+  int helpers, started, generation, count, next, grain, working;
+  mc_range_fn fn;
+  void *arg;
+} g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, -1, 0, 0, 0, 0, 0, 0, NULL, NULL};
+
+static int pool_take(int *lo, int *hi) {   /* g_pool.lock held */
+  if (g_pool.next >= g_pool.count) return 0;
+  *lo = g_pool.next;
+  *hi = *lo + g_pool.grain < g_pool.count ? *lo + g_pool.grain : g_pool.count;
+  g_pool.next = *hi;
+  return 1;
+}
+static void *pool_worker(void *unused) {
+  (void)unused;
+  int seen = 0;
+  pthread_mutex_lock(&g_pool.lock);
+  for (;;) {
+    while (g_pool.generation == seen) pthread_cond_wait(&g_pool.go, &g_pool.lock);
+    seen = g_pool.generation;
+    g_pool.working++;
+    int lo, hi;
+    while (pool_take(&lo, &hi)) {
+      pthread_mutex_unlock(&g_pool.lock);
+      g_pool.fn(g_pool.arg, lo, hi);
+      pthread_mutex_lock(&g_pool.lock);
+    }
+    if (--g_pool.working == 0) pthread_cond_broadcast(&g_pool.done);
+  }
+  return NULL;
+}
+static void mc_parallel_for(mc_range_fn fn, void *arg, int count, int grain) {
+  if (g_pool.helpers < 0) {
+    const char *e = getenv("MOSFHET_HIP_MARSHAL_THREADS");
+    int want = e ? atoi(e) : 3;
+    if (want < 0) want = 0;
+    if (want > 15) want = 15;
+    __atomic_store_n(&g_pool.helpers, want, __ATOMIC_RELEASE);
+  }
+  if (g_pool.helpers == 0 || count < 4 * grain || pthread_mutex_trylock(&g_pool.user)) {
+    fn(arg, 0, count);
+    return;
+  }
+  pthread_mutex_lock(&g_pool.lock);
+  while (g_pool.started < g_pool.helpers) {
+    pthread_t t;
+    pthread_attr_t a;
+    pthread_attr_init(&a);
+    pthread_attr_setdetachstate(&a, PTHREAD_CREATE_DETACHED);
+    if (pthread_create(&t, &a, pool_worker, NULL)) { g_pool.helpers = g_pool.started; break; }
+    g_pool.started++;
+  }
+  g_pool.fn = fn; g_pool.arg = arg; g_pool.count = count; g_pool.next = 0; g_pool.grain = grain;
+  g_pool.generation++;
+  g_pool.working++;                    /* the caller works too */
+  pthread_cond_broadcast(&g_pool.go);
+  int lo, hi;
+  while (pool_take(&lo, &hi)) {
+    pthread_mutex_unlock(&g_pool.lock);
+    fn(arg, lo, hi);
+    pthread_mutex_lock(&g_pool.lock);
+  }
+  g_pool.working--;
+  while (g_pool.working > 0) pthread_cond_wait(&g_pool.done, &g_pool.lock);
+  pthread_mutex_unlock(&g_pool.lock);
+  pthread_mutex_unlock(&g_pool.user);
+}
+
+typedef struct { Torus *flat; TLWE *c; int n; } TlweSpan;
+static void tlwe_to_flat_range(void *pv, int lo, int hi) {
+  const TlweSpan *a = (const TlweSpan *)pv;
+  for (int i = lo; i < hi; i++) {
+    memcpy(a->flat + (size_t)i * (a->n + 1), a->c[i]->a, sizeof(Torus) * (size_t)a->n);
+    a->flat[(size_t)i * (a->n + 1) + a->n] = a->c[i]->b;
+  }
+}
+static void tlwe_from_flat_range(void *pv, int lo, int hi) {
+  const TlweSpan *a = (const TlweSpan *)pv;
+  for (int i = lo; i < hi; i++) {
+    memcpy(a->c[i]->a, a->flat + (size_t)i * (a->n + 1), sizeof(Torus) * (size_t)a->n);
+    a->c[i]->b = a->flat[(size_t)i * (a->n + 1) + a->n];
+  }
+}
 static void tlwe_array_to_flat(Torus *flat, TLWE *c, int count, int n) {
   if (n < 0) return;
-  for (int i = 0; i < count; i++) {
-    memcpy(flat + (size_t)i * (n + 1), c[i]->a, sizeof(Torus) * (size_t)n);
-    flat[(size_t)i * (n + 1) + n] = c[i]->b;
-  }
+  TlweSpan a = {flat, c, n};
+  mc_parallel_for(tlwe_to_flat_range, &a, count, 64);
 }
 
 static void tlwe_array_from_flat(TLWE *c, const Torus *flat, int count, int n) {
   if (n < 0) return;
-  for (int i = 0; i < count; i++) {
-    memcpy(c[i]->a, flat + (size_t)i * (n + 1), sizeof(Torus) * (size_t)n);
-    c[i]->b = flat[(size_t)i * (n + 1) + n];
-  }
+  TlweSpan a = {(Torus *)flat, c, n};
+  mc_parallel_for(tlwe_from_flat_range, &a, count, 64);
 }
 
 void *mc_dev_alloc(size_t bytes) {

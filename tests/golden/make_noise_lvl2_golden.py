@@ -1,12 +1,18 @@
 """Golden fixture: the REFERENCE's own noise at N = 2048 (TFHEpp lvl2: n = 632, l = 4, Bg = 2^9) for the three batch criteria the GPU tests used to
 derive by hand:
 
-  pbs   |phase - LUT slot| of programmable_bootstrap (precision 3; test/tests.c:1545-1560's shape) over 512 samples, both reference builds;
-  ga    the same for functional_bootstrap_ga at n = 632 (test/tests.c:1614-1640's shape: torus_base 4), 256 samples -- blind_rotate_ga forces every
+  pbs   |phase - LUT slot| of programmable_bootstrap (precision 3; test/tests.c:1545-1560's shape) over 2048 samples, both reference builds;
+  ga    the same for functional_bootstrap_ga at n = 632 (test/tests.c:1614-1640's shape: torus_base 4), 512 samples -- blind_rotate_ga forces every
         mod-switched mask word odd (src/bootstrap_ga.c:44), so the error has a drift component on top of the noise;
   cb    circuit_bootstrap_3 at BASELINE.json configs[3]'s keys (test/tests.c:967-1003: packing key t = 6, base 2^4 -- 184,320 seed-compressed rows made by
         the reference's own trlwe_new_packing1_KS_key --, private pair t = 20, base 2^2): every output TRGSW multiplies a random TRLWE sample
-        (trgsw_mul_trlwe_DFT) and the phase error of the product is taken per coefficient, 48 inputs x 2048 coefficients.
+        (trgsw_mul_trlwe_DFT) and the phase error of the product is taken per coefficient, 192 inputs x 2048 coefficients.  The error of one output is
+        dominated by ONE rounding term per gadget level (the 40 dropped bits of the packing key switch land on X^0 and are spread by the private key
+        switch's multiplication by the key), so its size varies from output to output like a chi-square with 4 degrees of freedom: stored are the rms,
+        maximum and share within 2^58 of EVERY output, and the full error vectors of the first 24.  The amplification of that term depends on the
+        random sample being multiplied and on the key (the negacyclic product of the sample's digit polynomials with the 0/1 key is dominated by a few
+        low-frequency bins: +-20 % in rms between two samples), so the sample and its message are stored too and the GPU test uses the same keys
+        (same seed) and the same sample.
 
 Keys and ciphertexts come from the host layer's seeded generator (the same seeds as the GPU tests); everything is computed by oracle/_ref, the reference
 compiled from /root/reference.  Stored: the error magnitudes (float32 log2 for the big one), seeds and parameters -- data only.
@@ -24,7 +30,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 SEED = 0x4E4F4953   # "NOIS"
-B_PBS, B_GA, B_CB = 512, 256, 48
+B_PBS, B_GA, B_CB, B_CB_FULL = 2048, 512, 192, 24
 
 
 def dist(ph, want):
@@ -108,10 +114,11 @@ def main():
     stats("cb products", errs)
     stats("  selector 1", errs[[b for b in range(B_CB) if ms[b]]])
     stats("  selector 0", errs[[b for b in range(B_CB) if not ms[b]]])
-    res["cb_log2"] = np.log2(errs + 1.0).astype(np.float32)
+    res["cb_log2"] = np.log2(errs[:B_CB_FULL] + 1.0).astype(np.float32)
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "noise_lvl2.npz"), seed=np.uint64(SEED), lut=lut,
                         pbs_avx512=res["pbs_avx512"], pbs_ffnt=res["pbs_ffnt"], ga=res["ga"], cb_log2=res["cb_log2"],
-                        cb_messages=np.array(ms), params=np.array([n, N, l, Bg, 6, 4, 20, 2], dtype=np.int64))
+                        cb_rms=np.sqrt((errs ** 2).mean(axis=1)), cb_max=errs.max(axis=1), cb_within58=(errs < 2.0 ** 58).mean(axis=1),
+                        cb_rnd=rnd, cb_msg=msg, cb_messages=np.array(ms), params=np.array([n, N, l, Bg, 6, 4, 20, 2], dtype=np.int64))
 
 
 if __name__ == "__main__":

@@ -227,8 +227,8 @@ def test_reference_phase_error_distribution_pins_the_batch_criterion(oracle):
 
 
 def test_reference_noise_at_lvl2_pins_the_n2048_criteria(oracle):
-    """tests/golden/noise_lvl2.npz (make_noise_lvl2_golden.py): the reference's own phase errors at the TFHEpp lvl2 set -- 512 programmable bootstraps
-    through both of its builds, 256 functional_bootstrap_ga at n = 632, and 48 circuit_bootstrap_3 outputs (config-4 keys, the reference's own packing
+    """tests/golden/noise_lvl2.npz (make_noise_lvl2_golden.py): the reference's own phase errors at the TFHEpp lvl2 set -- 2048 programmable bootstraps
+    through both of its builds, 512 functional_bootstrap_ga at n = 632, and 192 circuit_bootstrap_3 outputs (config-4 keys, the reference's own packing
     key) multiplied into a random TRLWE sample.  They pin the batch criteria of the N = 2048 GPU tests (rms within 5-15 %, maximum + 1 bit) where
     round 2 had hand-derived "97 % / 99 % within 2^58" clauses; here: the fixture is self-consistent, and the ORACLE's bootstraps at the same
     parameters and seeds have the same noise (32 of them: the oracle takes 0.1 s per lvl2 bootstrap)."""
@@ -239,17 +239,21 @@ def test_reference_noise_at_lvl2_pins_the_n2048_criteria(oracle):
     assert tuple(g["params"]) == (632, 2048, 4, 9, 6, 4, 20, 2)
     rms = lambda e: np.sqrt((e ** 2).mean())
     pa, pf, ga = g["pbs_avx512"], g["pbs_ffnt"], g["ga"]
-    assert pa.size == pf.size == 512 and ga.size == 256
+    assert pa.size == pf.size == 2048 and ga.size == 512
     # lvl2 leaves 17 bits of headroom under the reference's 2^58 assertion: rms 2^39.0, max 2^40.6
     for e in (pa, pf, ga):
         assert e.max() < 2.0 ** 41.5 and 38.5 < np.log2(rms(e)) < 39.5
     assert abs(rms(pf) / rms(pa) - 1) < 0.10
     cb = 2.0 ** g["cb_log2"].astype(np.float64) - 1.0
-    assert cb.shape == (48, 2048)
-    # ... the circuit bootstrap does not: 1.1 % of the reference's own product coefficients miss its 2^58 assertion (test/tests.c:992)
-    assert 56.2 < np.log2(rms(cb)) < 56.6 and 2.0 ** 58.5 < cb.max() < 2.0 ** 60 and 0.98 < (cb < 2.0 ** 58).mean() < 0.995
+    assert cb.shape == (24, 2048) and g["cb_rms"].shape == g["cb_max"].shape == g["cb_within58"].shape == (192,)
+    assert np.allclose(np.sqrt((cb ** 2).mean(axis=1)), g["cb_rms"][:24], rtol=1e-3) and np.allclose(cb.max(axis=1), g["cb_max"][:24], rtol=1e-3)
+    # ... the circuit bootstrap does not: 1 % of the reference's own product coefficients miss its 2^58 assertion (test/tests.c:992), and one output's
+    # error size varies like a chi-square with few degrees of freedom (one rounding term per gadget level dominates)
+    pooled = np.sqrt((g["cb_rms"] ** 2).mean())
+    assert 56.3 < np.log2(pooled) < 56.7 and 2.0 ** 58.5 < g["cb_max"].max() < 2.0 ** 60 and 0.98 < g["cb_within58"].mean() < 0.995
+    assert np.log2(g["cb_rms"].max() / g["cb_rms"].min()) > 2.5
     ones = g["cb_messages"] != 0
-    assert abs(rms(cb[ones]) / rms(cb[~ones]) - 1) < 0.15          # selector 1 and selector 0: the same noise
+    assert abs(np.sqrt((g["cb_rms"][ones] ** 2).mean()) / np.sqrt((g["cb_rms"][~ones] ** 2).mean()) - 1) < 0.20   # selector 1 and selector 0: the same noise
     # the oracle at the same seeds
     import mosfhet_amd as ma
     from mosfhet_amd import host
@@ -260,7 +264,7 @@ def test_reference_noise_at_lvl2_pins_the_n2048_criteria(oracle):
     bk = host.gen_bootstrap_key(rk, lk, P["l"], P["Bg_bit"])
     lut = g["lut"]
     tv = host.torus_packing(lut, 1, P["N"])
-    cts = host.tlwe_samples([host.double2torus((b % 4) / 8.0) for b in range(512)], lk)[:32]
+    cts = host.tlwe_samples([host.double2torus((b % 4) / 8.0) for b in range(2048)], lk)[:32]
     bk_dft = oracle.bk_to_dft(bk, 1, P["l"])
     with ThreadPoolExecutor(8) as pool:
         outs = list(pool.map(lambda c: oracle.programmable_bootstrap(tv, c, bk_dft, P["l"], P["Bg_bit"], 3, 0, 0), cts))
