@@ -21,8 +21,13 @@
  *   return value     0 on success, a negative MOSFHET_HIP_E* code otherwise; mosfhet_hip_last_error()
  *                    returns a thread-local message.  The legacy void API of mosfhet_compat.h aborts on
  *                    error, like the reference's assert/exit behaviour (src/misc.c:104-128).
- *   supported        k = 1; N = 1024, 2048, 4096 (all ring degrees of the reference's parameter sets, test/tests.c:37-62);
- *                    l <= 4 with l*Bg_bit < 64 (compile-time specialisations for 2x8, 4x9, 1x23); any n.
+ *   supported        tuned kernels: k = 1; N = 1024, 2048, 4096 (all ring degrees of the reference's parameter sets, test/tests.c:37-62);
+ *                    l <= 6 with l*Bg_bit < 64 (compile-time specialisations for 2x8, 4x9, 1x23); any n.  Every entry point.
+ *                    general path (csrc/general_kernels.h; the reference is generic in k and N, src/trgsw.c:385-423): k <= 3 and any power-of-two
+ *                    N in 256 .. 16384 -- a correctness path, one workgroup per ciphertext, bit-identical to the same oracle.  A bootstrap key with such
+ *                    parameters (mosfhet_hip_bsk_create[_from_device]) serves programmable / functional bootstraps (+ wo_extract), blind_rotate, the
+ *                    full-domain bootstrap, key switch + bootstrap and external products; the other entry points return MOSFHET_HIP_EINVAL for it.
+ *                    mosfhet_hip_torus_to_dft_batch / _dft_to_torus_batch take any such N (natural slot order outside 1024 / 2048 / 4096).
  *   threading        re-entrant, like the reference (thread-local scratch there, src/polynomial.c:269-352): a context and its key
  *                    handles are read-only after creation and may be shared by any number of host threads; device temporaries of
  *                    the compositions and of the table key switches belong to the CALLING THREAD (grown on demand, released at

@@ -14,7 +14,11 @@
 #include <type_traits>
 #include <vector>
 
+#include <map>
+#include <mutex>
+
 #include "bootstrap_kernels.h"
+#include "general_kernels.h"
 #include "keyswitch_kernels.h"
 #include "ext_kernels.h"
 #include "keygen_kernels.h"
@@ -42,11 +46,14 @@ static int fail(int code, const char *fmt, ...) {
 struct mosfhet_hip_ctx {
   int device = 0;
   d2 *tw1024 = nullptr, *tw2048 = nullptr, *tw4096 = nullptr;  // device twiddle tables
+  std::map<int, d2 *> tw_general;                               // ... of the other rings, made on first use (general_kernels.h)
+  std::mutex tw_lock;
   ~mosfhet_hip_ctx() {
     (void)hipSetDevice(device);
     if (tw1024) (void)hipFree(tw1024);
     if (tw2048) (void)hipFree(tw2048);
     if (tw4096) (void)hipFree(tw4096);
+    for (auto &e : tw_general) (void)hipFree(e.second);
   }
 };
 
@@ -113,6 +120,7 @@ struct mosfhet_hip_bsk {
   int unfolding = 1;          // > 1: d_bk is null and d_su holds the torus-domain samples of new_bootstrap_key (src/bootstrap.c:23-48)
   uint64_t *d_su = nullptr;   // [n 2^u / u][2l][2][N]
   size_t bytes = 0;
+  bool general = false;       // k > 1 or a ring without a tuned kernel: natural slot order, general_kernels.h (bootstraps and external products only)
   bool owns = true;           // false: d_bk belongs to the caller (mosfhet_hip_bsk_view_create)
   ~mosfhet_hip_bsk() {
     if (ctx) (void)hipSetDevice(ctx->device);
@@ -244,27 +252,77 @@ extern "C" int mosfhet_hip_ctx_sync(mosfhet_hip_ctx_t ctx, void *stream) {
   return MOSFHET_HIP_OK;
 }
 
-static int check_params(const char *who, int k, int N, int l, int Bg_bit) {
-  if (k != 1) return fail(MOSFHET_HIP_EINVAL, "%s: only k = 1 is supported (got %d)", who, k);
-  if (!ring_ok(N)) return fail(MOSFHET_HIP_EINVAL, "%s: ring degree N = %d not supported (1024, 2048, 4096)", who, N);
+// k = 1 and N in {1024, 2048, 4096}: the tuned kernels.  Any other power-of-two ring up to 16384 and k <= 3: the general path (general_kernels.h).
+static bool general_ring(int k, int N) { return !(k == 1 && ring_ok(N)); }
+static int check_params(const char *who, int k, int N, int l, int Bg_bit, bool allow_general = false) {
+  if (general_ring(k, N)) {
+    if (!allow_general) {
+      if (k != 1) return fail(MOSFHET_HIP_EINVAL, "%s: only k = 1 is supported here (got %d)", who, k);
+      return fail(MOSFHET_HIP_EINVAL, "%s: ring degree N = %d not supported here (1024, 2048, 4096)", who, N);
+    }
+    if (k < 1 || k > 3) return fail(MOSFHET_HIP_EINVAL, "%s: k = %d not supported (1 .. 3)", who, k);
+    if (N < 256 || N > 16384 || (N & (N - 1))) return fail(MOSFHET_HIP_EINVAL, "%s: ring degree N = %d not supported (a power of two in 256 .. 16384)", who, N);
+  }
   if (l < 1 || Bg_bit < 1 || Bg_bit > 31 || l * Bg_bit >= 64) return fail(MOSFHET_HIP_EINVAL, "%s: bad gadget l=%d Bg_bit=%d (Bg_bit <= 31, l*Bg_bit < 64)", who, l, Bg_bit);
   if (l > 6) return fail(MOSFHET_HIP_EINVAL, "%s: l = %d not instantiated (1..6: the reference's own programs go up to l = 6, applications/multi-ciphertext-arith/src/ufhe.c:19)", who, l);
   return MOSFHET_HIP_OK;
 }
 
+static int ilog2(int x) { int r = 0; while ((1 << r) < x) r++; return r; }
+
+// twiddle table of a general ring on the context's device, made on first use
+static int general_twiddles(mosfhet_hip_ctx_t ctx, int N, const d2 **out) {
+  if (N == 1024) { *out = ctx->tw1024; return MOSFHET_HIP_OK; }
+  if (N == 2048) { *out = ctx->tw2048; return MOSFHET_HIP_OK; }
+  if (N == 4096) { *out = ctx->tw4096; return MOSFHET_HIP_OK; }
+  std::lock_guard<std::mutex> hold(ctx->tw_lock);
+  auto it = ctx->tw_general.find(N);
+  if (it == ctx->tw_general.end()) {
+    std::vector<double> tw;
+    make_twiddles(N, tw);
+    d2 *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, tw.size() * sizeof(double) + 16));
+    HIP_TRY(hipMemcpy(d, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice));
+    it = ctx->tw_general.emplace(N, d).first;
+  }
+  *out = it->second;
+  return MOSFHET_HIP_OK;
+}
+
+// general kernels keep the whole transform in LDS: (N / 2) complex = 8 N bytes, above 64 KiB only with the attribute set
+template <class K>
+static int general_lds(K kernel, int N) {
+  const int bytes = 8 * N;
+  if (bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  return MOSFHET_HIP_OK;
+}
+
+#define TUNED_ONLY(bsk_, who_)                                                                                                                       \
+  do {                                                                                                                                               \
+    if ((bsk_) && (bsk_)->general)                                                                                                                   \
+      return fail(MOSFHET_HIP_EINVAL, "%s: keys of the general-ring path (k > 1 or N outside 1024 / 2048 / 4096) serve bootstraps, the full-domain " \
+                                      "bootstrap, key-switch + bootstrap and external products only", who_);                                         \
+  } while (0)
+
 // ---- bootstrap key ----
 extern "C" int mosfhet_hip_bsk_create_from_device(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t *out, const uint64_t *d_bk,
                                                   int n, int k, int N, int l, int Bg_bit, void *stream) {
   if (!ctx || !out || !d_bk || n < 1) return fail(MOSFHET_HIP_EINVAL, "bsk_create: bad argument");
-  int rc = check_params("bsk_create", k, N, l, Bg_bit);
+  int rc = check_params("bsk_create", k, N, l, Bg_bit, true);
   if (rc) return rc;
   HIP_TRY(hipSetDevice(ctx->device));
   std::unique_ptr<mosfhet_hip_bsk> b_owner(new mosfhet_hip_bsk());
   mosfhet_hip_bsk *b = b_owner.get();
   b->ctx = ctx; b->n = n; b->k = k; b->N = N; b->l = l; b->Bg_bit = Bg_bit;
+  b->general = general_ring(k, N);
   const size_t polys = (size_t)n * (k + 1) * l * (k + 1);
   b->bytes = polys * N * sizeof(double);
   HIP_TRY(hipMalloc((void **)&b->d_bk, b->bytes));
+  if (b->general) {
+    const d2 *tw = nullptr;
+    if ((rc = general_twiddles(ctx, N, &tw)) || (rc = general_lds(torus_to_dft_general_kernel, N))) return rc;
+    hipLaunchKernelGGL(torus_to_dft_general_kernel, dim3((unsigned)polys), dim3(GEN_THREADS), (size_t)8 * N, pick(ctx, stream), d_bk, b->d_bk, tw, N, ilog2(N / 2));
+  } else
   RING_DISPATCH(ctx, N, hipLaunchKernelGGL(torus_to_dft_kernel<F>, dim3((unsigned)polys), dim3(F::THREADS), 0, pick(ctx, stream), d_bk, b->d_bk, TW));
   HIP_TRY(hipGetLastError());
   *out = b_owner.release();
@@ -274,7 +332,7 @@ extern "C" int mosfhet_hip_bsk_create_from_device(mosfhet_hip_ctx_t ctx, mosfhet
 extern "C" int mosfhet_hip_bsk_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t *out, const uint64_t *h_bk,
                                       int n, int k, int N, int l, int Bg_bit) {
   if (!ctx || !out || !h_bk || n < 1) return fail(MOSFHET_HIP_EINVAL, "bsk_create: bad argument");
-  int rc = check_params("bsk_create", k, N, l, Bg_bit);
+  int rc = check_params("bsk_create", k, N, l, Bg_bit, true);
   if (rc) return rc;
   HIP_TRY(hipSetDevice(ctx->device));
   const size_t bytes = (size_t)n * (k + 1) * l * (k + 1) * N * sizeof(uint64_t);
@@ -304,6 +362,10 @@ extern "C" int mosfhet_hip_bsk_export_dft(mosfhet_hip_bsk_t bsk, double *h_out) 
   HIP_TRY(hipMemcpy(tmp.data(), bsk->d_bk, bsk->bytes, hipMemcpyDeviceToHost));
   const int M = bsk->N / 2;
   const size_t polys = bsk->bytes / sizeof(double) / bsk->N;
+  if (bsk->general) {   // natural slot order already
+    memcpy(h_out, tmp.data(), bsk->bytes);
+    return MOSFHET_HIP_OK;
+  }
   for (size_t q = 0; q < polys; q++)
     for (int j = 0; j < M; j++) {  // oracle index j = thread*8 + m  <->  device index m*T + thread, T = N/16
       const int dev = (j & 7) * (bsk->N / 16) + (j >> 3);
@@ -458,6 +520,28 @@ static int bootstrap_common(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hip_
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
   if (bsk->unfolding > 1) return bootstrap_unfolded(who, ctx, bsk, d_out, d_tv, tv_count, d_in, count, pre, kappa, theta, torus_base, extract, skip_init, stream, rows);
+  if (bsk->general) {
+    if (rows != 1) return fail(MOSFHET_HIP_EINVAL, "%s: TRGSW accumulators need a tuned ring (k = 1, N in 1024 / 2048 / 4096)", who);
+    GeneralParams g;
+    int rc = general_twiddles(ctx, bsk->N, &g.tw);
+    if (rc || (rc = general_lds(pbs_general_kernel, bsk->N))) return rc;
+    const int k = bsk->k, N = bsk->N;
+    // accumulators ([count][k+1][N] words; the output buffer itself when the rotated TRLWE is what is asked for) and products ([count][k+1][N/2] complex)
+    uint64_t *scratch = nullptr;
+    const size_t acc_words = extract ? (size_t)count * (k + 1) * N : 0, prod_words = (size_t)count * (k + 1) * N;
+    if ((rc = pool_get(ctx->device, POOL_BSK, acc_words + prod_words, &scratch))) return rc;
+    g.bk = bsk->d_bk; g.in = d_in; g.tv = d_tv; g.out = d_out;
+    g.acc = extract ? scratch : d_out;
+    g.prod = reinterpret_cast<d2 *>(scratch + acc_words);
+    g.tv_stride = (tv_count == 1) ? 0 : (long long)(k + 1) * N;
+    g.n = bsk->n; g.k = k; g.N = N; g.logM = ilog2(N / 2); g.l = bsk->l; g.Bg_bit = bsk->Bg_bit;
+    g.pre = pre; g.kappa = kappa; g.theta = theta;
+    g.prec_offset = skip_init ? 0 : (uint64_t)((int64_t)(18446744073709551616.0 * (1. / (4 * (double)torus_base))));
+    g.extract = extract; g.skip_init = skip_init;
+    hipLaunchKernelGGL(pbs_general_kernel, dim3((unsigned)count), dim3(GEN_THREADS), (size_t)8 * N, pick(ctx, stream), g);
+    HIP_TRY(hipGetLastError());
+    return MOSFHET_HIP_OK;
+  }
   PbsParams p;
   p.bk = bsk->d_bk;
   p.tw = bsk->N == 1024 ? ctx->tw1024 : (bsk->N == 2048 ? ctx->tw2048 : ctx->tw4096);
@@ -528,6 +612,19 @@ extern "C" int mosfhet_hip_external_product_batch(mosfhet_hip_ctx_t ctx, mosfhet
   if (bsk->unfolding > 1) return fail(MOSFHET_HIP_EINVAL, "external_product: an unfolded key has no DFT entries");
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
+  if (bsk->general) {
+    const int k = bsk->k, N = bsk->N, M = N / 2;
+    const d2 *tw = nullptr;
+    int rc = general_twiddles(ctx, N, &tw);
+    if (rc || (rc = general_lds(external_product_general_kernel, N))) return rc;
+    uint64_t *prod = nullptr;
+    if ((rc = pool_get(ctx->device, POOL_BSK, (size_t)count * (k + 1) * N, &prod))) return rc;
+    const d2 *g = bsk->d_bk + (size_t)key_index * (k + 1) * bsk->l * (k + 1) * M;
+    hipLaunchKernelGGL(external_product_general_kernel, dim3((unsigned)count), dim3(GEN_THREADS), (size_t)8 * N, pick(ctx, stream), g, (size_t)0, tw, d_in, d_out,
+                       reinterpret_cast<d2 *>(prod), k, N, ilog2(M), bsk->l, bsk->Bg_bit);
+    HIP_TRY(hipGetLastError());
+    return MOSFHET_HIP_OK;
+  }
   const d2 *row = bsk->d_bk + (size_t)key_index * (2 * bsk->l * 2 * (bsk->N / 2));
   hipStream_t s = pick(ctx, stream);
   RING_DISPATCH(ctx, bsk->N, launch_external_product<F>(bsk->l, bsk->Bg_bit, s, row, TW, d_in, d_out, count, (size_t)0, (size_t)2 * F::N, nullptr, nullptr, bsk->owns));
@@ -538,9 +635,17 @@ extern "C" int mosfhet_hip_external_product_batch(mosfhet_hip_ctx_t ctx, mosfhet
 // ---- polynomial-level entry points ----
 extern "C" int mosfhet_hip_torus_to_dft_batch(mosfhet_hip_ctx_t ctx, double *d_out, const uint64_t *d_in, int N, int count, void *stream) {
   if (!ctx || (count > 0 && !d_out) || (count > 0 && !d_in) || count < 0) return fail(MOSFHET_HIP_EINVAL, "torus_to_dft: bad argument");
-  if (!ring_ok(N)) return fail(MOSFHET_HIP_EINVAL, "torus_to_dft: N = %d not supported (1024, 2048, 4096)", N);
+  if (!ring_ok(N) && (N < 256 || N > 16384 || (N & (N - 1)))) return fail(MOSFHET_HIP_EINVAL, "torus_to_dft: N = %d not supported (a power of two in 256 .. 16384)", N);
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
+  if (!ring_ok(N)) {   // general ring: natural slot order (general_kernels.h)
+    const d2 *tw = nullptr;
+    int rc = general_twiddles(ctx, N, &tw);
+    if (rc || (rc = general_lds(torus_to_dft_general_kernel, N))) return rc;
+    hipLaunchKernelGGL(torus_to_dft_general_kernel, dim3((unsigned)count), dim3(GEN_THREADS), (size_t)8 * N, pick(ctx, stream), d_in, (d2 *)d_out, tw, N, ilog2(N / 2));
+    HIP_TRY(hipGetLastError());
+    return MOSFHET_HIP_OK;
+  }
   RING_DISPATCH(ctx, N, hipLaunchKernelGGL(torus_to_dft_kernel<F>, dim3(count), dim3(F::THREADS), 0, pick(ctx, stream), d_in, (d2 *)d_out, TW));
   HIP_TRY(hipGetLastError());
   return MOSFHET_HIP_OK;
@@ -548,9 +653,17 @@ extern "C" int mosfhet_hip_torus_to_dft_batch(mosfhet_hip_ctx_t ctx, double *d_o
 
 extern "C" int mosfhet_hip_dft_to_torus_batch(mosfhet_hip_ctx_t ctx, uint64_t *d_out, const double *d_in, int N, int count, void *stream) {
   if (!ctx || (count > 0 && !d_out) || (count > 0 && !d_in) || count < 0) return fail(MOSFHET_HIP_EINVAL, "dft_to_torus: bad argument");
-  if (!ring_ok(N)) return fail(MOSFHET_HIP_EINVAL, "dft_to_torus: N = %d not supported (1024, 2048, 4096)", N);
+  if (!ring_ok(N) && (N < 256 || N > 16384 || (N & (N - 1)))) return fail(MOSFHET_HIP_EINVAL, "dft_to_torus: N = %d not supported (a power of two in 256 .. 16384)", N);
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
+  if (!ring_ok(N)) {
+    const d2 *tw = nullptr;
+    int rc = general_twiddles(ctx, N, &tw);
+    if (rc || (rc = general_lds(dft_to_torus_general_kernel, N))) return rc;
+    hipLaunchKernelGGL(dft_to_torus_general_kernel, dim3((unsigned)count), dim3(GEN_THREADS), (size_t)8 * N, pick(ctx, stream), (const d2 *)d_in, d_out, tw, N, ilog2(N / 2));
+    HIP_TRY(hipGetLastError());
+    return MOSFHET_HIP_OK;
+  }
   RING_DISPATCH(ctx, N, hipLaunchKernelGGL(dft_to_torus_kernel<F>, dim3(count), dim3(F::THREADS), 0, pick(ctx, stream), (const d2 *)d_in, d_out, TW));
   HIP_TRY(hipGetLastError());
   return MOSFHET_HIP_OK;
@@ -636,18 +749,20 @@ extern "C" int mosfhet_hip_full_domain_functional_bootstrap_batch(mosfhet_hip_ct
     return fail(MOSFHET_HIP_EINVAL, "fdfb: key-switch key is %d -> %d, expected %d -> %d", ksk->n_in, ksk->n_out, bsk->k * bsk->N, bsk->n);
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
-  const int N = bsk->N, n = bsk->n;
-  const size_t w_tv = (size_t)2 * N, w_sign = (size_t)count * (N + 1), w_in2 = (size_t)count * (n + 1);
+  const int N = bsk->N, n = bsk->n, k = bsk->k;
+  const size_t w_tv = (size_t)(k + 1) * N, w_sign = (size_t)count * (k * N + 1), w_in2 = (size_t)count * (n + 1);
+  // (general keys keep their accumulators in the POOL_BSK slot: this composition's temporaries take another one)
   uint64_t *tv_sign = nullptr;
-  int rc = bsk_scratch(bsk, w_tv + w_sign + w_in2, &tv_sign);
+  int rc = bsk->general ? pool_get(bsk->ctx->device, POOL_EXT0, w_tv + w_sign + w_in2, &tv_sign) : bsk_scratch(bsk, w_tv + w_sign + w_in2, &tv_sign);
   if (rc) return rc;
   uint64_t *ct_sign = tv_sign + w_tv, *in2 = ct_sign + w_sign;
   hipStream_t s = pick(ctx, stream);
-  // src/bootstrap.c:525-527: sign = 2^62 - 2^(62 - precision), constant test vector
+  // src/bootstrap.c:525-527: sign = 2^62 - 2^(62 - precision), constant test vector (mask components zero, body constant)
   const uint64_t sign = (1ull << 62) - (1ull << (62 - precision));
-  hipLaunchKernelGGL(trlwe_constant_kernel, dim3((N + 255) / 256), dim3(256), 0, s, tv_sign, N, sign);
+  if (k > 1) HIP_TRY(hipMemsetAsync(tv_sign, 0, (size_t)(k - 1) * N * sizeof(uint64_t), s));
+  hipLaunchKernelGGL(trlwe_constant_kernel, dim3((N + 255) / 256), dim3(256), 0, s, tv_sign + (size_t)(k - 1) * N, N, sign);
   if ((rc = mosfhet_hip_functional_bootstrap_batch(ctx, bsk, ct_sign, tv_sign, 1, d_in, count, 1 << (precision - 1), stream))) return rc;
-  hipLaunchKernelGGL(tlwe_add_to_b_kernel, dim3((count + 255) / 256), dim3(256), 0, s, ct_sign, count, (size_t)N + 1, (uint64_t)0 - sign);
+  hipLaunchKernelGGL(tlwe_add_to_b_kernel, dim3((count + 255) / 256), dim3(256), 0, s, ct_sign, count, (size_t)k * N + 1, (uint64_t)0 - sign);
   if ((rc = mosfhet_hip_tlwe_keyswitch_batch(ctx, ksk, in2, ct_sign, count, stream))) return rc;
   if ((rc = mosfhet_hip_tlwe_addto_batch(ctx, in2, d_in, n, count, stream))) return rc;
   return mosfhet_hip_functional_bootstrap_batch(ctx, bsk, d_out, d_tv, tv_count, in2, count, 1 << precision, stream);
@@ -656,6 +771,7 @@ extern "C" int mosfhet_hip_full_domain_functional_bootstrap_batch(mosfhet_hip_ct
 extern "C" int mosfhet_hip_multivalue_bootstrap_CLOT21_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_out,
                                                              const uint64_t *d_tv, int tv_count, const uint64_t *d_in, int count,
                                                              int torus_base, int n_luts, void *stream) {
+  TUNED_ONLY(bsk, "multivalue_bootstrap_CLOT21");
   if (!ctx || !bsk || (count > 0 && !d_out) || (count > 0 && !d_tv) || (count > 0 && !d_in) || count < 0 || torus_base < 1 || n_luts < 1)
     return fail(MOSFHET_HIP_EINVAL, "multivalue_CLOT21: bad argument");
   const int N = bsk->N;
@@ -753,6 +869,7 @@ extern "C" int mosfhet_hip_trlwe_eval_automorphism_batch(mosfhet_hip_ctx_t ctx, 
 extern "C" int mosfhet_hip_functional_bootstrap_ga_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, mosfhet_hip_gak_t gak,
                                                          uint64_t *d_out, const uint64_t *d_tv, int tv_count, const uint64_t *d_in,
                                                          int count, int torus_base, int extract, void *stream) {
+  TUNED_ONLY(bsk, "functional_bootstrap_ga");
   if (!ctx || !bsk || !gak || (count > 0 && !d_out) || (count > 0 && !d_tv) || (count > 0 && !d_in) || count < 0 || torus_base < 1)
     return fail(MOSFHET_HIP_EINVAL, "functional_bootstrap_ga: bad argument");
   if (tv_count != 1 && tv_count != count) return fail(MOSFHET_HIP_EINVAL, "functional_bootstrap_ga: tv_count must be 1 or count");
@@ -838,6 +955,7 @@ __global__ void circuit_bootstrap_lut_kernel(uint64_t *__restrict__ tv, int N, i
 
 extern "C" int mosfhet_hip_circuit_bootstrap_3_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, mosfhet_hip_gak_t kska, mosfhet_hip_ksk_t kskb,
                                                      uint64_t *d_out, const uint64_t *d_in, int count, void *stream) {
+  TUNED_ONLY(bsk, "circuit_bootstrap_3");
   if (!ctx || !bsk || !kska || !kskb || (count > 0 && !d_out) || (count > 0 && !d_in) || count < 0) return fail(MOSFHET_HIP_EINVAL, "circuit_bootstrap_3: bad argument");
   const int N = bsk->N, l = bsk->l;
   if (kska->entries != 2 || kska->N != N) return fail(MOSFHET_HIP_EINVAL, "circuit_bootstrap_3: kska must be the 2-entry private key-switch set for N");

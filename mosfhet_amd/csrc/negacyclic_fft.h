@@ -689,6 +689,14 @@ struct RoundCtx {
     asm volatile("" : "+s"(two32));
     asm volatile("" : "+s"(scale32));
   }
+  // run-time ring (general_kernels.h): s = 2^-(64 + log2 M) and s 2^32, both assembled from their exponents by the scalar unit (there is no scalar
+  // floating point to multiply them with)
+  __device__ __forceinline__ explicit RoundCtx(int logM)
+      : scale(__longlong_as_double((long long)(1023 - 64 - logM) << 52)), magic(0x1.8p52), two32(0x1p32), scale32(__longlong_as_double((long long)(1023 - 32 - logM) << 52)) {
+    asm volatile("" : "+v"(magic));
+    asm volatile("" : "+s"(two32));
+    asm volatile("" : "+s"(scale32));
+  }
 };
 __device__ __forceinline__ uint64_t round_mod_2_64(double v, const RoundCtx &rc) {
   double f = v * rc.scale;

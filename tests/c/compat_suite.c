@@ -566,11 +566,14 @@ static void case_threads(void) {
 /* the reference's default parameter set SET_2 (test/tests.c:43-45: N = 2048, l = 1, Bg = 2^23) and its largest, SET_3 (:47-49: N = 4096, l = 1,
  * Bg = 2^22), with a shortened LWE key: bootstraps, the batch entry, the key switch back and the full-domain bootstrap on those rings */
 static void case_other_rings(void) {
-  static const struct { int N, Bg_bit; double sigma; } sets[2] = {{2048, 23, 2.2148688116005568e-16}, {4096, 22, 2.2148688116005568e-16}};
-  for (int q = 0; q < 2; q++) {
-    const int N2 = sets[q].N, l2 = 1, Bg2 = sets[q].Bg_bit, n2 = 64;
+  /* the reference's larger rings (tuned kernels), then what only the general path serves (csrc/general_kernels.h): k = 2 and rings outside 1024 .. 4096 */
+  static const struct { int N, k, l, Bg_bit, n; double sigma; } sets[5] = {{2048, 1, 1, 23, 64, 2.2148688116005568e-16}, {4096, 1, 1, 22, 64, 2.2148688116005568e-16},
+                                                                           {512, 2, 2, 8, 24, 2.2148688116005568e-16}, {8192, 1, 1, 23, 12, 2.2148688116005568e-16},
+                                                                           {1024, 2, 2, 10, 16, 2.2148688116005568e-16}};
+  for (int q = 0; q < 5; q++) {
+    const int N2 = sets[q].k * sets[q].N, l2 = sets[q].l, Bg2 = sets[q].Bg_bit, n2 = sets[q].n;   /* N2: dimension of the extracted LWE key */
     TLWE_Key lk = tlwe_new_binary_key(n2, 1.0e-7);
-    TRLWE_Key rk = trlwe_new_binary_key(N2, 1, sets[q].sigma);
+    TRLWE_Key rk = trlwe_new_binary_key(sets[q].N, sets[q].k, sets[q].sigma);
     TLWE_Key xk = tlwe_alloc_key(N2, rk->sigma);
     trlwe_extract_tlwe_key(xk, rk);
     TRGSW_Key gk = trgsw_new_key(rk, l2, Bg2);
@@ -578,7 +581,7 @@ static void case_other_rings(void) {
     TLWE_KS_Key ks2 = tlwe_new_KS_key(lk, xk, 5, 3);
     Torus lut[4] = {int2torus(1, 4), int2torus(5, 4), int2torus(9, 4), int2torus(13, 4)}, lut8[8];
     for (int i = 0; i < 8; i++) lut8[i] = int2torus((uint64_t)((3 * i + 1) & 7), 3);
-    TRLWE tv = trlwe_alloc_new_sample(1, N2), tv8 = trlwe_alloc_new_sample(1, N2);
+    TRLWE tv = trlwe_alloc_new_sample(sets[q].k, sets[q].N), tv8 = trlwe_alloc_new_sample(sets[q].k, sets[q].N);
     trlwe_torus_packing(tv, lut, 4);
     trlwe_torus_packing_many_LUT(tv8, lut8, 4, 2);
     enum { COUNT = 9 };
@@ -588,7 +591,7 @@ static void case_other_rings(void) {
     for (int i = 0; i < COUNT; i++) WITHIN(1ULL << 58, lut[i % 4], tlwe_phase(out[i], xk), "programmable_bootstrap_batch on the larger rings");
     TLWE one = tlwe_alloc_sample(N2);
     functional_bootstrap(one, tv, in[3], b2, 4);
-    CHECK(same_tlwe(one, out[3]), "N = %d: functional_bootstrap differs from the programmable batch entry", N2);
+    CHECK(same_tlwe(one, out[3]), "N = %d, k = %d: functional_bootstrap differs from the programmable batch entry", sets[q].N, sets[q].k);
     tlwe_keyswitch_batch(back, out, COUNT, ks2);
     for (int i = 0; i < COUNT; i++) WITHIN(1ULL << 59, lut[i % 4], tlwe_phase(back[i], lk), "key switch back from the larger rings");
     for (int m = 0; m < 8; m++) {
