@@ -812,7 +812,16 @@ enum { MODE_FUNCTIONAL, MODE_PROGRAMMABLE, MODE_WO_EXTRACT };
 /* Large batches are pipelined in chunks over two streams of the calling thread: while the GPU bootstraps chunk c, the host packs chunk c + 1 into
  * the pinned staging buffer and unpacks the results of chunk c - 1 (the pointer-chasing TLWE arrays cost about as much host time as the PCIe
  * copies).  Chunks of 2048 keep every launch at full occupancy. */
-#define PIPE_CHUNK 2048
+#define PIPE_CHUNK pipe_chunk()
+static int pipe_chunk(void) {   /* MOSFHET_HIP_PIPE_CHUNK overrides (tools/compat_latency.c sweeps it) */
+  static int v = 0;
+  if (!v) {
+    const char *e = getenv("MOSFHET_HIP_PIPE_CHUNK");
+    int x = e ? atoi(e) : 1024;
+    v = x >= 64 ? x : 1024;
+  }
+  return v;
+}
 static __thread void *g_pipe_streams[2];
 static void bootstrap_pipelined(int mode, TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_Key key, int a0, int kappa, int theta) {
   mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
