@@ -247,6 +247,11 @@ int mosfhet_hip_bsk_unfolded_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t *ou
 /* Bootstraps of few ciphertexts with an unfolded key assemble the selectors of all key groups side by side first (two launches per chunk of `max_batch`
  * ciphertexts, up to 8 chunks; same results bit for bit); larger batches run one fused kernel.  -1: default (64, capped by 2 GiB of selectors), 0: never. */
 int mosfhet_hip_set_unfold_split_max(int max_batch);
+/* Unfolding 2 rotates with the per-group TRGSW assembled in the DFT domain (the key's samples are transformed once, when the handle is made; per step
+ * and ciphertext the transforms of ONE CMUX for two mask words: mosfhet_amd/csrc/unfold_kernels.h).  Same mathematics as src/bootstrap.c:124-149, another
+ * order of floating-point operations (oracle/oracle_ext.c:orc_blind_rotate_unfolded2_dft mirrors it bit for bit; it agrees with the reference's own
+ * results to FFT rounding).  on = 0 (or MOSFHET_HIP_UNFOLD2_DFT=0) selects the torus-domain assembly, as for u = 4 and 8. */
+int mosfhet_hip_set_unfold2_dft(int on);
 /* the same key encrypted on the device (torus-domain samples, generator and secrets as mosfhet_hip_bsk_generate) */
 int mosfhet_hip_bsk_unfolded_generate(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t *out, const uint64_t *h_s_rlwe /*[N]*/, int N, const uint64_t *h_s_lwe /*[n]*/, int n,
                                       int l, int Bg_bit, double sigma, uint64_t seed, int unfolding);

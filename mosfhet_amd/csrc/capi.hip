@@ -21,6 +21,7 @@
 #include "general_kernels.h"
 #include "keyswitch_kernels.h"
 #include "ext_kernels.h"
+#include "unfold_kernels.h"
 #include "keygen_kernels.h"
 
 using namespace mosfhet;
@@ -47,6 +48,7 @@ struct mosfhet_hip_ctx {
   int device = 0;
   d2 *tw1024 = nullptr, *tw2048 = nullptr, *tw4096 = nullptr;  // device twiddle tables
   std::map<int, d2 *> tw_general;                               // ... of the other rings, made on first use (general_kernels.h)
+  d2 *wtab[3] = {nullptr, nullptr, nullptr};                    // W[x] = exp(i pi x / N), x < 2N, for N = 1024, 2048, 4096 (unfold_kernels.h)
   std::mutex tw_lock;
   ~mosfhet_hip_ctx() {
     (void)hipSetDevice(device);
@@ -54,6 +56,8 @@ struct mosfhet_hip_ctx {
     if (tw2048) (void)hipFree(tw2048);
     if (tw4096) (void)hipFree(tw4096);
     for (auto &e : tw_general) (void)hipFree(e.second);
+    for (d2 *w : wtab)
+      if (w) (void)hipFree(w);
   }
 };
 
@@ -119,6 +123,7 @@ struct mosfhet_hip_bsk {
   int n, k, N, l, Bg_bit;
   int unfolding = 1;          // > 1: d_bk is null and d_su holds the torus-domain samples of new_bootstrap_key (src/bootstrap.c:23-48)
   uint64_t *d_su = nullptr;   // [n 2^u / u][2l][2][N]
+  d2 *d_su_dft = nullptr;     // unfolding 2: the same samples transformed, [n / 2][4][2l][2][8][T] (unfold_kernels.h); the rotation reads these, UBR phase 1 reads d_su
   size_t bytes = 0;
   bool general = false;       // k > 1 or a ring without a tuned kernel: natural slot order, general_kernels.h (bootstraps and external products only)
   bool owns = true;           // false: d_bk belongs to the caller (mosfhet_hip_bsk_view_create)
@@ -126,6 +131,7 @@ struct mosfhet_hip_bsk {
     if (ctx) (void)hipSetDevice(ctx->device);
     if (d_bk && owns) (void)hipFree(d_bk);
     if (d_su) (void)hipFree(d_su);
+    if (d_su_dft) (void)hipFree(d_su_dft);
   }
 };
 
@@ -219,6 +225,16 @@ extern "C" int mosfhet_hip_ctx_create(mosfhet_hip_ctx_t *out, int device) {
     d2 *&dst = (N == 1024) ? c->tw1024 : (N == 2048 ? c->tw2048 : c->tw4096);
     HIP_TRY(hipMalloc((void **)&dst, tw.size() * sizeof(double)));
     HIP_TRY(hipMemcpy(dst, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice));
+    // same definition as oracle_ext.c:orc_monomial_table
+    std::vector<double> w(4 * (size_t)N);
+    const long double pi = 3.141592653589793238462643383279502884L;
+    for (int x = 0; x < 2 * N; x++) {
+      w[2 * (size_t)x] = (double)cosl(pi * (long double)x / (long double)N);
+      w[2 * (size_t)x + 1] = (double)sinl(pi * (long double)x / (long double)N);
+    }
+    d2 *&wd = c->wtab[N == 1024 ? 0 : (N == 2048 ? 1 : 2)];
+    HIP_TRY(hipMalloc((void **)&wd, w.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(wd, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));
   }
   *out = c.release();
   return MOSFHET_HIP_OK;

@@ -400,6 +400,15 @@ class Engine:
                                               l, Bg_bit, C.c_double(sigma), C.c_uint64(seed), int(ga)))
         return BootstrapKey(self, h, s_lwe.size, 1, s_rlwe.size, l, Bg_bit)
 
+    def generate_bootstrap_key_unfolded(self, s_rlwe, s_lwe, l, Bg_bit, sigma, seed, unfolding):
+        """On-device key of new_bootstrap_key(.., unfolding > 1): per group of `unfolding` key bits the 2^unfolding samples TRGSW(group spells j)."""
+        s_rlwe = np.ascontiguousarray(s_rlwe, dtype=np.uint64)
+        s_lwe = np.ascontiguousarray(s_lwe, dtype=np.uint64)
+        h = C.c_void_p()
+        _check(lib().mosfhet_hip_bsk_unfolded_generate(self.h, C.byref(h), s_rlwe.ctypes.data_as(C.c_void_p), s_rlwe.size, s_lwe.ctypes.data_as(C.c_void_p), s_lwe.size,
+                                                       l, Bg_bit, C.c_double(sigma), C.c_uint64(seed), int(unfolding)))
+        return BootstrapKey(self, h, s_lwe.size, 1, s_rlwe.size, l, Bg_bit)
+
     def generate_keyswitch_key(self, s_out, s_in, t, base_bit, sigma, seed, compressed=False):
         """On-device LWE -> LWE key-switch table (tlwe_new_KS_key) from the binary keys s_in (switched from) and s_out (switched to)."""
         s_out = np.ascontiguousarray(s_out, dtype=np.uint64)
@@ -646,6 +655,11 @@ class Engine:
 def set_unfold_split_max(max_batch):
     """chunk size of the two-phase unfolded bootstrap (-1 default, 0 = always the fused kernel)"""
     _check(lib().mosfhet_hip_set_unfold_split_max(int(max_batch)))
+
+
+def set_unfold2_dft(on):
+    """unfolding-2 keys: DFT-domain assembly of the per-group TRGSW (default) or the torus-domain one of u = 4 and 8"""
+    _check(lib().mosfhet_hip_set_unfold2_dft(int(bool(on))))
 
 
 def set_team_max_batch(max_batch):

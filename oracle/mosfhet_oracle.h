@@ -170,6 +170,12 @@ void orc_full_domain_functional_bootstrap_CLOT21(const orc_fft_plan *p, Torus *o
 void orc_gen_bootstrap_key_unfolded(orc_rng *r, Torus *su /*[n 2^u/u][2l][2][N]*/, const Torus *lwe_s, int n, const Torus *rlwe_s, int N, int l,
                     int Bg_bit, double sigma, int unfolding);                             /* bootstrap.c:23-48 */
 void orc_blind_rotate_unfolded(const orc_fft_plan *p, Torus *acc, const Torus *a, const Torus *su, int n, int l, int Bg_bit, int unfolding); /* bootstrap.c:124-149 */
+/* unfolding 2 with the per-group TRGSW assembled in the DFT domain (the GPU kernel's order; oracle_ext.c) */
+void orc_monomial_table(double *out /*[2N][2]*/, int N);
+void orc_unfold2_selector_dft(double *S, const double *K, Torus a0, Torus a1, int N, int l);
+void orc_blind_rotate_unfolded2_dft(const orc_fft_plan *p, Torus *acc, const Torus *a, const double *su_dft, int n, int l, int Bg_bit);
+void orc_functional_bootstrap_unfolded2_dft(const orc_fft_plan *p, Torus *out, const Torus *tv, const Torus *in, const double *su_dft, int n, int l, int Bg_bit,
+                                            int torus_base, int extract);
 void orc_functional_bootstrap_unfolded(const orc_fft_plan *p, Torus *out, const Torus *tv, const Torus *in, const Torus *su, int n, int l, int Bg_bit,
                     int torus_base, int unfolding, int extract);                          /* bootstrap.c:192-206 with key->unfolding > 1 */
 

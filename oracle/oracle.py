@@ -536,6 +536,26 @@ def functional_bootstrap_unfolded(tv, c, su, l, Bg_bit, torus_base, unfolding, e
     return out
 
 
+def monomial_table(N):
+    """W[x] = exp(i pi x / N), x < 2N, as float64 [2N][2]"""
+    out = np.empty((2 * N, 2), dtype=np.float64)
+    lib().orc_monomial_table(_d(out), N)
+    return out
+
+
+def su_to_dft(su, l):
+    """torus-domain unfolded key samples [cnt][2l][2][N] -> their transforms, same shape (natural slot order)"""
+    return bk_to_dft(su, 1, l)
+
+
+def functional_bootstrap_unfolded2_dft(tv, c, su_dft, l, Bg_bit, torus_base, extract=True):
+    """functional_bootstrap(_wo_extract) with an unfolding-2 key, the per-group TRGSW assembled in the DFT domain (the GPU kernel's order)"""
+    N = tv.shape[-1]
+    out = np.empty(N + 1 if extract else (2, N), dtype=np.uint64)
+    lib().orc_functional_bootstrap_unfolded2_dft(plan(N).h, _u(out), _u(tv), _u(c), _d(su_dft), C.c_int(c.size - 1), l, Bg_bit, torus_base, int(extract))
+    return out
+
+
 def multivalue_bootstrap_UBR_phase1(c, su, l, Bg_bit, unfolding):
     N = su.shape[-1]
     n = c.size - 1

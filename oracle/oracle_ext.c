@@ -391,6 +391,97 @@ void orc_blind_rotate_unfolded(const orc_fft_plan *p, Torus *acc, const Torus *a
   free(xai); free(out); free(xai_dft);
 }
 
+/* ------------------------------------------------------------------------------------------------------------------------------------------
+ * Unfolding 2 with the per-group TRGSW assembled in the DFT DOMAIN (the order the GPU's unfolding-2 kernels compute in; mosfhet_amd/csrc/
+ * unfold_kernels.h).  The reference assembles  xai = su_0 + sum_{j=1..3} X^(e_j) su_j  in the torus domain and transforms it
+ * (src/bootstrap.c:134-143); multiplication by X^e is pointwise multiplication by y^e at every root y the transform evaluates at, so with the
+ * samples transformed once (su_dft) the same TRGSW_DFT is  S = su_dft_0 + sum_j y^(e_j) (.) su_dft_j  up to floating-point rounding: no transform
+ * of key material per step at all.  Slot sigma (natural order) holds the value at y = psi^(4 bitrev(sigma) + 1), psi = exp(i pi / N)
+ * (oracle_fft.c); with sigma = 8 t + m:
+ *     4 bitrev(sigma) + 1 = (4 bitrev(t) + 1) + bitrev3(m) N / 4,   so   y^e = W[(4 bitrev(t) + 1) e mod 2N] * W[(bitrev3(m) e mod 8) N / 4],
+ * W[x] = exp(i pi x / N) -- one table lookup per lane and a wave-uniform eighth root per register on the GPU.
+ * FIXED ORDER (mirrored by the kernels): per slot and j = 1, 2, 3 in order
+ *     c = (m == 0) ? base : base * kappa      base = W[(4 bitrev(t) + 1) e_j mod 2N], kappa = W[(bitrev3(m) e_j mod 8) N / 4];
+ *                                             cr = fma(-bi, ki, br * kr),  ci = fma(bi, kr, br * ki)
+ *     S = K_0;  S.re = fma(-ci, Kj.im, fma(cr, Kj.re, S.re)),  S.im = fma(ci, Kj.re, fma(cr, Kj.im, S.im))
+ * then the external product of src/trgsw.c:270-286 with S exactly as orc_external_product does it; the product REPLACES the accumulator. */
+void orc_monomial_table(double *out /*[2N][2]*/, int N) {
+  const long double pi = 3.141592653589793238462643383279502884L;
+  for (int x = 0; x < 2 * N; x++) {
+    out[2 * x] = (double)cosl(pi * (long double)x / (long double)N);
+    out[2 * x + 1] = (double)sinl(pi * (long double)x / (long double)N);
+  }
+}
+
+static unsigned bitrev_u(unsigned x, int bits) {
+  unsigned r = 0;
+  for (int i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; }
+  return r;
+}
+
+/* the selector of one group: S[2l][2][N] from the group's four transformed samples K[4][2l][2][N] and the two mask words */
+void orc_unfold2_selector_dft(double *S, const double *K, Torus a0, Torus a1, int N, int l) {
+  const int M = N / 2;
+  int log_N2 = 0, logM = 0;
+  while ((1 << log_N2) < 2 * N) log_N2++;
+  while ((1 << logM) < M) logM++;
+  double *Wt = (double *)malloc(sizeof(double) * 4 * (size_t)N);
+  orc_monomial_table(Wt, N);
+  const size_t sz = (size_t)2 * l * 2 * N;
+  const unsigned e[4] = {0, (unsigned)orc_torus2int(a0, log_N2), (unsigned)orc_torus2int(a1, log_N2), (unsigned)orc_torus2int(a0 + a1, log_N2)};
+  for (int rc = 0; rc < 2 * l * 2; rc++)
+    for (int sg = 0; sg < M; sg++) {
+      const int t = sg >> 3, m = sg & 7;
+      const unsigned g0 = 4u * bitrev_u((unsigned)t, logM - 3) + 1u;
+      const size_t at = (size_t)rc * N + 2 * (size_t)sg;
+      double sr = K[at], si = K[at + 1];
+      for (int j = 1; j < 4; j++) {
+        const unsigned xb = (g0 * e[j]) & (unsigned)(2 * N - 1);
+        double cr = Wt[2 * xb], ci = Wt[2 * xb + 1];
+        if (m) {
+          const unsigned q8 = (bitrev_u((unsigned)m, 3) * e[j]) & 7u;
+          const double kr = Wt[2 * (size_t)(q8 * (unsigned)(N / 4))], ki = Wt[2 * (size_t)(q8 * (unsigned)(N / 4)) + 1];
+          const double xr = fma(-ci, ki, cr * kr), xi = fma(ci, kr, cr * ki);
+          cr = xr; ci = xi;
+        }
+        const double Kr = K[(size_t)j * sz + at], Ki = K[(size_t)j * sz + at + 1];
+        sr = fma(-ci, Ki, fma(cr, Kr, sr));
+        si = fma(ci, Kr, fma(cr, Ki, si));
+      }
+      S[at] = sr;
+      S[at + 1] = si;
+    }
+  free(Wt);
+}
+
+void orc_blind_rotate_unfolded2_dft(const orc_fft_plan *p, Torus *acc, const Torus *a, const double *su_dft /*[n/2 * 4][2l][2][N]*/, int n, int l, int Bg_bit) {
+  const int N = plan_N(p);
+  const size_t sz = (size_t)2 * l * 2 * N;
+  double *S = (double *)malloc(sizeof(double) * sz);
+  Torus *out = talloc((size_t)2 * N);
+  for (int i = 0; i < n; i += 2) {
+    orc_unfold2_selector_dft(S, su_dft + (size_t)(i / 2) * 4 * sz, a[i], a[i + 1], N, l);
+    orc_external_product(p, out, acc, S, 1, l, Bg_bit);
+    memcpy(acc, out, sizeof(Torus) * (size_t)2 * N);
+  }
+  free(S); free(out);
+}
+
+/* functional_bootstrap(_wo_extract) with an unfolding-2 key in that order */
+void orc_functional_bootstrap_unfolded2_dft(const orc_fft_plan *p, Torus *out, const Torus *tv, const Torus *in, const double *su_dft, int n, int l, int Bg_bit,
+                                            int torus_base, int extract) {
+  const int N = plan_N(p);
+  int log_N2 = 0;
+  while ((1 << log_N2) < 2 * N) log_N2++;
+  Torus *acc = talloc((size_t)2 * N);
+  const int rot = 2 * N - (int)orc_torus2int(in[n] + orc_double2torus(1. / (4 * torus_base)), log_N2);
+  for (int c = 0; c < 2; c++) orc_poly_mul_by_xai(acc + (size_t)c * N, tv + (size_t)c * N, N, rot);
+  orc_blind_rotate_unfolded2_dft(p, acc, in, su_dft, n, l, Bg_bit);
+  if (extract) orc_trlwe_extract_tlwe(out, acc, 1, N, 0);
+  else memcpy(out, acc, sizeof(Torus) * (size_t)2 * N);
+  free(acc);
+}
+
 /* src/bootstrap.c:192-206 with key->unfolding > 1 */
 void orc_functional_bootstrap_unfolded(const orc_fft_plan *p, Torus *out, const Torus *tv, const Torus *in, const Torus *su, int n, int l, int Bg_bit,
                                        int torus_base, int unfolding, int extract) {

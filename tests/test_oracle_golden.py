@@ -175,6 +175,9 @@ def test_callers_match_reference_golden(oracle):
     priv = O.trlwe_priv_keyswitch_2(K["ct"], O.ks_to_dft(K["ks0"]), O.ks_to_dft(K["ks1"]), 10, 3)
     pack = np.stack([O.trlwe_packing1_keyswitch(c, K["kskb"], 3) for c in K["cs"]])
     unf = np.stack([O.functional_bootstrap_unfolded(U["tv"], c, U["su"], l, Bg, 4, U["unfolding"]) for c in U["cts"]])
+    if U["unfolding"] == 2:
+        su_dft = O.su_to_dft(U["su"], l)
+        unf_dft = np.stack([O.functional_bootstrap_unfolded2_dft(U["tv"], c, su_dft, l, Bg, 4) for c in U["cts"]])
     seen = 0
     for be in ("avx512", "ffnt"):
         if "fdfb_" + be not in g:
@@ -191,6 +194,11 @@ def test_callers_match_reference_golden(oracle):
             ph_m, ph_r = O.tlwe_phase(unf[m], U["s"]), O.tlwe_phase(np.ascontiguousarray(g["unfolded_" + be][m]), U["s"])
             assert O.torus_dist(ph_m, U["lut"][m]) < 2.0 ** 58 and O.torus_dist(ph_r, U["lut"][m]) < 2.0 ** 58
             assert O.torus_dist(ph_m, ph_r) < 2.0 ** 50, (be, m)
+            if U["unfolding"] == 2:
+                # the DFT-domain assembly of the unfolding-2 kernel (oracle_ext.c:orc_blind_rotate_unfolded2_dft) against the reference's output
+                ph_d = O.tlwe_phase(unf_dft[m], U["s"])
+                assert O.torus_dist(ph_d, U["lut"][m]) < 2.0 ** 58 and O.torus_dist(ph_d, ph_r) < 2.0 ** 50, (be, m)
+                assert O.torus_dist(ph_d, ph_m) < 2.0 ** 34, (be, m)
     assert seen >= 1
 
 

@@ -380,6 +380,12 @@ def test_functional_bootstrap_unfolded(oracle, ref, unfolding):
         assert oracle.torus_dist(oracle.tlwe_phase(mine, s), lut[m]) < 2.0 ** 58
         assert oracle.torus_dist(oracle.tlwe_phase(theirs, s), lut[m]) < 2.0 ** 58
         assert oracle.torus_dist(oracle.tlwe_phase(mine, s), oracle.tlwe_phase(theirs, s)) < 2.0 ** 50
+        if unfolding == 2:
+            # the order the GPU's unfolding-2 kernel computes in (per-group TRGSW assembled in the DFT domain): the same result up to FFT rounding
+            dft = oracle.functional_bootstrap_unfolded2_dft(tv, c, oracle.su_to_dft(su, l), l, Bg, 4)
+            assert oracle.torus_dist(oracle.tlwe_phase(dft, s), lut[m]) < 2.0 ** 58
+            assert oracle.torus_dist(oracle.tlwe_phase(dft, s), oracle.tlwe_phase(theirs, s)) < 2.0 ** 50
+            assert oracle.torus_dist(oracle.tlwe_phase(dft, s), oracle.tlwe_phase(mine, s)) < 2.0 ** 34
     # multivalue_bootstrap_UBR_phase1 / phase2 (src/bootstrap.c:151-190): one phase 1, several test vectors; in the oracle the
     # pair computes exactly what the unfolded bootstrap computes
     luts = oracle.u64(rng.words(8)).reshape(2, 4)
