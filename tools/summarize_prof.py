@@ -37,7 +37,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
                 agg[r.get("Kernel_Name", "")][r.get("Counter_Name", "")].append(float(r.get("Counter_Value", 0)))
         print("\n## counters (%s)" % os.path.relpath(f, root))
         for k, cs in agg.items():
-            if not any(x in k for x in ("pbs_kernel", "keyswitch", "external_product")):
+            if not any(x in k for x in ("pbs_kernel", "keyswitch", "external_product", "unfold2")):
                 continue
             for c, v in cs.items():
                 print("  %-50s %-28s per-dispatch mean=%.6g  (n=%d)" % (k[:50], c, sum(v) / len(v), len(v)))
