@@ -491,6 +491,139 @@ __global__ __launch_bounds__(64 * 2 * L) void pbs_team_kernel(PbsParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// The same idea on a ring of two wavefronts (N = 2048: the lvl2 set and the reference's applications, where ONE bootstrap takes 11.8 ms at l = 4 and
+// 18.7 ms at l = 6 on pbs_kernel and gate-by-gate programs wait for exactly that): TEAMS transform teams of F::THREADS threads per ciphertext, team w
+// owns TRGSW rows w, w + TEAMS, ... of every CMUX (digits, forward transform, the transformed digits left in its own exchange buffer), teams 0 and 1
+// run the multiply-accumulate over the rows of each phase -- in row order, the fma chain of pbs_kernel and the oracle: bit-identical results -- and
+// the inverse transform of one output component each.  Critical path per CMUX: 2L / TEAMS forward + 1 inverse transform instead of 2L + 2.
+// F's cross-wavefront exchanges use workgroup barriers, so every team walks the same sequence of barriers (the teams without an output component
+// or, in a ragged last phase, without a row execute the barriers of the transform and nothing else).  Dynamic LDS: TEAMS exchange buffers + the accumulator (TEAMS = 4: 104 KiB, one ciphertext per CU).
+// ------------------------------------------------------------------------------------------------------------
+template <int L> struct WideTeams { static constexpr int value = L == 1 ? 2 : 4; };   // teams per ciphertext (4 x 128 threads keep the 256-register budget of pbs_kernel); rows in ceil(2l / 4) phases
+
+template <class F, int L, int BG>
+__global__ __launch_bounds__(F::THREADS * WideTeams<L>::value) void pbs_wide_team_kernel(PbsParams p) {
+  constexpr int N = F::N, M = F::M, T = F::THREADS, LOG2N2 = F::LOGM + 2, R = 2 * L, TEAMS = WideTeams<L>::value, PHASES = (R + TEAMS - 1) / TEAMS, WG = T * TEAMS;
+  constexpr int KPRE = TEAMS == 4 ? 3 : TEAMS;   // key rows requested ahead of each phase's forward transform (what the registers hold without spilling)
+  static_assert(TEAMS >= 2, "teams 0 and 1 own the two output components");
+  constexpr bool kReduce = !(BG > 0 && kCeilLog2<2 * L>::value + (F::LOGM + 1) + BG - 1 + 63 < 83);   // see pbs_kernel
+  extern __shared__ __attribute__((aligned(16))) unsigned char wide_lds[];
+  d2 *xch_all = reinterpret_cast<d2 *>(wide_lds);                                                     // [TEAMS][F::XCH_SLOTS]
+  uint64_t *acc = reinterpret_cast<uint64_t *>(wide_lds + sizeof(d2) * (size_t)TEAMS * F::XCH_SLOTS);  // [2][N]
+  const int tid = threadIdx.x, team = __builtin_amdgcn_readfirstlane(tid / T), t = tid % T;
+  d2 *xch = xch_all + (size_t)team * F::XCH_SLOTS;
+  const size_t b = blockIdx.x;
+  const uint64_t *__restrict__ ct = p.in + b * (size_t)(p.n + 1);
+  const int Bg_bit = BG > 0 ? BG : p.Bg_bit;
+  F fft;
+  fft.init(p.tw, t);
+  if (p.skip_init) {
+    const uint64_t *src = p.out + b * (size_t)(2 * N);
+    for (int x = tid; x < 2 * N; x += WG) acc[x] = src[x];
+  } else {
+    const uint64_t *__restrict__ tv = p.tv + b * (size_t)p.tv_stride;
+    const uint32_t bbar = modswitch<LOG2N2>(pbs_pre(ct[p.n], p, LOG2N2) + p.prec_offset);
+    const int rot = (2 * N - (int)bbar) & (2 * N - 1);
+    const int a_lo = rot & (N - 1);
+    const bool flip = (rot & N) != 0;
+    for (int x = tid; x < 2 * N; x += WG) acc[x] = rot_coeff<N>(tv + (x / N) * N, x & (N - 1), a_lo, flip);
+  }
+  __syncthreads();
+  uint64_t off = 1ull << (63 - L * Bg_bit);
+#pragma unroll
+  for (int i = 0; i < L; i++) off += 1ull << (63 - i * Bg_bit);
+  const RoundCtx scale(0x1p-64 / (double)M);
+  const size_t row_sz = (size_t)2 * L * 2 * M;
+  const uint32_t mask = (1u << Bg_bit) - 1;
+  const int half = 1 << (Bg_bit - 1);
+  const bool mac = team < 2;    // this team owns output component `team`
+  for (int i = 0; i < p.n; i++) {
+    const int abar = (int)modswitch<LOG2N2>(pbs_pre(ct[i], p, LOG2N2));
+    if (!abar) continue;   // src/bootstrap.c:114 (uniform over the workgroup)
+    const d2 *__restrict__ bkrow = p.bk + (size_t)i * row_sz;
+    const int a_lo = abar & (N - 1);
+    const bool flip = (abar & N) != 0;
+    double o_re[8], o_im[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) { o_re[m] = 0.0; o_im[m] = 0.0; }
+#pragma unroll
+    for (int ph = 0; ph < PHASES; ph++) {
+      // teams 0 and 1 request their component of the phase's first key rows now, under the digit extraction and the forward transform
+      const int rows = (ph + 1) * TEAMS <= R ? TEAMS : R - ph * TEAMS;   // rows of this phase (a constant once the phases are unrolled)
+      d2 kk[KPRE][8];
+      if (mac) {
+#pragma unroll
+        for (int r = 0; r < KPRE; r++)
+          if (r < rows)
+#pragma unroll
+            for (int m = 0; m < 8; m++) kk[r][m] = bkrow[(size_t)(ph * TEAMS + r) * (2 * M) + (size_t)team * M + m * T + t];
+      }
+      const int row = ph * TEAMS + team, q = row / L, shift = 64 - (row % L + 1) * Bg_bit;   // this team's row: component q, level row % L
+      double re[8], im[8];
+      if (row >= R) {   // ragged last phase: no row for this team -- keep the barrier sequence, leave the FP64 pipe to the others
+        F::transform_barriers_only();
+        __syncthreads();
+        __syncthreads();
+        continue;
+      }
+      {
+        const uint64_t *accq = acc + (size_t)q * N;
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          const int j = m * T + t;
+          const uint64_t d_lo = rot_coeff<N>(accq, j, a_lo, flip) - accq[j] + off;
+          const uint64_t d_hi = rot_coeff<N>(accq, j + M, a_lo, flip) - accq[j + M] + off;
+          re[m] = (double)((int)((uint32_t)(d_lo >> shift) & mask) - half);
+          im[m] = (double)((int)((uint32_t)(d_hi >> shift) & mask) - half);
+        }
+      }
+      fft.forward(re, im, xch, t);
+#pragma unroll
+      for (int m = 0; m < 8; m++) xch[m * T + t] = d2{re[m], im[m]};
+      __syncthreads();
+      if (mac) {   // fma chain over the phase's rows in order
+#pragma unroll
+        for (int r = 0; r < TEAMS; r++) {
+          if (r >= rows) continue;
+          const d2 *__restrict__ dr = xch_all + (size_t)r * F::XCH_SLOTS;
+#pragma unroll
+          for (int m = 0; m < 8; m++) {
+            const d2 d = dr[m * T + t];
+            d2 k;
+            if (r < KPRE) k = kk[r < KPRE ? r : 0][m];
+            else k = bkrow[(size_t)(ph * TEAMS + r) * (2 * M) + (size_t)team * M + m * T + t];
+            o_re[m] = __builtin_fma(-d.y, k.y, __builtin_fma(d.x, k.x, o_re[m]));
+            o_im[m] = __builtin_fma(d.y, k.x, __builtin_fma(d.x, k.y, o_im[m]));
+          }
+        }
+      }
+      __syncthreads();   // the transformed digits are consumed: the buffers are free for the next phase's exchanges / the inverse
+    }
+    if (mac) {   // (workgroup barriers inside: the other teams walk the same barriers)
+      fft.inverse(o_re, o_im, xch, t);
+      uint64_t *accw = acc + (size_t)team * N;
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        accw[m * T + t] = add_rounded<kReduce>(accw[m * T + t], o_re[m], scale);
+        accw[M + m * T + t] = add_rounded<kReduce>(accw[M + m * T + t], o_im[m], scale);
+      }
+    } else {
+      F::transform_barriers_only();
+    }
+    __syncthreads();
+  }
+  if (p.extract) {
+    // src/trlwe.c:540-552 at idx = 0
+    uint64_t *dst = p.out + b * (size_t)(N + 1);
+    for (int j = tid; j < N; j += WG) dst[j] = (j == 0) ? acc[0] : (0 - acc[N - j]);
+    if (tid == 0) dst[N] = acc[N];
+  } else {
+    uint64_t *dst = p.out + b * (size_t)(2 * N);
+    for (int x = tid; x < 2 * N; x += WG) dst[x] = acc[x];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Galois-automorphism bootstrap [src/bootstrap_ga.c:39-76] and its building blocks:
 //   trlwe_keyswitch          [src/keyswitch.c:162-193]  out = (0, b) - IDFT(sum_j DFT(digit_j(a)) (.) KS[j])
 //   trlwe_eval_automorphism  [src/trlwe.c:775-781, src/polynomial.c:442-450]  X -> X^gen on both components, then

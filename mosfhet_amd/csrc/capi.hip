@@ -520,6 +520,35 @@ extern "C" int mosfhet_hip_set_team_max_batch(int max_batch) {
   return MOSFHET_HIP_OK;
 }
 
+// The same switch for N = 2048 (pbs_wide_team_kernel: one workgroup of 2 - 6 transform teams per ciphertext, one ciphertext per CU).
+// MOSFHET_HIP_WIDE_TEAM_MAX overrides (0 disables).
+static int g_wide_team_max = -1;
+static int wide_team_max_batch() {
+  if (g_wide_team_max < 0) {
+    const char *e = getenv("MOSFHET_HIP_WIDE_TEAM_MAX");
+    g_wide_team_max = e ? atoi(e) : 256;
+  }
+  return g_wide_team_max;
+}
+extern "C" int mosfhet_hip_set_wide_team_max_batch(int max_batch) {
+  g_wide_team_max = max_batch < 0 ? 0 : max_batch;
+  return MOSFHET_HIP_OK;
+}
+
+template <int LL, int BB>
+static int launch_wide_team(const PbsParams &p, int count, hipStream_t s) {
+  using F = Fft2048;
+  constexpr size_t lds = sizeof(d2) * (size_t)WideTeams<LL>::value * F::XCH_SLOTS + sizeof(uint64_t) * 2 * F::N;
+  static bool configured = false;   // (idempotent: a race sets the same value twice)
+  if (!configured) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_wide_team_kernel<F, LL, BB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = true;
+  }
+  hipLaunchKernelGGL((pbs_wide_team_kernel<F, LL, BB>), dim3((unsigned)count), dim3(F::THREADS * WideTeams<LL>::value), lds, s, p);
+  HIP_TRY(hipGetLastError());
+  return MOSFHET_HIP_OK;
+}
+
 static int bootstrap_unfolded(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_out, const uint64_t *d_tv, int tv_count,
                               const uint64_t *d_in, int count, int pre, int kappa, int theta, int torus_base, int extract, int skip_init, void *stream, int rows);
 
@@ -590,6 +619,19 @@ static int bootstrap_common(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hip_
 #undef TEAM_LAUNCH
     HIP_TRY(hipGetLastError());
     return MOSFHET_HIP_OK;
+  }
+  if (bsk->N == 2048 && rows == 1 && count <= wide_team_max_batch()) {
+    hipStream_t s = pick(ctx, stream);
+    const int l = bsk->l, Bg = bsk->Bg_bit;
+    if (l == 4 && Bg == 9) return launch_wide_team<4, 9>(p, count, s);
+    if (l == 2 && Bg == 8) return launch_wide_team<2, 8>(p, count, s);
+    if (l == 1 && Bg == 23) return launch_wide_team<1, 23>(p, count, s);
+    if (l == 1) return launch_wide_team<1, 0>(p, count, s);
+    if (l == 2) return launch_wide_team<2, 0>(p, count, s);
+    if (l == 3) return launch_wide_team<3, 0>(p, count, s);
+    if (l == 4) return launch_wide_team<4, 0>(p, count, s);
+    if (l == 5) return launch_wide_team<5, 0>(p, count, s);
+    if (l == 6) return launch_wide_team<6, 0>(p, count, s);
   }
   int rc_pbs = MOSFHET_HIP_OK;
   RING_DISPATCH(ctx, bsk->N, rc_pbs = launch_pbs_f<F>(bsk->l, bsk->Bg_bit, p, count, pick(ctx, stream), bsk->owns));

@@ -405,6 +405,14 @@ struct Fft2048T {
     team_sync();
   }
 
+  // the workgroup barriers of one forward / inverse transform and nothing else: for teams of a multi-team workgroup that sit a transform out
+  // (bootstrap_kernels.h: pbs_wide_team_kernel)
+  static __device__ __forceinline__ void transform_barriers_only() {
+    team_sync();
+    team_sync();
+    team_sync();
+  }
+
   // two inverse transforms pipelined through the one buffer (cf. Fft1024::inverse2): wave-local exchanges rely on in-order DS
   // execution, the cross-wavefront B -> A exchange keeps its workgroup barriers (5 in all instead of 6) and every register pass
   // runs while the other transform's exchange is in flight.

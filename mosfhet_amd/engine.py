@@ -667,6 +667,11 @@ def set_team_max_batch(max_batch):
     _check(lib().mosfhet_hip_set_team_max_batch(int(max_batch)))
 
 
+def set_wide_team_max_batch(max_batch):
+    """Batches up to this size use the latency-oriented bootstrap kernel at N = 2048 (0 disables it)."""
+    _check(lib().mosfhet_hip_set_wide_team_max_batch(int(max_batch)))
+
+
 def twiddles(N):
     out = np.empty(2 * (N // 2 - 1), dtype=np.float64)
     _check(lib().mosfhet_hip_twiddles(N, out.ctypes.data_as(C.c_void_p)))
