@@ -513,7 +513,7 @@ __global__ __launch_bounds__(F::THREADS * WideTeams<L>::value) void pbs_wide_tea
   const int tid = threadIdx.x, team = __builtin_amdgcn_readfirstlane(tid / T), t = tid % T;
   d2 *xch = xch_all + (size_t)team * F::XCH_SLOTS;
   const size_t b = blockIdx.x;
-  const uint64_t *__restrict__ ct = p.in + b * (size_t)(p.n + 1);
+  const uint64_t *__restrict__ ct = p.in + (p.rows > 1 ? b / (size_t)p.rows : b) * (size_t)(p.n + 1);   // rows > 1: TRGSW accumulators, see PbsParams
   const int Bg_bit = BG > 0 ? BG : p.Bg_bit;
   F fft;
   fft.init(p.tw, t);
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(F::THREADS * WideTeams<L>::value) void pbs_wide_tea
     const uint64_t *src = p.out + b * (size_t)(2 * N);
     for (int x = tid; x < 2 * N; x += WG) acc[x] = src[x];
   } else {
-    const uint64_t *__restrict__ tv = p.tv + b * (size_t)p.tv_stride;
+    const uint64_t *__restrict__ tv = p.rows > 1 ? p.tv + (b % (size_t)p.rows) * (size_t)(2 * N) : p.tv + b * (size_t)p.tv_stride;
     const uint32_t bbar = modswitch<LOG2N2>(pbs_pre(ct[p.n], p, LOG2N2) + p.prec_offset);
     const int rot = (2 * N - (int)bbar) & (2 * N - 1);
     const int a_lo = rot & (N - 1);

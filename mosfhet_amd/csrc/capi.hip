@@ -620,7 +620,7 @@ static int bootstrap_common(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hip_
     HIP_TRY(hipGetLastError());
     return MOSFHET_HIP_OK;
   }
-  if (bsk->N == 2048 && rows == 1 && count <= wide_team_max_batch()) {
+  if (bsk->N == 2048 && count <= wide_team_max_batch()) {   // (count = workgroups: ciphertexts x accumulator rows)
     hipStream_t s = pick(ctx, stream);
     const int l = bsk->l, Bg = bsk->Bg_bit;
     if (l == 4 && Bg == 9) return launch_wide_team<4, 9>(p, count, s);
