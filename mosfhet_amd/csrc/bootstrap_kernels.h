@@ -492,14 +492,18 @@ __global__ __launch_bounds__(64 * 2 * L) void pbs_team_kernel(PbsParams p) {
 
 // ------------------------------------------------------------------------------------------------------------
 // The same idea on a ring of two wavefronts (N = 2048: the lvl2 set and the reference's applications, where ONE bootstrap takes 11.8 ms at l = 4 and
-// 18.7 ms at l = 6 on pbs_kernel and gate-by-gate programs wait for exactly that): TEAMS transform teams of F::THREADS threads per ciphertext, team w
+// 16 ms at l = 6 on pbs_kernel and gate-by-gate programs wait for exactly that): TEAMS transform teams of F::THREADS threads per ciphertext, team w
 // owns TRGSW rows w, w + TEAMS, ... of every CMUX (digits, forward transform, the transformed digits left in its own exchange buffer), teams 0 and 1
 // run the multiply-accumulate over the rows of each phase -- in row order, the fma chain of pbs_kernel and the oracle: bit-identical results -- and
 // the inverse transform of one output component each.  Critical path per CMUX: 2L / TEAMS forward + 1 inverse transform instead of 2L + 2.
-// F's cross-wavefront exchanges use workgroup barriers, so every team walks the same sequence of barriers (the teams without an output component
-// or, in a ragged last phase, without a row execute the barriers of the transform and nothing else).  Dynamic LDS: TEAMS exchange buffers + the accumulator (TEAMS = 4: 104 KiB, one ciphertext per CU).
+// F's cross-wavefront exchanges use workgroup barriers, so every team walks the same sequence of barriers (with more than two teams, those without an
+// output component or, in a ragged last phase, without a row execute the barriers of the transform and nothing else).
+// TEAMS = 2 (four wavefronts, one per SIMD: every transform has an FP64 pipe to itself, and each phase's key rows -- 64 KiB per CU at ~50 GB/s -- arrive
+// under the phase's own transform) measured 8.8 ms per lvl2 bootstrap against 9.3 ms with four teams, which share the pipes two to one and in lock step
+// cannot hide each other's LDS exchanges; requesting the rows a whole phase ahead into a second register buffer changed nothing (9.4 ms).
+// Dynamic LDS: TEAMS exchange buffers + the accumulator (68 KiB at two teams).
 // ------------------------------------------------------------------------------------------------------------
-template <int L> struct WideTeams { static constexpr int value = L == 1 ? 2 : 4; };   // teams per ciphertext (4 x 128 threads keep the 256-register budget of pbs_kernel); rows in ceil(2l / 4) phases
+template <int L> struct WideTeams { static constexpr int value = 2; };   // teams per ciphertext: four wavefronts, one per SIMD (measured against 4 teams below); rows in l phases of two
 
 template <class F, int L, int BG>
 __global__ __launch_bounds__(F::THREADS * WideTeams<L>::value) void pbs_wide_team_kernel(PbsParams p) {

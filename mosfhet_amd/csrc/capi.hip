@@ -520,13 +520,13 @@ extern "C" int mosfhet_hip_set_team_max_batch(int max_batch) {
   return MOSFHET_HIP_OK;
 }
 
-// The same switch for N = 2048 (pbs_wide_team_kernel: one workgroup of 2 - 6 transform teams per ciphertext, one ciphertext per CU).
+// The same switch for N = 2048 (pbs_wide_team_kernel: one workgroup of two transform teams per ciphertext).
 // MOSFHET_HIP_WIDE_TEAM_MAX overrides (0 disables).
 static int g_wide_team_max = -1;
 static int wide_team_max_batch() {
   if (g_wide_team_max < 0) {
     const char *e = getenv("MOSFHET_HIP_WIDE_TEAM_MAX");
-    g_wide_team_max = e ? atoi(e) : 256;
+    g_wide_team_max = e ? atoi(e) : 512;
   }
   return g_wide_team_max;
 }
