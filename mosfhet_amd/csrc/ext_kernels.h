@@ -512,4 +512,87 @@ __global__ __launch_bounds__(F::THREADS) void ubr_phase2_kernel(const d2 *__rest
     }
 }
 
+// The same on two transform teams per workgroup (N = 2048; cf. bootstrap_kernels.h: pbs_wide_team_kernel): team w transforms the digits of row
+// 2 ph + w, both teams multiply-accumulate the phase's two rows -- team c the output component c, rows in order: the fma chain of ubr_phase2_kernel,
+// bit-identical results -- and after the last phase run one inverse transform each.  l forward + 1 inverse transform on the critical path of every
+// group instead of 2l + 2: what a single unfolded bootstrap waits for.  Dynamic LDS: 2 exchange buffers + the accumulator.
+template <class F>
+__global__ __launch_bounds__(2 * F::THREADS) void ubr_phase2_wide_kernel(const d2 *__restrict__ sa, const d2 *__restrict__ tw, const uint64_t *__restrict__ in,
+                                                                        const uint64_t *__restrict__ tvs, uint64_t *__restrict__ out, int n, int l, int Bg_bit,
+                                                                        int groups, int tv_count, uint64_t prec_offset) {
+  constexpr int N = F::N, M = F::M, T = F::THREADS, LOG2N2 = F::LOGM + 2, WG = 2 * T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ubr_lds[];
+  d2 *xch_all = reinterpret_cast<d2 *>(ubr_lds);                                                  // [2][F::XCH_SLOTS]
+  uint64_t *acc = reinterpret_cast<uint64_t *>(ubr_lds + sizeof(d2) * (size_t)2 * F::XCH_SLOTS);   // [2][N]
+  const int tid = threadIdx.x, team = __builtin_amdgcn_readfirstlane(tid / T), t = tid % T;
+  d2 *xch = xch_all + (size_t)team * F::XCH_SLOTS;
+  const size_t b = blockIdx.x / tv_count, v = blockIdx.x % tv_count;
+  const uint64_t *__restrict__ ct = in + b * (size_t)(n + 1);
+  const uint64_t *__restrict__ tv = tvs + v * (size_t)(2 * N);
+  F fft;
+  fft.init(tw, t);
+  {
+    const uint32_t bbar = modswitch<LOG2N2>(ct[n] + prec_offset);
+    const int rot = (2 * N - (int)bbar) & (2 * N - 1);
+    const int a_lo = rot & (N - 1);
+    const bool flip = (rot & N) != 0;
+    for (int x = tid; x < 2 * N; x += WG) acc[x] = rot_coeff<N>(tv + (x / N) * N, x & (N - 1), a_lo, flip);
+  }
+  __syncthreads();
+  uint64_t off = 1ull << (63 - l * Bg_bit);
+  for (int i = 0; i < l; i++) off += 1ull << (63 - i * Bg_bit);
+  const uint32_t mask = (1u << Bg_bit) - 1;
+  const int half = 1 << (Bg_bit - 1);
+  const RoundCtx scale(0x1p-64 / (double)M);
+  const size_t key_sz = (size_t)2 * l * 2 * M;
+#pragma unroll 1
+  for (int g = 0; g < groups; g++) {
+    const d2 *__restrict__ key = sa + (b * groups + g) * key_sz + (size_t)team * M;   // this team's output component of every row
+    double o_re[8], o_im[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) { o_re[m] = 0.0; o_im[m] = 0.0; }
+#pragma unroll 1
+    for (int ph = 0; ph < l; ph++) {
+      d2 kk[2][8];
+#pragma unroll
+      for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int m = 0; m < 8; m++) kk[r][m] = key[(size_t)(2 * ph + r) * (2 * M) + m * T + t];
+      const int row = 2 * ph + team, q = row / l, shift = 64 - (row % l + 1) * Bg_bit;
+      const uint64_t *accq = acc + (size_t)q * N;
+      double re[8], im[8];
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        re[m] = (double)((int)((uint32_t)((accq[m * T + t] + off) >> shift) & mask) - half);
+        im[m] = (double)((int)((uint32_t)((accq[M + m * T + t] + off) >> shift) & mask) - half);
+      }
+      fft.forward(re, im, xch, t);
+#pragma unroll
+      for (int m = 0; m < 8; m++) xch[m * T + t] = d2{re[m], im[m]};
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        const d2 *__restrict__ dr = xch_all + (size_t)r * F::XCH_SLOTS;
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          const d2 d = dr[m * T + t], k = kk[r][m];
+          o_re[m] = __builtin_fma(-d.y, k.y, __builtin_fma(d.x, k.x, o_re[m]));
+          o_im[m] = __builtin_fma(d.y, k.x, __builtin_fma(d.x, k.y, o_im[m]));
+        }
+      }
+      __syncthreads();
+    }
+    fft.inverse(o_re, o_im, xch, t);
+    uint64_t *accw = acc + (size_t)team * N;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {      // the product REPLACES the accumulator
+      accw[m * T + t] = round_mod_2_64(o_re[m], scale);
+      accw[M + m * T + t] = round_mod_2_64(o_im[m], scale);
+    }
+    __syncthreads();
+  }
+  uint64_t *o = out + (size_t)blockIdx.x * (2 * N);
+  for (int x = tid; x < 2 * N; x += WG) o[x] = acc[x];
+}
+
 }  // namespace mosfhet
