@@ -539,11 +539,8 @@ template <int LL, int BB>
 static int launch_wide_team(const PbsParams &p, int count, hipStream_t s) {
   using F = Fft2048;
   constexpr size_t lds = sizeof(d2) * (size_t)WideTeams<LL>::value * F::XCH_SLOTS + sizeof(uint64_t) * 2 * F::N;
-  static bool configured = false;   // (idempotent: a race sets the same value twice)
-  if (!configured) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_wide_team_kernel<F, LL, BB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
-  }
+  // per launch, like general_lds: the attribute belongs to the current device's copy of the kernel (several devices in one process: mosfhet_compat_multi.c)
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_wide_team_kernel<F, LL, BB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((pbs_wide_team_kernel<F, LL, BB>), dim3((unsigned)count), dim3(F::THREADS * WideTeams<LL>::value), lds, s, p);
   HIP_TRY(hipGetLastError());
   return MOSFHET_HIP_OK;
