@@ -316,7 +316,7 @@ int mosfhet_hip_tlwe_ksk_generate(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t *out,
  * of 2l wavefronts per ciphertext, ~1/3 of the latency), larger ones the throughput kernel (one wavefront per ciphertext).  Results are
  * bit-identical.  Default 512 (or env MOSFHET_HIP_TEAM_MAX); 0 disables the latency kernel. */
 int mosfhet_hip_set_team_max_batch(int max_batch);
-/* the same switch-over for N = 2048 (one workgroup of two transform teams per ciphertext; default 512, MOSFHET_HIP_WIDE_TEAM_MAX; 0 disables) */
+/* the same switch-over for N = 2048 and, at half the value, N = 4096 (one workgroup of two transform teams per ciphertext; default 512, MOSFHET_HIP_WIDE_TEAM_MAX; 0 disables) */
 int mosfhet_hip_set_wide_team_max_batch(int max_batch);
 
 /* The canonical caller pattern in one call (applications/multi-ciphertext-arith/src/integer.c:94-95): tlwe_keyswitch kN -> n, then

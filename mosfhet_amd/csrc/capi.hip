@@ -535,15 +535,27 @@ extern "C" int mosfhet_hip_set_wide_team_max_batch(int max_batch) {
   return MOSFHET_HIP_OK;
 }
 
-template <int LL, int BB>
+template <class F, int LL, int BB>
 static int launch_wide_team(const PbsParams &p, int count, hipStream_t s) {
-  using F = Fft2048;
-  constexpr size_t lds = sizeof(d2) * (size_t)WideTeams<LL>::value * F::XCH_SLOTS + sizeof(uint64_t) * 2 * F::N;
+  constexpr size_t lds = sizeof(d2) * (size_t)2 * F::XCH_SLOTS + sizeof(uint64_t) * 2 * F::N;
   // per launch, like general_lds: the attribute belongs to the current device's copy of the kernel (several devices in one process: mosfhet_compat_multi.c)
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_wide_team_kernel<F, LL, BB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((pbs_wide_team_kernel<F, LL, BB>), dim3((unsigned)count), dim3(F::THREADS * WideTeams<LL>::value), lds, s, p);
+  hipLaunchKernelGGL((pbs_wide_team_kernel<F, LL, BB>), dim3((unsigned)count), dim3(2 * F::THREADS), lds, s, p);
   HIP_TRY(hipGetLastError());
   return MOSFHET_HIP_OK;
+}
+template <class F>
+static int launch_wide_team_f(int l, int Bg, const PbsParams &p, int count, hipStream_t s) {
+  if (l == 4 && Bg == 9) return launch_wide_team<F, 4, 9>(p, count, s);
+  if (l == 2 && Bg == 8) return launch_wide_team<F, 2, 8>(p, count, s);
+  if (l == 1 && Bg == 23) return launch_wide_team<F, 1, 23>(p, count, s);
+  if (l == 1) return launch_wide_team<F, 1, 0>(p, count, s);
+  if (l == 2) return launch_wide_team<F, 2, 0>(p, count, s);
+  if (l == 3) return launch_wide_team<F, 3, 0>(p, count, s);
+  if (l == 4) return launch_wide_team<F, 4, 0>(p, count, s);
+  if (l == 5) return launch_wide_team<F, 5, 0>(p, count, s);
+  if (l == 6) return launch_wide_team<F, 6, 0>(p, count, s);
+  return fail(MOSFHET_HIP_EINVAL, "l = %d not instantiated", l);
 }
 
 static int bootstrap_unfolded(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_out, const uint64_t *d_tv, int tv_count,
@@ -617,19 +629,9 @@ static int bootstrap_common(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hip_
     HIP_TRY(hipGetLastError());
     return MOSFHET_HIP_OK;
   }
-  if (bsk->N == 2048 && count <= wide_team_max_batch()) {   // (count = workgroups: ciphertexts x accumulator rows)
-    hipStream_t s = pick(ctx, stream);
-    const int l = bsk->l, Bg = bsk->Bg_bit;
-    if (l == 4 && Bg == 9) return launch_wide_team<4, 9>(p, count, s);
-    if (l == 2 && Bg == 8) return launch_wide_team<2, 8>(p, count, s);
-    if (l == 1 && Bg == 23) return launch_wide_team<1, 23>(p, count, s);
-    if (l == 1) return launch_wide_team<1, 0>(p, count, s);
-    if (l == 2) return launch_wide_team<2, 0>(p, count, s);
-    if (l == 3) return launch_wide_team<3, 0>(p, count, s);
-    if (l == 4) return launch_wide_team<4, 0>(p, count, s);
-    if (l == 5) return launch_wide_team<5, 0>(p, count, s);
-    if (l == 6) return launch_wide_team<6, 0>(p, count, s);
-  }
+  // (count = workgroups: ciphertexts x accumulator rows; N = 4096: 136 KiB of LDS, one workgroup per CU -- half the batch)
+  if (bsk->N == 2048 && count <= wide_team_max_batch()) return launch_wide_team_f<Fft2048>(bsk->l, bsk->Bg_bit, p, count, pick(ctx, stream));
+  if (bsk->N == 4096 && count <= wide_team_max_batch() / 2) return launch_wide_team_f<Fft4096>(bsk->l, bsk->Bg_bit, p, count, pick(ctx, stream));
   int rc_pbs = MOSFHET_HIP_OK;
   RING_DISPATCH(ctx, bsk->N, rc_pbs = launch_pbs_f<F>(bsk->l, bsk->Bg_bit, p, count, pick(ctx, stream), bsk->owns));
   return rc_pbs;

@@ -623,6 +623,12 @@ struct Fft4096T {
     team_sync();
   }
 
+  // the workgroup barriers of one forward / inverse transform and nothing else (cf. Fft2048T)
+  static __device__ __forceinline__ void transform_barriers_only() {
+    team_sync();
+    team_sync();
+    team_sync();
+  }
   __device__ __forceinline__ void inverse2(double (&xr)[8], double (&xi)[8], double (&yr)[8], double (&yi)[8], d2 *xch, int t) const {
     d2 *pd = xch + base_d3(t), *pc = xch + base_c(t), *pb2 = xch + base_b2(t), *pb1 = xch + base_b1(t), *pa = xch + base_a(t);
     pass_d_inv(xr, xi);

@@ -1,11 +1,11 @@
-"""Latency of small batches at N = 2048: pbs_wide_team_kernel against pbs_kernel (run through gpurun): tools/gpu_latency_wide.py [lvl2|ufhe]"""
+"""Latency of small batches at N = 2048 / 4096: pbs_wide_team_kernel against pbs_kernel (run through gpurun): tools/gpu_latency_wide.py [lvl2|ufhe|set2|set3]"""
 import sys, os, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import mosfhet_amd as ma
 from mosfhet_amd import host, engine
 name = sys.argv[1] if len(sys.argv) > 1 else "lvl2"
-P = dict(ma.PARAMS_LVL2)
+P = dict({"set2": ma.PARAMS_SET2, "set3": ma.PARAMS_SET3}.get(name, ma.PARAMS_LVL2))
 if name == "ufhe":      # applications/multi-ciphertext-arith/src/ufhe.c:19: N = 2048, l = 6, Bg = 2^7
     P.update(l=6, Bg_bit=7)
 host.seed(0x57494445)
