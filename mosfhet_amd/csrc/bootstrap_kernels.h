@@ -852,6 +852,174 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_ga_kernel(GaParams g) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Galois-automorphism bootstrap for FEW ciphertexts: two transform teams per ciphertext (cf. pbs_wide_team_kernel), run-time gadget.  Both accumulator
+// components live in LDS.  Every product -- the external product with BK_i (2l rows) and the key switch of an automorphism (l rows, component a only) --
+// runs its rows two at a time: team w transforms the digits of row 2 ph + w, both teams multiply-accumulate the phase's rows in row order (team c the
+// output component c: the fma chain of cmux_rows), one inverse transform each.  Same digits, same chains, same rounding as pbs_ga_kernel: bit-identical.
+// A team without a row in a ragged last phase (odd l in the key switch) executes the transform's barriers only.
+// ------------------------------------------------------------------------------------------------------------
+template <class F>
+struct GaWide {
+  static constexpr int N = F::N, M = F::M, T = F::THREADS, WG = 2 * T;
+  const F &fft;
+  d2 *xch_all, *xch;
+  uint64_t *acc;   // [2][N]
+  int team, t, tid, l, Bg_bit;
+  uint64_t off;
+  uint32_t mask;
+  int half;
+
+  // o = sum over `rows` rows: DFT(digit(level r % l of component (comp_of_row0 + r / l))) (.) key[r][team]   (rows in order)
+  __device__ __forceinline__ void product(double (&o_re)[8], double (&o_im)[8], const d2 *__restrict__ key, int rows) const {
+#pragma unroll
+    for (int m = 0; m < 8; m++) { o_re[m] = 0.0; o_im[m] = 0.0; }
+#pragma unroll 1
+    for (int r0 = 0; r0 < rows; r0 += 2) {
+      const int in_phase = rows - r0 < 2 ? rows - r0 : 2, row = r0 + team;
+      d2 kk[2][8];
+#pragma unroll
+      for (int r = 0; r < 2; r++)
+        if (r < in_phase)
+#pragma unroll
+          for (int m = 0; m < 8; m++) kk[r][m] = key[(size_t)(r0 + r) * (2 * M) + (size_t)team * M + m * T + t];
+      if (row < rows) {
+        const uint64_t *accq = acc + (size_t)(row / l) * N;
+        const int shift = 64 - (row % l + 1) * Bg_bit;
+        double re[8], im[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          re[m] = (double)((int)((uint32_t)((accq[m * T + t] + off) >> shift) & mask) - half);
+          im[m] = (double)((int)((uint32_t)((accq[M + m * T + t] + off) >> shift) & mask) - half);
+        }
+        fft.forward(re, im, xch, t);
+#pragma unroll
+        for (int m = 0; m < 8; m++) xch[m * T + t] = d2{re[m], im[m]};
+      } else {
+        F::transform_barriers_only();
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        if (r >= in_phase) continue;
+        const d2 *__restrict__ dr = xch_all + (size_t)r * F::XCH_SLOTS;
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          const d2 d = dr[m * T + t], k = kk[r][m];
+          o_re[m] = __builtin_fma(-d.y, k.y, __builtin_fma(d.x, k.x, o_re[m]));
+          o_im[m] = __builtin_fma(d.y, k.x, __builtin_fma(d.x, k.y, o_im[m]));
+        }
+      }
+      __syncthreads();
+    }
+    fft.inverse(o_re, o_im, xch, t);
+  }
+
+  // acc <- BK (.) acc   (src/bootstrap_ga.c:50: the product replaces the accumulator)
+  __device__ __forceinline__ void external_product(const d2 *__restrict__ bkrow, const RoundCtx &scale) const {
+    double o_re[8], o_im[8];
+    product(o_re, o_im, bkrow, 2 * l);
+    uint64_t *accw = acc + (size_t)team * N;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      accw[m * T + t] = round_mod_2_64(o_re[m], scale);
+      accw[M + m * T + t] = round_mod_2_64(o_im[m], scale);
+    }
+    __syncthreads();
+  }
+
+  // acc <- Auto_gen(acc): permute both components in place (out[(i gen) mod N] = +-in[i]), then key switch component a with `entry`:
+  // a = -as(a), b = b - as(a) [src/trlwe.c:775-781, src/keyswitch.c:162-193]
+  __device__ __forceinline__ void eval_automorphism(const d2 *__restrict__ entry, int gen, const RoundCtx &scale) const {
+    constexpr int PER = 2 * N / WG;
+    uint64_t v[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) v[j] = acc[j * WG + tid];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+      const int x = j * WG + tid, c = x / N, i = x & (N - 1), ig = i * gen;
+      acc[c * N + (ig & (N - 1))] = (ig & N) ? (0 - v[j]) : v[j];
+    }
+    __syncthreads();
+    double o_re[8], o_im[8];
+    product(o_re, o_im, entry, l);
+    uint64_t *accw = acc + (size_t)team * N;
+    if (team == 0) {
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        accw[m * T + t] = 0 - round_mod_2_64(o_re[m], scale);
+        accw[M + m * T + t] = 0 - round_mod_2_64(o_im[m], scale);
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        accw[m * T + t] -= round_mod_2_64(o_re[m], scale);
+        accw[M + m * T + t] -= round_mod_2_64(o_im[m], scale);
+      }
+    }
+    __syncthreads();
+  }
+};
+
+template <class F>
+__global__ __launch_bounds__(2 * F::THREADS) void pbs_ga_wide_kernel(GaParams g, int l) {
+  constexpr int N = F::N, M = F::M, T = F::THREADS, LOG2N2 = F::LOGM + 2, WG = 2 * T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ga_lds[];
+  d2 *xch_all = reinterpret_cast<d2 *>(ga_lds);
+  uint64_t *acc = reinterpret_cast<uint64_t *>(ga_lds + sizeof(d2) * (size_t)2 * F::XCH_SLOTS);
+  const PbsParams &p = g.p;
+  const int tid = threadIdx.x, team = __builtin_amdgcn_readfirstlane(tid / T), t = tid % T;
+  const size_t b = blockIdx.x;
+  const int Bg_bit = p.Bg_bit;
+  F fft;
+  fft.init(p.tw, t);
+  uint64_t off = 1ull << (63 - l * Bg_bit);
+  for (int i = 0; i < l; i++) off += 1ull << (63 - i * Bg_bit);
+  const RoundCtx scale(0x1p-64 / (double)M);
+  const size_t row_sz = (size_t)2 * l * 2 * M, ak_sz = (size_t)l * 2 * M;
+  const uint64_t *__restrict__ ct = p.in + b * (size_t)(p.n + 1);
+  if (p.skip_init) {
+    const uint64_t *src = p.out + b * (size_t)(2 * N);
+    for (int x = tid; x < 2 * N; x += WG) acc[x] = src[x];
+  } else {
+    const uint64_t *__restrict__ tv = p.tv + b * (size_t)p.tv_stride;
+    const uint32_t bbar = modswitch<LOG2N2>(ct[p.n] + p.prec_offset);
+    const int rot = (2 * N - (int)bbar) & (2 * N - 1);
+    const int a_lo = rot & (N - 1);
+    const bool flip = (rot & N) != 0;
+    for (int x = tid; x < 2 * N; x += WG) acc[x] = rot_coeff<N>(tv + (x / N) * N, x & (N - 1), a_lo, flip);
+  }
+  __syncthreads();
+  const GaWide<F> w{fft, xch_all, xch_all + (size_t)team * F::XCH_SLOTS, acc, team, t, tid, l, Bg_bit, off, (1u << Bg_bit) - 1, 1 << (Bg_bit - 1)};
+  const uint32_t mask = 2 * N - 1;
+  uint32_t a_cur = modswitch<LOG2N2>(ct[0]) | 1u;
+  {
+    const int gen = (int)inverse_mod_2n(a_cur, mask);
+    w.eval_automorphism(g.ak + (size_t)((gen - 1) >> 1) * ak_sz, gen, scale);
+  }
+  for (int i = 0; i < p.n; i++) {
+    int gen;
+    if (i + 1 < p.n) {
+      const uint32_t a_next = modswitch<LOG2N2>(ct[i + 1]) | 1u;
+      gen = (int)((a_cur * inverse_mod_2n(a_next, mask)) & mask);
+      a_cur = a_next;
+    } else {
+      gen = (int)a_cur;
+    }
+    w.external_product(p.bk + (size_t)i * row_sz, scale);
+    w.eval_automorphism(g.ak + (size_t)((gen - 1) >> 1) * ak_sz, gen, scale);
+  }
+  if (p.extract) {
+    uint64_t *dst = p.out + b * (size_t)(N + 1);
+    for (int j = tid; j < N; j += WG) dst[j] = (j == 0) ? acc[0] : (0 - acc[N - j]);
+    if (tid == 0) dst[N] = acc[N];
+  } else {
+    uint64_t *dst = p.out + b * (size_t)(2 * N);
+    for (int x = tid; x < 2 * N; x += WG) dst[x] = acc[x];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // FFT-based TRLWE key switch with run-time (t, base_bit) [src/keyswitch.c:162-193] and trlwe_priv_keyswitch_2
 // [src/keyswitch.c:52-63], used by circuit_bootstrap_3 (kska: t = 20, base_bit = 2 in the reference's test).
 // One team per TRLWE sample; everything stays in registers (thread owns coefficients m*T+t and m*T+t+M).

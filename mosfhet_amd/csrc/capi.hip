@@ -889,6 +889,18 @@ static void launch_ga(const GaParams &g, int count, hipStream_t s) {
 
 template <class F>
 static int launch_ga_f(int l, int Bg_bit, const GaParams &g, int count, hipStream_t s) {
+  // few ciphertexts: two transform teams per ciphertext (pbs_ga_wide_kernel, bit-identical; the switch-overs of the plain bootstrap's latency kernels)
+  if constexpr (F::N <= 2048) {
+    if (g.mode == 0 && count <= (F::N == 1024 ? team_max_batch() : wide_team_max_batch())) {
+      constexpr size_t lds = sizeof(d2) * (size_t)2 * F::XCH_SLOTS + sizeof(uint64_t) * 2 * F::N;
+      if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_ga_wide_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      GaParams gw = g;
+      gw.p.Bg_bit = Bg_bit;
+      hipLaunchKernelGGL(pbs_ga_wide_kernel<F>, dim3((unsigned)count), dim3(2 * F::THREADS), lds, s, gw, l);
+      HIP_TRY(hipGetLastError());
+      return MOSFHET_HIP_OK;
+    }
+  }
   if (l == 2 && Bg_bit == 8) launch_ga<F, 2, 8>(g, count, s);
   else if (l == 4 && Bg_bit == 9) launch_ga<F, 4, 9>(g, count, s);
   else if (l == 1) launch_ga<F, 1, 0>(g, count, s);

@@ -155,6 +155,7 @@ struct Fft1024 {
   //   layout B (reg m = j[5:3], lane = (h = j[8:6], lo)):  f1 = 72 h + lo + 8 m ;  f2 = 72 h + lo + 9 m
   //   layout C (reg m = j[2:0], lane = j[8:3]):            f2 = 9 lane + m
   static constexpr int XCH_SLOTS = 576;
+  static __device__ __forceinline__ void transform_barriers_only() {}   // the transforms of one wavefront have no workgroup barriers
 
   // forward: input in layout A, output in layout C ("slot order": slot = lane*8 + m).
   // Split in two (head = passes A, B and both transposes; tail = pass C) so the caller can issue the bootstrap-key
