@@ -630,6 +630,8 @@ static int bootstrap_common(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hip_
     return MOSFHET_HIP_OK;
   }
   // (count = workgroups: ciphertexts x accumulator rows; N = 4096: 136 KiB of LDS, one workgroup per CU -- half the batch)
+  // N = 1024: what pbs_team_kernel (above) does not take -- gadgets longer than 4, TRGSW accumulator rows
+  if (bsk->N == 1024 && (bsk->l > 4 || rows > 1) && count <= team_max_batch()) return launch_wide_team_f<Fft1024>(bsk->l, bsk->Bg_bit, p, count, pick(ctx, stream));
   if (bsk->N == 2048 && count <= wide_team_max_batch()) return launch_wide_team_f<Fft2048>(bsk->l, bsk->Bg_bit, p, count, pick(ctx, stream));
   if (bsk->N == 4096 && count <= wide_team_max_batch() / 2) return launch_wide_team_f<Fft4096>(bsk->l, bsk->Bg_bit, p, count, pick(ctx, stream));
   int rc_pbs = MOSFHET_HIP_OK;
