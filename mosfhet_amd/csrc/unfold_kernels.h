@@ -16,7 +16,7 @@
 // reference's torus-domain assembly the results differ by FFT rounding, 2^27 - 2^30 in phase after a full rotation -- tests/test_oracle_golden.py,
 // tests/test_oracle_vs_reference.py):
 //   pbs_unfold2_kernel    one team per ciphertext, S formed in registers row by row                     (batches: throughput)
-//   unfold2_select_kernel S of ALL groups of a ciphertext side by side, then ext_kernels.h:ubr_phase2_kernel walks the n / 2 products  (few ciphertexts: latency)
+//   unfold2_select_kernel S of ALL groups of a ciphertext side by side, then ext_kernels.h:ubr_phase2[_wide]_kernel walks the n / 2 products  (few ciphertexts: latency)
 #pragma once
 #include "bootstrap_kernels.h"
 
@@ -76,7 +76,8 @@ __device__ __forceinline__ void unfold2_group(unsigned (&e)[3], d2 (&base)[3], u
 }
 
 // Selectors of all groups, written out: out[b][g] = S of group g for ciphertext b, [2l][2][8][T] complex -- the layout of ubr_phase1_kernel's output, so
-// ubr_phase2_kernel finishes the bootstrap.  grid = (2l * 2, n / 2, count): one team per polynomial; pre / kappa / theta as in PbsParams.
+// ubr_phase2_kernel / ubr_phase2_wide_kernel finish the bootstrap.  grid = (2l * 2, n / 2, count): one team per polynomial; `in` is the input as the
+// rotation sees it (programmable_bootstrap's scaling is applied by the caller, capi_ext.inc: pbs_pre_kernel).
 template <class F>
 __global__ __launch_bounds__(F::THREADS) void unfold2_select_kernel(const d2 *__restrict__ su_dft, const d2 *__restrict__ wtab, const uint64_t *__restrict__ in,
                                                                   d2 *__restrict__ out, int n, int l) {
