@@ -424,7 +424,9 @@ inline hipError_t launch_tlwe_keyswitch(const uint64_t *ksk, uint64_t *out, size
   if (count <= small_max)
     return launch_tlwe_keyswitch_small(ksk, out, out_stride, in, in_stride, count, n_in, row, b_word, t, base_bit, ws, s, compressed, seed, mask_words);
   static const int tile_env = getenv("MOSFHET_KS_TILE") ? atoi(getenv("MOSFHET_KS_TILE")) : 0;   // tuning: 256 or 512 ciphertexts per workgroup
-  if (tile_env == 512 || (tile_env != 256 && base_bit >= 3))
+  // (up to 256 ciphertexts one 256-wide tile holds them all: the 512-wide tile's extra wavefronts would only stage rows -- +15 % on circuit bootstraps of
+  // 64 - 256 ciphertexts, the shape of a batch of 1024 split over 8 GPUs)
+  if (tile_env == 512 || (tile_env != 256 && base_bit >= 3 && (count > 256 || base_bit > 4)))   // (wider digits need the 512-thread tile's staging width)
     return launch_tlwe_keyswitch_nw<8>(ksk, out, out_stride, in, in_stride, count, n_in, row, b_word, t, base_bit, ws, s, compressed, seed, mask_words);
   return launch_tlwe_keyswitch_nw<KS_NW>(ksk, out, out_stride, in, in_stride, count, n_in, row, b_word, t, base_bit, ws, s, compressed, seed, mask_words);
 }
