@@ -20,6 +20,7 @@ Prints ONE JSON line (rank 0) with the contract fields plus
   roofline_external_product_lvl2 : the same at N = 2048, l = 4 (64 KiB per unit, 256 KiB key entry);
   value_regime : how `value` was launched (steps alternate over --streams HIP streams) next to roofline.kernel_ms (one launch alone);
   sustained    : the same step back to back for >= 2.5 s (N = 1);
+  single_bootstrap_ms : one programmable bootstrap alone (latency kernel), hipEvents on the launch stream;
   replicas     : N > 1 only -- every rank holds the same key (same seed), different ciphertexts, and its outputs decrypt;
   cpu_baseline : the reference's own programmable_bootstrap (oracle/_ref, built from /root/reference) timed on
                  this box's host cores on a bounded sample (N=1 only), plus config 1 (one FFNT pure-C bootstrap).
@@ -348,6 +349,9 @@ def main():
         ep2 = external_product_leg(eng, ma, host, dict(ma.PARAMS_LVL2), max(64, args.ep_batch // 4), measured_traffic, "latest_traffic_ep_lvl2.json",
                                    "mosfhet::external_product_kernel<mosfhet::Fft2048T<false>, 4, 9, false>", torch)
 
+    # one bootstrap alone (the latency kernel: one workgroup of 2l wavefronts for the ciphertext), same key, same timing method as roofline.kernel_ms
+    latency_ms = eng.time_programmable_bootstrap(bsk, d_tv, d_ct[:1], 3, 5, out=d_out[:1]) if rank == 0 else None
+
     # sustained rate: the same step back to back for >= 2.5 s (the contract's timed region is K steps = a fraction of a second; this is the figure a
     # long-running caller sees, and it keeps the GPU visibly busy for a utilisation sampler)
     sustained = None
@@ -393,6 +397,7 @@ def main():
             "roofline_external_product": ep,
             "roofline_external_product_lvl2": ep2,
             "sustained": sustained,
+            "single_bootstrap_ms": latency_ms,
             "replicas": replicas,
             "cpu_baseline": cpu,
             "max_phase_error_log2": float(np.log2(err + 1)),
