@@ -430,17 +430,18 @@ __global__ __launch_bounds__(F::THREADS) void ubr_phase1_kernel(const uint64_t *
 }
 
 // multivalue_bootstrap_UBR_phase2 [src/bootstrap.c:177-190]: acc = tv X^(2N - bbar); for every group acc <- sa[b][g] (.) acc.
-// One team per (ciphertext, test vector): blockIdx.x = b * tv_count + v; writes the rotated TRLWE (the caller extracts).
+// One team per (ciphertext, test vector): blockIdx.x = b * tv_count + v; writes the rotated TRLWE (the caller extracts).  tv_stride_b != 0 (with
+// tv_count = 1): every ciphertext has its own test vector.
 template <class F>
 __global__ __launch_bounds__(F::THREADS) void ubr_phase2_kernel(const d2 *__restrict__ sa, const d2 *__restrict__ tw, const uint64_t *__restrict__ in,
                                                               const uint64_t *__restrict__ tvs, uint64_t *__restrict__ out, int n, int l, int Bg_bit,
-                                                              int groups, int tv_count, uint64_t prec_offset) {
+                                                              int groups, int tv_count, uint64_t prec_offset, long long tv_stride_b) {
   constexpr int N = F::N, M = F::M, T = F::THREADS, LOG2N2 = F::LOGM + 2;
   __shared__ __attribute__((aligned(16))) d2 xch[F::XCH_SLOTS];
   const int t = threadIdx.x;
   const size_t b = blockIdx.x / tv_count, v = blockIdx.x % tv_count;
   const uint64_t *__restrict__ ct = in + b * (size_t)(n + 1);
-  const uint64_t *__restrict__ tv = tvs + v * (size_t)(2 * N);
+  const uint64_t *__restrict__ tv = tvs + v * (size_t)(2 * N) + b * (size_t)tv_stride_b;   // tv_stride_b: words between the test vectors of consecutive ciphertexts (0: shared)
   F fft;
   fft.init(tw, t);
   uint64_t acc[2][2][8];
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(F::THREADS) void ubr_phase2_kernel(const d2 *__rest
 template <class F>
 __global__ __launch_bounds__(2 * F::THREADS) void ubr_phase2_wide_kernel(const d2 *__restrict__ sa, const d2 *__restrict__ tw, const uint64_t *__restrict__ in,
                                                                         const uint64_t *__restrict__ tvs, uint64_t *__restrict__ out, int n, int l, int Bg_bit,
-                                                                        int groups, int tv_count, uint64_t prec_offset) {
+                                                                        int groups, int tv_count, uint64_t prec_offset, long long tv_stride_b) {
   constexpr int N = F::N, M = F::M, T = F::THREADS, LOG2N2 = F::LOGM + 2, WG = 2 * T;
   extern __shared__ __attribute__((aligned(16))) unsigned char ubr_lds[];
   d2 *xch_all = reinterpret_cast<d2 *>(ubr_lds);                                                  // [2][F::XCH_SLOTS]
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(2 * F::THREADS) void ubr_phase2_wide_kernel(const d
   d2 *xch = xch_all + (size_t)team * F::XCH_SLOTS;
   const size_t b = blockIdx.x / tv_count, v = blockIdx.x % tv_count;
   const uint64_t *__restrict__ ct = in + b * (size_t)(n + 1);
-  const uint64_t *__restrict__ tv = tvs + v * (size_t)(2 * N);
+  const uint64_t *__restrict__ tv = tvs + v * (size_t)(2 * N) + b * (size_t)tv_stride_b;   // tv_stride_b: words between the test vectors of consecutive ciphertexts (0: shared)
   F fft;
   fft.init(tw, t);
   {
