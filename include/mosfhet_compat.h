@@ -55,10 +55,13 @@ typedef struct _Bootstrap_Key { TRGSW_DFT *s; TRGSW *su; int n, k, N, Bg_bit, l,
 void mosfhet_seed(uint64_t seed);              /* reseed the host generator used by all *_sample / *_key functions */
 void mosfhet_set_device(int device);           /* GPU used by this process (default: env MOSFHET_HIP_DEVICE or 0) */
 void mosfhet_set_devices(int n, const int *ids);   /* several GPUs (default: env MOSFHET_HIP_DEVICES="0,1,..."): ids[0] is the primary device (keys are made
-                                                    * there, single-sample calls run there); the *_batch entry points of bootstraps and LWE key switches cut
-                                                    * their batch into n contiguous slices, one per GPU, each on its own host thread, stream and staging, with
-                                                    * the keys replicated per GPU on first use.  SURVEY 8(e); no collective.  Before the first call. */
+                                                    * there, single-sample calls run there); EVERY *_batch entry point -- bootstraps, Galois bootstraps, LWE key
+                                                    * switches, full-domain bootstraps (plain, KS21, CLOT21), multi-value and circuit bootstraps -- cuts its
+                                                    * batch into n contiguous slices, one per GPU, each on its own host thread, stream and staging, with the
+                                                    * keys replicated per GPU on first use, device to device.  SURVEY 8(e); no collective.  Before the first call. */
 int mosfhet_device_count(void);                /* GPUs in use */
+void mosfhet_replication_stats(unsigned long long bytes[4], double seconds[4], int keys[4]);   /* key replication so far, per route: 0 same device, 1 peer to
+                                                    * peer (xGMI), 2 device to device without peer access, 3 host bounce buffer (mosfhet_hip_last_clone_route) */
 void *mosfhet_engine_ctx(void);                /* the mosfhet_hip_ctx_t behind the compat layer */
 void *mosfhet_bootstrap_key_device(Bootstrap_Key key);   /* the mosfhet_hip_bsk_t behind a Bootstrap_Key */
 
@@ -175,6 +178,8 @@ void programmable_bootstrap(TLWE out, TRLWE tv, TLWE in, Bootstrap_Key key, int 
 
 void full_domain_functional_bootstrap(TLWE out, TRLWE tv, TLWE in, Bootstrap_Key key, TLWE_KS_Key tlwe_ksk, int precision); /* :519-538 */
 void multivalue_bootstrap_CLOT21(TLWE *out, TRLWE tv, TLWE in, Bootstrap_Key key, int torus_base, int n_luts);              /* :222-230 */
+void multivalue_bootstrap_CLOT21_batch(TLWE *out /* [count * n_luts]: LUT j of input b at b * n_luts + j */, TRLWE tv, TLWE *in, int count, Bootstrap_Key key,
+                                       int torus_base, int n_luts);                                                          /* new */
 void trlwe_torus_packing_many_LUT(TRLWE out, Torus *in, int lut_size, int n_luts);   /* src/trlwe.c:677-687 (host) */
 
 /* ---- bootstrap with Galois automorphisms (src/bootstrap_ga.c)  -> GPU ---- */

@@ -352,6 +352,19 @@ int mosfhet_hip_ksk_info(mosfhet_hip_ksk_t ksk, int *out6);
 int mosfhet_hip_ksk_alloc(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t *out, int kind, int n, int n_out_or_N, int t, int base_bit);
 int mosfhet_hip_ksk_import_rows(mosfhet_hip_ksk_t ksk, size_t first_row, size_t count, const uint64_t *h_in);
 
+/* Key replication for several GPUs (keys replicated per GPU, optionally by hipMemcpyPeer over xGMI instead of host copies): a copy of
+ * `src` on the device of `dst_ctx`, DEVICE TO DEVICE -- hipMemcpyPeer with peer access enabled where the two devices allow it (xGMI on an MI355X node),
+ * HIP's own staged copy otherwise, and a pinned 64 MiB host bounce buffer when even that is refused.  Every field travels as it is: a seed-compressed
+ * table key stays compressed (3 GB instead of the 6 GB its exported rows take at BASELINE configs[3]), an unfolded key keeps its torus-domain samples.
+ * Same bits on both devices, so results do not depend on which replica serves a slice.  The source key's device need not be the caller's current one.
+ * mosfhet_hip_last_clone_route(): how the calling thread's last clone travelled -- 0 same device, 1 peer to peer, 2 device to device without peer
+ * access (HIP stages it), 3 host bounce buffer. */
+int mosfhet_hip_bsk_clone(mosfhet_hip_ctx_t dst_ctx, mosfhet_hip_bsk_t *out, mosfhet_hip_bsk_t src);
+int mosfhet_hip_ksk_clone(mosfhet_hip_ctx_t dst_ctx, mosfhet_hip_ksk_t *out, mosfhet_hip_ksk_t src);
+int mosfhet_hip_gak_clone(mosfhet_hip_ctx_t dst_ctx, mosfhet_hip_gak_t *out, mosfhet_hip_gak_t src);
+int mosfhet_hip_last_clone_route(void);
+size_t mosfhet_hip_gak_bytes(mosfhet_hip_gak_t gak);                     /* device bytes of an FFT key-switch key set (= mosfhet_hip_trlwe_ksk_bytes) */
+
 /* Timing hook for bench.py: runs `reps` launches of the programmable-bootstrap kernel on `stream`
  * bracketed by hipEvents ON THAT STREAM and returns the average kernel time in milliseconds
  * (synchronises the stream). */

@@ -273,6 +273,75 @@ __device__ __forceinline__ void cmux_rows(const typename Digits<L, BG>::word_t (
   }
 }
 
+// The same rows TWO AT A TIME (L even; transforms with forward2_head: N = 2048): the forward transforms of rows (lv, lv + 1) are software-pipelined
+// through the one exchange buffer (Fft2048T::forward2_head) and the four key half-rows of the pair move through two 32-register buffers, each requested
+// behind the register pass or the products next to it (the pass's temporaries and a landing buffer never live together):
+//     kA <- row x, component 0      when y is parked in LDS (its registers are free): under x's last pass
+//     kB <- row x, component 1      behind x's last pass: under x's products of component 0
+//     kA <- row y, component 0      behind those products: under x's products of component 1, y's read-back and last pass
+//     kB <- row y, component 1      behind y's last pass: under y's products of component 0
+// Per output component the products are accumulated in row order with the fma chain of cmux_rows: bit-identical.
+// Where it pays (same-box A/B, experiments/README.md round 4): the lvl2 external product with the twiddles of passes B and C in LDS (Fft2048L) and the
+// pipelined unit loop, -11 %; the fused bootstrap kernel gains nothing (its second wavefront per SIMD already fills the exchanges) and keeps cmux_rows.
+template <class F, int L, int BG>
+__device__ __forceinline__ void cmux_rows2(const typename Digits<L, BG>::word_t (&w_lo)[8], const typename Digits<L, BG>::word_t (&w_hi)[8],
+                                           const uint32_t (&ext)[8], int p, double (&o_re)[2][8], double (&o_im)[2][8], d2 *xch,
+                                           const F &fft, const d2 *__restrict__ bkrow, int Bg_bit, int t) {
+  static_assert(L % 2 == 0 && F::kForward2, "rows are taken two at a time");
+  constexpr int M = F::M, T = F::THREADS;
+  using D = Digits<L, BG>;
+#pragma unroll 1
+  for (int lv = 0; lv < L; lv += 2) {
+    const d2 *__restrict__ row_x = bkrow + (size_t)(p * L + lv) * (2 * M), *__restrict__ row_y = row_x + 2 * M;
+    double xr[8], xi[8], yr[8], yi[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      xr[m] = D::digit(w_lo[m], ext[m], 0, lv, Bg_bit);
+      xi[m] = D::digit(w_hi[m], ext[m], 1, lv, Bg_bit);
+      yr[m] = D::digit(w_lo[m], ext[m], 0, lv + 1, Bg_bit);
+      yi[m] = D::digit(w_hi[m], ext[m], 1, lv + 1, Bg_bit);
+    }
+    fft.forward2_head(xr, xi, yr, yi, xch, t);
+    d2 kA[8], kB[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) kA[m] = row_x[m * T + t];
+    fft.pass_d_fwd(xr, xi);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int m = 0; m < 8; m++) kB[m] = row_x[M + m * T + t];
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      o_re[0][m] = __builtin_fma(-xi[m], kA[m].y, __builtin_fma(xr[m], kA[m].x, o_re[0][m]));
+      o_im[0][m] = __builtin_fma(xi[m], kA[m].x, __builtin_fma(xr[m], kA[m].y, o_im[0][m]));
+    }
+    asm volatile("" ::: "memory");   // the next request reuses the registers the products above have consumed
+#pragma unroll
+    for (int m = 0; m < 8; m++) kA[m] = row_y[m * T + t];
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      o_re[1][m] = __builtin_fma(-xi[m], kB[m].y, __builtin_fma(xr[m], kB[m].x, o_re[1][m]));
+      o_im[1][m] = __builtin_fma(xi[m], kB[m].x, __builtin_fma(xr[m], kB[m].y, o_im[1][m]));
+    }
+    asm volatile("" ::: "memory");
+    fft.forward2_fetch(yr, yi, xch, t);
+    fft.pass_d_fwd(yr, yi);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int m = 0; m < 8; m++) kB[m] = row_y[M + m * T + t];
+    F::forward2_done();
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      o_re[0][m] = __builtin_fma(-yi[m], kA[m].y, __builtin_fma(yr[m], kA[m].x, o_re[0][m]));
+      o_im[0][m] = __builtin_fma(yi[m], kA[m].x, __builtin_fma(yr[m], kA[m].y, o_im[0][m]));
+    }
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      o_re[1][m] = __builtin_fma(-yi[m], kB[m].y, __builtin_fma(yr[m], kB[m].x, o_re[1][m]));
+      o_im[1][m] = __builtin_fma(yi[m], kB[m].x, __builtin_fma(yr[m], kB[m].y, o_im[1][m]));
+    }
+  }
+}
+
 // The fused bootstrap kernel.  Accumulator placement: component a (acc[0]) in VGPRs in the transform's input
 // layout (thread t owns coefficients m*T+t and m*T+t+M: 32 VGPRs), component b (acc[1]) resident in LDS; with
 // the transpose buffer that is 17 KiB of LDS per wavefront and <= 256 VGPRs, i.e. two wavefronts per SIMD /
@@ -758,7 +827,7 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_ga_kernel(GaParams g) {
   const size_t b = blockIdx.x;
   const int Bg_bit = BG > 0 ? BG : p.Bg_bit;
   F fft;
-  fft.init(p.tw, t);
+  fft_setup(fft, p.tw, t);
   uint64_t off = 1ull << (63 - L * Bg_bit);
 #pragma unroll
   for (int i = 0; i < L; i++) off += 1ull << (63 - i * Bg_bit);
@@ -1226,11 +1295,15 @@ __global__ __launch_bounds__(F::THREADS, EP_MIN_WAVES) void external_product_ker
   const int t = threadIdx.x;
   const int Bg_bit = BG > 0 ? BG : Bg_bit_rt;
   F fft;
-  fft.init(tw, t);
+  fft_setup(fft, tw, t);
   uint64_t off = 1ull << (63 - L * Bg_bit);
 #pragma unroll
   for (int i = 0; i < L; i++) off += 1ull << (63 - i * Bg_bit);
   const RoundCtx scale(0x1p-64 / (double)M);
+  // rows two at a time + the software-pipelined unit loop: transforms with the pass twiddles in LDS (Fft2048L: the registers that makes free are what
+  // both need); the launcher picks that type for the gadgets where the build has no scratch
+  constexpr bool kPairs = F::kForward2 && F::kLtw && L % 2 == 0;
+  constexpr bool kPipe = T == 64 || EP_PIPE_ALL || (kPairs && !CMUX && L == 4);   // (CMUX and other lengths keep the plain loop: pipelined, those builds spill)
 
   // Software pipeline over the team's units: the 8 KiB of a component are requested one phase before they are needed and wait in registers as raw
   // words (32 VGPRs) only until they arrive, then as packed digit words (16) -- so a team always has half a ciphertext in flight from HBM.
@@ -1258,7 +1331,7 @@ __global__ __launch_bounds__(F::THREADS, EP_MIN_WAVES) void external_product_ker
 #pragma unroll
     for (int m = 0; m < 8; m++) D::pack(w_lo[m], w_hi[m], ext[m], raw_lo[m] + off, raw_hi[m] + off);
   };
-  if constexpr (T > 64 && !EP_PIPE_ALL) {
+  if constexpr (!kPipe) {
     // Rings of two or four wavefronts per team keep the plain structure -- component loop rolled, each component requested where it is used.  The
     // pipelined form below is (a) not faster there (lvl2: 0.509 vs 0.488 ms per 16,384 units, SET_2: 0.249-0.292 vs 0.237-0.243 ms: these teams are
     // issue-bound, and the first key-row wait of a unit waits for the older ciphertext loads too) and (b) gave intermittently wrong units on every such
@@ -1279,7 +1352,8 @@ __global__ __launch_bounds__(F::THREADS, EP_MIN_WAVES) void external_product_ker
       for (int q = 0; q < 2; q++) {
         request(u, q);
         pack();
-        cmux_rows<F, L, BG>(w_lo, w_hi, ext, q, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
+        if constexpr (kPairs) cmux_rows2<F, L, BG>(w_lo, w_hi, ext, q, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
+        else cmux_rows<F, L, BG>(w_lo, w_hi, ext, q, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
       }
       if (out_dft) {
         d2 *dd = out_dft + u * 2 * M;
@@ -1315,14 +1389,19 @@ __global__ __launch_bounds__(F::THREADS, EP_MIN_WAVES) void external_product_ker
 #endif
     pack();              // component a (requested during the previous unit)
     request(u, 1);       // component b: in flight under the rows of component a
+    if constexpr (kPairs) {
+      cmux_rows2<F, L, BG>(w_lo, w_hi, ext, 0, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
+    } else {
 #ifdef MOSFHET_EP_FIRST
-    cmux_rows<F, L, BG, EP_ONE_K, true>(w_lo, w_hi, ext, 0, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
+      cmux_rows<F, L, BG, EP_ONE_K, true>(w_lo, w_hi, ext, 0, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
 #else
-    cmux_rows<F, L, BG, EP_ONE_K>(w_lo, w_hi, ext, 0, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
+      cmux_rows<F, L, BG, EP_ONE_K>(w_lo, w_hi, ext, 0, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
 #endif
+    }
     pack();
     if (u + gridDim.x < (size_t)count) request(u + gridDim.x, 0);   // the next unit's component a: under the rows of b, the inverse pair and the stores
-    cmux_rows<F, L, BG, EP_ONE_K>(w_lo, w_hi, ext, 1, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
+    if constexpr (kPairs) cmux_rows2<F, L, BG>(w_lo, w_hi, ext, 1, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
+    else cmux_rows<F, L, BG, EP_ONE_K>(w_lo, w_hi, ext, 1, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
     if (out_dft) {
       d2 *dd = out_dft + u * 2 * M;
 #pragma unroll

@@ -14,6 +14,7 @@
 #include <type_traits>
 #include <vector>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 
@@ -124,6 +125,8 @@ struct mosfhet_hip_bsk {
   int unfolding = 1;          // > 1: d_bk is null and d_su holds the torus-domain samples of new_bootstrap_key (src/bootstrap.c:23-48)
   uint64_t *d_su = nullptr;   // [n 2^u / u][2l][2][N]
   d2 *d_su_dft = nullptr;     // unfolding 2: the same samples transformed, [n / 2][4][2l][2][8][T] (unfold_kernels.h); the rotation reads these, UBR phase 1 reads d_su
+  std::mutex su_dft_lock;     // ... made on the first rotation that reads them (unfold2_ready): a key that only ever takes the torus-domain path
+  std::atomic<int> su_dft_ready{0};   // (MOSFHET_HIP_UNFOLD2_DFT=0) never pays for the second copy
   size_t bytes = 0;
   bool general = false;       // k > 1 or a ring without a tuned kernel: natural slot order, general_kernels.h (bootstraps and external products only)
   bool owns = true;           // false: d_bk belongs to the caller (mosfhet_hip_bsk_view_create)
@@ -433,11 +436,21 @@ static void launch_external_product(int l, int Bg_bit, hipStream_t s, const d2 *
   const bool unbounded_2x8 = Bg_bit < 0;
   if (unbounded_2x8) Bg_bit = -Bg_bit;
   const dim3 grid((unsigned)(count < cap ? count : cap)), block(F::THREADS);
-#define EP_GO(LL, BB)                                                                                                                                    \
+#define EP_GO_F(FF, LL, BB)                                                                                                                              \
   do {                                                                                                                                                   \
-    if (d_in0) hipLaunchKernelGGL((external_product_kernel<F, LL, BB, true>), grid, block, 0, s, row, tw, d_in, d_out, Bg_bit, count, key_stride, in_stride, d_in0, d_out_dft);   \
-    else hipLaunchKernelGGL((external_product_kernel<F, LL, BB, false>), grid, block, 0, s, row, tw, d_in, d_out, Bg_bit, count, key_stride, in_stride, d_in0, d_out_dft);      \
+    if (d_in0) hipLaunchKernelGGL((external_product_kernel<FF, LL, BB, true>), grid, block, 0, s, row, tw, d_in, d_out, Bg_bit, count, key_stride, in_stride, d_in0, d_out_dft);   \
+    else hipLaunchKernelGGL((external_product_kernel<FF, LL, BB, false>), grid, block, 0, s, row, tw, d_in, d_out, Bg_bit, count, key_stride, in_stride, d_in0, d_out_dft);      \
   } while (0)
+#define EP_GO(LL, BB) EP_GO_F(F, LL, BB)
+  if constexpr (std::is_same<F, Fft2048>::value) {
+    // N = 2048, l = 4 (lvl2): rows two at a time with the pass twiddles in LDS and, outside the CMUX form, the pipelined unit loop
+    // (external_product_kernel: kPairs / kPipe; bit-identical, no scratch; lvl2: 0.437 against 0.492 ms per 16,384 units in a same-box A/B).
+    // MOSFHET_HIP_EP_PAIRS=0 keeps the plain kernel.
+    static int pairs = -1;
+    if (pairs < 0) { const char *e = getenv("MOSFHET_HIP_EP_PAIRS"); pairs = (e && e[0] == '0') ? 0 : 1; }
+    if (pairs && l == 4 && Bg_bit == 9) { EP_GO_F(Fft2048L, 4, 9); return; }
+    if (pairs && l == 4) { EP_GO_F(Fft2048L, 4, 0); return; }   // (other even lengths: not measured; their pipelined builds spill)
+  }
   if (l == 2 && Bg_bit == 8 && !unbounded_2x8) EP_GO(2, 8);
   else if (l == 4 && Bg_bit == 9) EP_GO(4, 9);
   else if (l == 1 && Bg_bit == 23) EP_GO(1, 23);
@@ -448,6 +461,7 @@ static void launch_external_product(int l, int Bg_bit, hipStream_t s, const d2 *
   else if (l == 5) EP_GO(5, 0);
   else EP_GO(6, 0);
 #undef EP_GO
+#undef EP_GO_F
 }
 
 // ---- bootstrap launches ----
@@ -507,7 +521,7 @@ static int launch_pbs_f(int l, int Bg_bit, const PbsParams &p, int count, hipStr
 
 // Batches up to this size take pbs_team_kernel (N = 1024): below ~1.5 workgroups per CU the one-wavefront-per-ciphertext kernel leaves
 // most of the chip idle and a bootstrap's latency is what counts.  MOSFHET_HIP_TEAM_MAX overrides (0 disables).
-static int g_team_max = -1;
+static std::atomic<int> g_team_max{-1};
 static int team_max_batch() {
   if (g_team_max < 0) {
     const char *e = getenv("MOSFHET_HIP_TEAM_MAX");
@@ -522,7 +536,7 @@ extern "C" int mosfhet_hip_set_team_max_batch(int max_batch) {
 
 // The same switch for N = 2048 (pbs_wide_team_kernel: one workgroup of two transform teams per ciphertext).
 // MOSFHET_HIP_WIDE_TEAM_MAX overrides (0 disables).
-static int g_wide_team_max = -1;
+static std::atomic<int> g_wide_team_max{-1};
 static int wide_team_max_batch() {
   if (g_wide_team_max < 0) {
     const char *e = getenv("MOSFHET_HIP_WIDE_TEAM_MAX");
@@ -544,10 +558,12 @@ static int launch_wide_team(const PbsParams &p, int count, hipStream_t s) {
   HIP_TRY(hipGetLastError());
   return MOSFHET_HIP_OK;
 }
+// bounded: see launch_external_product -- at N = 1024 the compile-time 2 x 2^8 instantiation rounds without the reduction mod 1, which only keys this
+// library transformed itself allow; key views over caller-held TRGSW_DFT sums take the reducing run-time-gadget instantiation
 template <class F>
-static int launch_wide_team_f(int l, int Bg, const PbsParams &p, int count, hipStream_t s) {
+static int launch_wide_team_f(int l, int Bg, const PbsParams &p, int count, hipStream_t s, bool bounded) {
   if (l == 4 && Bg == 9) return launch_wide_team<F, 4, 9>(p, count, s);
-  if (l == 2 && Bg == 8) return launch_wide_team<F, 2, 8>(p, count, s);
+  if (l == 2 && Bg == 8 && (bounded || F::N != 1024)) return launch_wide_team<F, 2, 8>(p, count, s);
   if (l == 1 && Bg == 23) return launch_wide_team<F, 1, 23>(p, count, s);
   if (l == 1) return launch_wide_team<F, 1, 0>(p, count, s);
   if (l == 2) return launch_wide_team<F, 2, 0>(p, count, s);
@@ -631,9 +647,9 @@ static int bootstrap_common(const char *who, mosfhet_hip_ctx_t ctx, mosfhet_hip_
   }
   // (count = workgroups: ciphertexts x accumulator rows; N = 4096: 136 KiB of LDS, one workgroup per CU -- half the batch)
   // N = 1024: what pbs_team_kernel (above) does not take -- gadgets longer than 4, TRGSW accumulator rows
-  if (bsk->N == 1024 && (bsk->l > 4 || rows > 1) && count <= team_max_batch()) return launch_wide_team_f<Fft1024>(bsk->l, bsk->Bg_bit, p, count, pick(ctx, stream));
-  if (bsk->N == 2048 && count <= wide_team_max_batch()) return launch_wide_team_f<Fft2048>(bsk->l, bsk->Bg_bit, p, count, pick(ctx, stream));
-  if (bsk->N == 4096 && count <= wide_team_max_batch() / 2) return launch_wide_team_f<Fft4096>(bsk->l, bsk->Bg_bit, p, count, pick(ctx, stream));
+  if (bsk->N == 1024 && (bsk->l > 4 || rows > 1) && count <= team_max_batch()) return launch_wide_team_f<Fft1024>(bsk->l, bsk->Bg_bit, p, count, pick(ctx, stream), bsk->owns);
+  if (bsk->N == 2048 && count <= wide_team_max_batch()) return launch_wide_team_f<Fft2048>(bsk->l, bsk->Bg_bit, p, count, pick(ctx, stream), bsk->owns);
+  if (bsk->N == 4096 && count <= wide_team_max_batch() / 2) return launch_wide_team_f<Fft4096>(bsk->l, bsk->Bg_bit, p, count, pick(ctx, stream), bsk->owns);
   int rc_pbs = MOSFHET_HIP_OK;
   RING_DISPATCH(ctx, bsk->N, rc_pbs = launch_pbs_f<F>(bsk->l, bsk->Bg_bit, p, count, pick(ctx, stream), bsk->owns));
   return rc_pbs;
@@ -902,6 +918,14 @@ static int launch_ga_f(int l, int Bg_bit, const GaParams &g, int count, hipStrea
       HIP_TRY(hipGetLastError());
       return MOSFHET_HIP_OK;
     }
+  }
+  if constexpr (std::is_same<F, Fft2048>::value) {
+    // N = 2048: the pass twiddles in LDS (Fft2048L) take the 2 x 2^9 ... 4 x 2^9 kernels out of scratch (68 bytes -> 0 at lvl2)
+    static int ltw = -1;
+    if (ltw < 0) { const char *e = getenv("MOSFHET_HIP_GA_LTW"); ltw = (e && e[0] == '0') ? 0 : 1; }
+    if (ltw && l == 4 && Bg_bit == 9) { launch_ga<Fft2048L, 4, 9>(g, count, s); HIP_TRY(hipGetLastError()); return MOSFHET_HIP_OK; }
+    if (ltw && l == 4) { launch_ga<Fft2048L, 4, 0>(g, count, s); HIP_TRY(hipGetLastError()); return MOSFHET_HIP_OK; }
+    if (ltw && l == 2) { launch_ga<Fft2048L, 2, 0>(g, count, s); HIP_TRY(hipGetLastError()); return MOSFHET_HIP_OK; }
   }
   if (l == 2 && Bg_bit == 8) launch_ga<F, 2, 8>(g, count, s);
   else if (l == 4 && Bg_bit == 9) launch_ga<F, 4, 9>(g, count, s);

@@ -39,7 +39,7 @@ MC_HIDDEN void mc_trlwe_from_flat(TRLWE c, const Torus *flat);
 
 /* mosfhet_compat_multi.c: several devices behind the API.  Device INDEX d = position in the list given to mosfhet_set_devices; index 0 is the primary */
 #define MC_MAX_DEVICES 16
-enum { MC_KEY_BSK = 0, MC_KEY_KSK = 1 };
+enum { MC_KEY_BSK = 0, MC_KEY_KSK = 1, MC_KEY_GAK = 2 };   /* bootstrap key, table key (LWE / packing / private), FFT key-switch key set */
 extern MC_HIDDEN int g_mc_ndev;                    /* devices in use */
 extern MC_HIDDEN int g_mc_devs[MC_MAX_DEVICES];    /* their HIP ordinals */
 extern MC_HIDDEN __thread int t_mc_in_shard;      /* inside one slice of a sharded batch (no nested sharding) */

@@ -78,6 +78,14 @@ void mosfhet_seed(uint64_t seed) {
   t_counter = 0;
   t_pos = 16;
   t_ready = 1;
+  /* the device generators' noise key follows the seed: an engine that is already running gets a fresh secret from the new stream (which also restarts
+   * its per-call nonce sequence), exactly what engine start-up does for a seed set before the first use -- so a re-seeded process reproduces the keys
+   * of its device generators too, noise included */
+  if (mc_engine_started()) {
+    uint8_t secret[32];
+    mc_rnd_bytes(secret, sizeof(secret));
+    if (mosfhet_hip_set_keygen_secret(secret)) mc_die("mosfhet_seed (key-generation secret)");
+  }
 }
 
 static void thread_start(void) {

@@ -536,12 +536,16 @@ static int pool_take(int *lo, int *hi) {   /* g_pool.lock held */
   g_pool.next = *hi;
   return 1;
 }
+static int g_pool_stop = 0;                       /* set (under g_pool.lock) when the library is unloaded: workers leave */
+static pthread_t g_pool_threads[16];
+static pthread_once_t g_pool_once = PTHREAD_ONCE_INIT;
 static void *pool_worker(void *unused) {
   (void)unused;
   int seen = 0;
   pthread_mutex_lock(&g_pool.lock);
   for (;;) {
-    while (g_pool.generation == seen) pthread_cond_wait(&g_pool.go, &g_pool.lock);
+    while (g_pool.generation == seen && !g_pool_stop) pthread_cond_wait(&g_pool.go, &g_pool.lock);
+    if (g_pool_stop) break;
     seen = g_pool.generation;
     g_pool.working++;
     int lo, hi;
@@ -552,27 +556,46 @@ static void *pool_worker(void *unused) {
     }
     if (--g_pool.working == 0) pthread_cond_broadcast(&g_pool.done);
   }
+  pthread_mutex_unlock(&g_pool.lock);
   return NULL;
 }
+/* fork(): the child has none of the workers and may have inherited the locks in any state -- it starts over with an empty pool */
+static void pool_atfork_child(void) {
+  pthread_mutex_init(&g_pool.user, NULL);
+  pthread_mutex_init(&g_pool.lock, NULL);
+  pthread_cond_init(&g_pool.go, NULL);
+  pthread_cond_init(&g_pool.done, NULL);
+  g_pool.started = 0; g_pool.working = 0; g_pool.count = 0; g_pool.next = 0;
+}
+static void pool_init_once(void) {
+  const char *e = getenv("MOSFHET_HIP_MARSHAL_THREADS");
+  int want = e ? atoi(e) : 3;
+  if (want < 0) want = 0;
+  if (want > 15) want = 15;
+  __atomic_store_n(&g_pool.helpers, want, __ATOMIC_RELEASE);
+  pthread_atfork(NULL, NULL, pool_atfork_child);
+}
+/* the library is going away (exit, or dlclose of a ctypes handle): the workers run code of this very object, so they are stopped and joined first */
+__attribute__((destructor)) static void pool_shutdown(void) {
+  pthread_mutex_lock(&g_pool.lock);
+  const int n = g_pool.started;
+  g_pool_stop = 1;
+  pthread_cond_broadcast(&g_pool.go);
+  pthread_mutex_unlock(&g_pool.lock);
+  for (int i = 0; i < n; i++) pthread_join(g_pool_threads[i], NULL);
+  pthread_mutex_lock(&g_pool.lock);
+  g_pool.started = 0;
+  pthread_mutex_unlock(&g_pool.lock);
+}
 static void mc_parallel_for(mc_range_fn fn, void *arg, int count, int grain) {
-  if (g_pool.helpers < 0) {
-    const char *e = getenv("MOSFHET_HIP_MARSHAL_THREADS");
-    int want = e ? atoi(e) : 3;
-    if (want < 0) want = 0;
-    if (want > 15) want = 15;
-    __atomic_store_n(&g_pool.helpers, want, __ATOMIC_RELEASE);
-  }
-  if (g_pool.helpers == 0 || count < 4 * grain || pthread_mutex_trylock(&g_pool.user)) {
+  pthread_once(&g_pool_once, pool_init_once);
+  if (__atomic_load_n(&g_pool.helpers, __ATOMIC_ACQUIRE) == 0 || count < 4 * grain || pthread_mutex_trylock(&g_pool.user)) {
     fn(arg, 0, count);
     return;
   }
   pthread_mutex_lock(&g_pool.lock);
-  while (g_pool.started < g_pool.helpers) {
-    pthread_t t;
-    pthread_attr_t a;
-    pthread_attr_init(&a);
-    pthread_attr_setdetachstate(&a, PTHREAD_CREATE_DETACHED);
-    if (pthread_create(&t, &a, pool_worker, NULL)) { g_pool.helpers = g_pool.started; break; }
+  while (!g_pool_stop && g_pool.started < __atomic_load_n(&g_pool.helpers, __ATOMIC_ACQUIRE)) {
+    if (pthread_create(&g_pool_threads[g_pool.started], NULL, pool_worker, NULL)) { __atomic_store_n(&g_pool.helpers, g_pool.started, __ATOMIC_RELEASE); break; }
     g_pool.started++;
   }
   g_pool.fn = fn; g_pool.arg = arg; g_pool.count = count; g_pool.next = 0; g_pool.grain = grain;
@@ -808,10 +831,11 @@ void free_bootstrap_key(Bootstrap_Key key) {
 
 /* ------------------------------------------------------------------ bootstraps (GPU) */
 enum { MODE_FUNCTIONAL, MODE_PROGRAMMABLE, MODE_WO_EXTRACT };
+#define MC_SHOULD_SHARD(count) (g_mc_ndev > 1 && !t_mc_in_shard && (count) >= 2 * g_mc_ndev)   /* several devices, not already inside a slice */
 
 /* Large batches are pipelined in chunks over two streams of the calling thread: while the GPU bootstraps chunk c, the host packs chunk c + 1 into
  * the pinned staging buffer and unpacks the results of chunk c - 1 (the pointer-chasing TLWE arrays cost about as much host time as the PCIe
- * copies).  Chunks of 2048 keep every launch at full occupancy. */
+ * copies).  Chunks of 1024 (MOSFHET_HIP_PIPE_CHUNK): two of them on the two streams are one residency round of the chip. */
 #define PIPE_CHUNK pipe_chunk()
 static int pipe_chunk(void) {   /* MOSFHET_HIP_PIPE_CHUNK overrides (tools/compat_latency.c sweeps it) */
   static int v = 0;
@@ -944,7 +968,7 @@ static void fdfb_slice(void *pv, int lo, int hi) {
 }
 
 void full_domain_functional_bootstrap_batch(TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_Key key, TLWE_KS_Key ksk, int precision) {
-  if (g_mc_ndev > 1 && !t_mc_in_shard && count >= 2 * g_mc_ndev) {
+  if (MC_SHOULD_SHARD(count)) {
     FdfbSlice a = {out, tv, in, key, ksk, precision};
     void *keys[2] = {key->device, ksk->device};
     const int kinds[2] = {MC_KEY_BSK, MC_KEY_KSK};
@@ -973,23 +997,45 @@ void full_domain_functional_bootstrap(TLWE out, TRLWE tv, TLWE in, Bootstrap_Key
   full_domain_functional_bootstrap_batch(&out, tv, &in, 1, key, ksk, precision);
 }
 
-void multivalue_bootstrap_CLOT21(TLWE *out, TRLWE tv, TLWE in, Bootstrap_Key key, int torus_base, int n_luts) {
+/* Every sharded entry point below follows bootstrap_many: with several devices in use (and not already inside a slice) the batch is cut by
+ * mc_run_sharded into one contiguous slice per device, each slice re-enters the same function on its device's host thread, and every key handle is
+ * looked up with mc_key_here (the replica on the calling thread's device).  SURVEY 8(e); src/bootstrap.c:222-230,346-366,391-517, src/bootstrap_ga.c:62-76
+ * are the single-sample callers these batches stand for. */
+typedef struct { TLWE *out; TRLWE tv; TLWE *in; Bootstrap_Key key; int torus_base, n_luts; } MvSlice;
+static void mv_slice(void *pv, int lo, int hi) {
+  MvSlice *a = (MvSlice *)pv;
+  if (hi > lo) multivalue_bootstrap_CLOT21_batch(a->out + (size_t)lo * a->n_luts, a->tv, a->in + lo, hi - lo, a->key, a->torus_base, a->n_luts);
+}
+
+/* out[b * n_luts + j] = LUT j of input b (src/bootstrap.c:222-230 once per input: one blind rotation, n_luts extractions) */
+void multivalue_bootstrap_CLOT21_batch(TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_Key key, int torus_base, int n_luts) {
+  if (MC_SHOULD_SHARD(count)) {
+    MvSlice a = {out, tv, in, key, torus_base, n_luts};
+    void *keys[1] = {key->device};
+    const int kinds[1] = {MC_KEY_BSK};
+    mc_run_sharded(mv_slice, &a, count, keys, kinds, 1);
+    return;
+  }
   mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
   const int n = key->n, N = key->N, k = key->k;
-  const size_t in_w = (size_t)(n + 1), tv_w = (size_t)(k + 1) * N, out_w = (size_t)n_luts * (k * N + 1);
+  const size_t in_w = (size_t)count * (n + 1), tv_w = (size_t)(k + 1) * N, out_w = (size_t)count * n_luts * (k * N + 1);
   Torus *h = (Torus *)mc_hstage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
-  tlwe_array_to_flat(h, &in, 1, n);
+  tlwe_array_to_flat(h, in, count, n);
   mc_trlwe_to_flat(h + in_w, tv);
   Torus *d = (Torus *)mc_stage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
   mc_dev_copy(d, h, sizeof(Torus) * (in_w + tv_w), HIP_H2D);
-  if (mosfhet_hip_multivalue_bootstrap_CLOT21_batch(ctx, (mosfhet_hip_bsk_t)mosfhet_bootstrap_key_device(key), d + in_w + tv_w, d + in_w, 1, d,
-                                                    1, torus_base, n_luts, NULL) ||
+  if (mosfhet_hip_multivalue_bootstrap_CLOT21_batch(ctx, (mosfhet_hip_bsk_t)mc_key_here(key->device, MC_KEY_BSK), d + in_w + tv_w, d + in_w, 1, d,
+                                                    count, torus_base, n_luts, NULL) ||
       mosfhet_hip_ctx_sync(ctx, NULL))
     mc_die("multivalue_bootstrap_CLOT21");
   mc_dev_copy(h + in_w + tv_w, d + in_w + tv_w, sizeof(Torus) * out_w, HIP_D2H);
-  tlwe_array_from_flat(out, h + in_w + tv_w, n_luts, k * N);
+  tlwe_array_from_flat(out, h + in_w + tv_w, count * n_luts, k * N);
   stage_free(d);
   mc_hstage_free(h);
+}
+
+void multivalue_bootstrap_CLOT21(TLWE *out, TRLWE tv, TLWE in, Bootstrap_Key key, int torus_base, int n_luts) {
+  multivalue_bootstrap_CLOT21_batch(out, tv, &in, 1, key, torus_base, n_luts);
 }
 
 /* ------------------------------------------------------------------ Galois-automorphism bootstrap */
@@ -1067,12 +1113,28 @@ void free_bootstrap_key_ga(Bootstrap_GA_Key key) {
   if (key->s) mc_trgsw_dft_views_free(key->s, key->n);
   for (int j = 0; j < key->N; j++) free(key->ak[j]);
   free(key->ak);
+  mc_replicas_free(key->device);
+  mc_replicas_free(key->ak_device);
   mosfhet_hip_bsk_destroy((mosfhet_hip_bsk_t)key->device);
   mosfhet_hip_gak_destroy((mosfhet_hip_gak_t)key->ak_device);
   free(key);
 }
 
+typedef struct { TLWE *out; TRLWE tv; TLWE *in; Bootstrap_GA_Key key; int torus_base; } GaSlice;
+static void bootstrap_ga_many(TLWE *out, TRLWE out_trlwe, TRLWE tv, TLWE *in, int count, Bootstrap_GA_Key key, int torus_base);
+static void ga_slice(void *pv, int lo, int hi) {
+  GaSlice *a = (GaSlice *)pv;
+  if (hi > lo) bootstrap_ga_many(a->out + lo, NULL, a->tv, a->in + lo, hi - lo, a->key, a->torus_base);
+}
+
 static void bootstrap_ga_many(TLWE *out, TRLWE out_trlwe, TRLWE tv, TLWE *in, int count, Bootstrap_GA_Key key, int torus_base) {
+  if (out && MC_SHOULD_SHARD(count)) {   /* bootstrap key + automorphism key set replicated (src/bootstrap_ga.c:62-76 per sample) */
+    GaSlice a = {out, tv, in, key, torus_base};
+    void *keys[2] = {key->device, key->ak_device};
+    const int kinds[2] = {MC_KEY_BSK, MC_KEY_GAK};
+    mc_run_sharded(ga_slice, &a, count, keys, kinds, 2);
+    return;
+  }
   mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
   const int n = key->n, N = key->N, extract = out != NULL;
   const size_t in_w = (size_t)count * (n + 1), tv_w = (size_t)2 * N;
@@ -1082,7 +1144,8 @@ static void bootstrap_ga_many(TLWE *out, TRLWE out_trlwe, TRLWE tv, TLWE *in, in
   mc_trlwe_to_flat(h + in_w, tv);
   Torus *d = (Torus *)mc_stage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
   mc_dev_copy(d, h, sizeof(Torus) * (in_w + tv_w), HIP_H2D);
-  if (mosfhet_hip_functional_bootstrap_ga_batch(ctx, (mosfhet_hip_bsk_t)key->device, (mosfhet_hip_gak_t)key->ak_device, d + in_w + tv_w, d + in_w, 1, d,
+  if (mosfhet_hip_functional_bootstrap_ga_batch(ctx, (mosfhet_hip_bsk_t)mc_key_here(key->device, MC_KEY_BSK), (mosfhet_hip_gak_t)mc_key_here(key->ak_device, MC_KEY_GAK),
+                                                d + in_w + tv_w, d + in_w, 1, d,
                                                 count, torus_base, extract, NULL) ||
       mosfhet_hip_ctx_sync(ctx, NULL))
     mc_die("functional_bootstrap_ga");
@@ -1177,7 +1240,7 @@ static void ks_slice(void *pv, int lo, int hi) {
 }
 
 void tlwe_keyswitch_batch(TLWE *out, TLWE *in, int count, TLWE_KS_Key ks) {
-  if (g_mc_ndev > 1 && !t_mc_in_shard && count >= 2 * g_mc_ndev) {
+  if (MC_SHOULD_SHARD(count)) {
     KsSlice a = {out, in, ks};
     void *keys[1] = {ks->device};
     const int kinds[1] = {MC_KEY_KSK};
@@ -1315,7 +1378,10 @@ TRLWE_KS_Key *trlwe_new_automorphism_KS_keyset_2(TRLWE_Key key, uint64_t *gens, 
 
 void free_trlwe_ks_key(TRLWE_KS_Key key) {
   if (!key) return;
-  if (key->owner) mosfhet_hip_gak_destroy((mosfhet_hip_gak_t)key->device);
+  if (key->owner) {
+    mc_replicas_free(key->device);
+    mosfhet_hip_gak_destroy((mosfhet_hip_gak_t)key->device);
+  }
   free(key);
 }
 
@@ -1387,7 +1453,20 @@ void trlwe_packing1_keyswitch(TRLWE out, TLWE in, Generic_KS_Key ks) {
   mc_hstage_free(h);
 }
 
+typedef struct { TRGSW *out; TLWE *in; Bootstrap_Key key; TRLWE_KS_Key *kska; Generic_KS_Key kskb; } Cb3Slice;
+static void cb3_slice(void *pv, int lo, int hi) {
+  Cb3Slice *a = (Cb3Slice *)pv;
+  if (hi > lo) circuit_bootstrap_3_batch(a->out + lo, a->in + lo, hi - lo, a->key, a->kska, a->kskb);
+}
+
 void circuit_bootstrap_3_batch(TRGSW *out, TLWE *in, int count, Bootstrap_Key key, TRLWE_KS_Key *kska, Generic_KS_Key kskb) {
+  if (MC_SHOULD_SHARD(count)) {   /* BASELINE configs[3]: bootstrap key, private FFT key-switch pair and the packing table replicated (src/bootstrap.c:346-366 per sample) */
+    Cb3Slice a = {out, in, key, kska, kskb};
+    void *keys[3] = {key->device, kska[0]->device, kskb->device};
+    const int kinds[3] = {MC_KEY_BSK, MC_KEY_GAK, MC_KEY_KSK};
+    mc_run_sharded(cb3_slice, &a, count, keys, kinds, 3);
+    return;
+  }
   mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
   const int n = key->n, N = key->N, l = key->l;
   const size_t in_w = (size_t)count * (n + 1), row = (size_t)2 * N, out_w = (size_t)count * 2 * l * row;
@@ -1395,8 +1474,8 @@ void circuit_bootstrap_3_batch(TRGSW *out, TLWE *in, int count, Bootstrap_Key ke
   tlwe_array_to_flat(h, in, count, n);
   Torus *d = (Torus *)mc_stage_alloc(sizeof(Torus) * (in_w + out_w));
   mc_dev_copy(d, h, sizeof(Torus) * in_w, HIP_H2D);
-  if (mosfhet_hip_circuit_bootstrap_3_batch(ctx, (mosfhet_hip_bsk_t)key->device, (mosfhet_hip_gak_t)kska[0]->device, (mosfhet_hip_ksk_t)kskb->device,
-                                            d + in_w, d, count, NULL) ||
+  if (mosfhet_hip_circuit_bootstrap_3_batch(ctx, (mosfhet_hip_bsk_t)mc_key_here(key->device, MC_KEY_BSK), (mosfhet_hip_gak_t)mc_key_here(kska[0]->device, MC_KEY_GAK),
+                                            (mosfhet_hip_ksk_t)mc_key_here(kskb->device, MC_KEY_KSK), d + in_w, d, count, NULL) ||
       mosfhet_hip_ctx_sync(ctx, NULL))
     mc_die("circuit_bootstrap_3");
   mc_dev_copy(h + in_w, d + in_w, sizeof(Torus) * out_w, HIP_D2H);
@@ -1457,14 +1536,28 @@ void trlwe_priv_keyswitch(TRLWE out, TLWE in, Generic_KS_Key ks) {
   buf_free(&b);
 }
 
+typedef struct { TRGSW *out; TLWE *in; Bootstrap_Key key; Generic_KS_Key kska, kskb; int variant; } CbSlice;
+static void circuit_bootstrap_many(TRGSW *out, TLWE *in, int count, Bootstrap_Key key, Generic_KS_Key kska, Generic_KS_Key kskb, int variant);
+static void cb_slice(void *pv, int lo, int hi) {
+  CbSlice *a = (CbSlice *)pv;
+  if (hi > lo) circuit_bootstrap_many(a->out + lo, a->in + lo, hi - lo, a->key, a->kska, a->kskb, a->variant);
+}
+
 static void circuit_bootstrap_many(TRGSW *out, TLWE *in, int count, Bootstrap_Key key, Generic_KS_Key kska, Generic_KS_Key kskb, int variant) {
+  if (MC_SHOULD_SHARD(count)) {   /* src/bootstrap.c:309-344 per sample: bootstrap key and both table keys replicated */
+    CbSlice a = {out, in, key, kska, kskb, variant};
+    void *keys[3] = {key->device, kska->device, kskb->device};
+    const int kinds[3] = {MC_KEY_BSK, MC_KEY_KSK, MC_KEY_KSK};
+    mc_run_sharded(cb_slice, &a, count, keys, kinds, 3);
+    return;
+  }
   const int n = key->n, N = key->N, l = key->l;
   const size_t in_w = (size_t)count * (n + 1), row = (size_t)2 * N, out_w = (size_t)count * 2 * l * row;
   Buf b = buf_new(in_w + out_w);
   tlwe_array_to_flat(b.h, in, count, n);
   buf_up(&b, 0, in_w);
-  check_rc(mosfhet_hip_circuit_bootstrap_batch(ectx(), (mosfhet_hip_bsk_t)key->device, (mosfhet_hip_ksk_t)kska->device, (mosfhet_hip_ksk_t)kskb->device, b.d + in_w,
-                                               b.d, count, variant, NULL), "circuit_bootstrap");
+  check_rc(mosfhet_hip_circuit_bootstrap_batch(ectx(), (mosfhet_hip_bsk_t)mc_key_here(key->device, MC_KEY_BSK), (mosfhet_hip_ksk_t)mc_key_here(kska->device, MC_KEY_KSK),
+                                               (mosfhet_hip_ksk_t)mc_key_here(kskb->device, MC_KEY_KSK), b.d + in_w, b.d, count, variant, NULL), "circuit_bootstrap");
   buf_down(&b, in_w, out_w);
   for (int c = 0; c < count; c++)
     for (int q = 0; q < 2 * l; q++) mc_trlwe_from_flat(out[c]->samples[q], b.h + in_w + ((size_t)c * 2 * l + q) * row);
@@ -1477,7 +1570,21 @@ void circuit_bootstrap_2_batch(TRGSW *out, TLWE *in, int count, Bootstrap_Key ke
   circuit_bootstrap_many(out, in, count, key, kska, kskb, 1);
 }
 
+typedef struct { TLWE *out; TorusPolynomial tv; TLWE *in; Bootstrap_Key key; Generic_KS_Key ksk; int torus_base, variant; } Ks21Slice;
+static void fdfb_ks21_many(TLWE *out, TorusPolynomial tv, TLWE *in, int count, Bootstrap_Key key, Generic_KS_Key ksk, int torus_base, int variant);
+static void ks21_slice(void *pv, int lo, int hi) {
+  Ks21Slice *a = (Ks21Slice *)pv;
+  if (hi > lo) fdfb_ks21_many(a->out + lo, a->tv, a->in + lo, hi - lo, a->key, a->ksk, a->torus_base, a->variant);
+}
+
 static void fdfb_ks21_many(TLWE *out, TorusPolynomial tv, TLWE *in, int count, Bootstrap_Key key, Generic_KS_Key ksk, int torus_base, int variant) {
+  if (MC_SHOULD_SHARD(count)) {   /* src/bootstrap.c:391-463 per sample */
+    Ks21Slice a = {out, tv, in, key, ksk, torus_base, variant};
+    void *keys[2] = {key->device, ksk->device};
+    const int kinds[2] = {MC_KEY_BSK, MC_KEY_KSK};
+    mc_run_sharded(ks21_slice, &a, count, keys, kinds, 2);
+    return;
+  }
   const int n = key->n, N = key->N;
   const size_t in_w = (size_t)count * (n + 1), tv_w = (size_t)2 * N, out_w = (size_t)count * (N + 1);
   if (tv->N != 2 * N) { fprintf(stderr, "mosfhet_amd: full_domain_functional_bootstrap_KS21: tv must have 2N coefficients\n"); abort(); }
@@ -1485,8 +1592,8 @@ static void fdfb_ks21_many(TLWE *out, TorusPolynomial tv, TLWE *in, int count, B
   tlwe_array_to_flat(b.h, in, count, n);
   memcpy(b.h + in_w, tv->coeffs, sizeof(Torus) * tv_w);
   buf_up(&b, 0, in_w + tv_w);
-  check_rc(mosfhet_hip_full_domain_functional_bootstrap_KS21_batch(ectx(), (mosfhet_hip_bsk_t)key->device, (mosfhet_hip_ksk_t)ksk->device, b.d + in_w + tv_w, b.d + in_w,
-                                                                   b.d, count, torus_base, variant, NULL), "full_domain_functional_bootstrap_KS21");
+  check_rc(mosfhet_hip_full_domain_functional_bootstrap_KS21_batch(ectx(), (mosfhet_hip_bsk_t)mc_key_here(key->device, MC_KEY_BSK), (mosfhet_hip_ksk_t)mc_key_here(ksk->device, MC_KEY_KSK),
+                                                                   b.d + in_w + tv_w, b.d + in_w, b.d, count, torus_base, variant, NULL), "full_domain_functional_bootstrap_KS21");
   buf_down(&b, in_w + tv_w, out_w);
   tlwe_array_from_flat(out, b.h + in_w + tv_w, count, N);
   buf_free(&b);
@@ -1539,16 +1646,31 @@ void tlwe_mul(TLWE out, TLWE in1, TLWE in2, int precision, Generic_KS_Key ksk, T
   buf_free(&b);
 }
 
+typedef struct { TLWE *out; const Torus *tv_flat; size_t tv_w; TLWE *in; Bootstrap_Key key; Generic_KS_Key ksk; TRLWE_KS_Key rlk; int precision, variant; } Clot21Slice;
+static void fdfb_clot21_many(TLWE *out, const Torus *tv_flat, size_t tv_w, TLWE *in, int count, Bootstrap_Key key, Generic_KS_Key ksk, TRLWE_KS_Key rlk, int precision,
+                             int variant);
+static void clot21_slice(void *pv, int lo, int hi) {
+  Clot21Slice *a = (Clot21Slice *)pv;
+  if (hi > lo) fdfb_clot21_many(a->out + lo, a->tv_flat, a->tv_w, a->in + lo, hi - lo, a->key, a->ksk, a->rlk, a->precision, a->variant);
+}
+
 static void fdfb_clot21_many(TLWE *out, const Torus *tv_flat, size_t tv_w, TLWE *in, int count, Bootstrap_Key key, Generic_KS_Key ksk, TRLWE_KS_Key rlk, int precision,
                              int variant) {
+  if (MC_SHOULD_SHARD(count)) {   /* src/bootstrap.c:465-517 per sample: bootstrap key, packing table and relinearisation key replicated */
+    Clot21Slice a = {out, tv_flat, tv_w, in, key, ksk, rlk, precision, variant};
+    void *keys[3] = {key->device, ksk->device, rlk->device};
+    const int kinds[3] = {MC_KEY_BSK, MC_KEY_KSK, MC_KEY_GAK};
+    mc_run_sharded(clot21_slice, &a, count, keys, kinds, 3);
+    return;
+  }
   const int n = key->n, N = key->N;
   const size_t in_w = (size_t)count * (n + 1), out_w = (size_t)count * (N + 1);
   Buf b = buf_new(in_w + tv_w + out_w);
   tlwe_array_to_flat(b.h, in, count, n);
   memcpy(b.h + in_w, tv_flat, sizeof(Torus) * tv_w);
   buf_up(&b, 0, in_w + tv_w);
-  check_rc(mosfhet_hip_full_domain_functional_bootstrap_CLOT21_batch(ectx(), (mosfhet_hip_bsk_t)key->device, (mosfhet_hip_ksk_t)ksk->device, (mosfhet_hip_gak_t)rlk->device,
-                                                                     b.d + in_w + tv_w, b.d + in_w, b.d, count, precision, variant, NULL),
+  check_rc(mosfhet_hip_full_domain_functional_bootstrap_CLOT21_batch(ectx(), (mosfhet_hip_bsk_t)mc_key_here(key->device, MC_KEY_BSK), (mosfhet_hip_ksk_t)mc_key_here(ksk->device, MC_KEY_KSK),
+                                                                     (mosfhet_hip_gak_t)mc_key_here(rlk->device, MC_KEY_GAK), b.d + in_w + tv_w, b.d + in_w, b.d, count, precision, variant, NULL),
            "full_domain_functional_bootstrap_CLOT21");
   buf_down(&b, in_w + tv_w, out_w);
   tlwe_array_from_flat(out, b.h + in_w + tv_w, count, N);

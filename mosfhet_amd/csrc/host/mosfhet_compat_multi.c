@@ -6,14 +6,15 @@
  *                                 and keys are created); env MOSFHET_HIP_DEVICES="0,1,..." does the same.
  * A *_batch entry point then cuts its batch into contiguous slices (mosfhet_amd/shard.py: the first count % n slices get one unit more) and runs
  * slice d on device d from its own host thread, with that thread's stream, pinned staging and device staging buffers -- the same single-device code
- * path, once per device.  A key is replicated on demand: its device image is exported from the primary device and imported on the other one
- * (bit-identical key, so results do not depend on the device count).  No collective anywhere.
+ * path, once per device.  A key is replicated on demand, device to device (mosfhet_hip_bsk_clone / _ksk_clone / _gak_clone: hipMemcpyPeer over xGMI
+ * between peers; bit-identical key, so results do not depend on the device count).  No collective anywhere.
  * A device may be listed more than once (two contexts on one GPU): that is how the CPU-box-sized tests exercise this file on a one-GPU machine.
  */
 #define _GNU_SOURCE
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "compat_internal.h"
 
@@ -51,7 +52,18 @@ void mc_devices_from_env(void) {
   if (n) g_mc_ndev = n;
 }
 
-/* the handle of `primary` (kind MC_KEY_*) on device index d, made from the primary's exported image the first time it is asked for */
+/* Replication statistics (tests/c/multi_device.c prints them): bytes and seconds per route of mosfhet_hip_last_clone_route */
+static double g_rep_seconds[4];
+static unsigned long long g_rep_bytes[4];
+static int g_rep_keys[4];
+void mosfhet_replication_stats(unsigned long long bytes[4], double seconds[4], int keys[4]) {
+  pthread_mutex_lock(&g_rep_lock);
+  for (int r = 0; r < 4; r++) { bytes[r] = g_rep_bytes[r]; seconds[r] = g_rep_seconds[r]; keys[r] = g_rep_keys[r]; }
+  pthread_mutex_unlock(&g_rep_lock);
+}
+
+/* the handle of `primary` (kind MC_KEY_*) on device index d, cloned device to device the first time it is asked for (mosfhet_hip_*_clone: hipMemcpyPeer
+ * over xGMI where the devices are peers; a seed-compressed table key travels compressed) */
 static void *replica_on(void *primary, int kind, int d) {
   if (d == 0 || !primary) return primary;
   pthread_mutex_lock(&g_rep_lock);
@@ -63,33 +75,30 @@ static void *replica_on(void *primary, int kind, int d) {
   if (!slot) { fprintf(stderr, "mosfhet_amd: too many replicated keys\n"); abort(); }
   if (!slot->rep[d]) {
     mosfhet_hip_ctx_t ctx = mc_ctx_of(d);
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    size_t bytes = 0;
     if (kind == MC_KEY_BSK) {
-      int info[6];
-      mosfhet_hip_bsk_t src = (mosfhet_hip_bsk_t)primary, dst = NULL;
-      if (mosfhet_hip_bsk_info(src, info)) mc_die("key replication");
-      const size_t bytes = mosfhet_hip_bsk_bytes(src);
-      void *img = mc_xmalloc(bytes);
-      if (mosfhet_hip_bsk_export(src, img) || mosfhet_hip_bsk_import(ctx, &dst, img, info[0], info[1], info[2], info[3], info[4], info[5])) mc_die("key replication");
-      free(img);
+      mosfhet_hip_bsk_t dst = NULL;
+      if (mosfhet_hip_bsk_clone(ctx, &dst, (mosfhet_hip_bsk_t)primary)) mc_die("key replication (bootstrap key)");
+      bytes = mosfhet_hip_bsk_bytes(dst);
       slot->rep[d] = dst;
-    } else {   /* MC_KEY_KSK: table key, streamed row-wise through a 64 MiB host buffer */
-      int info[6];
-      mosfhet_hip_ksk_t src = (mosfhet_hip_ksk_t)primary, dst = NULL;
-      if (mosfhet_hip_ksk_info(src, info)) mc_die("key replication");
-      const int n_in = info[0], row = info[1], t = info[3], base_bit = info[4], kind_id = info[5];
-      const int n = kind_id == 2 ? n_in - 1 : n_in, n_out_or_N = kind_id == 0 ? row - 1 : row / 2;
-      if (mosfhet_hip_ksk_alloc(ctx, &dst, kind_id, n, n_out_or_N, t, base_bit)) mc_die("key replication");
-      const size_t rows = (size_t)n_in * t * ((1u << base_bit) - 1), row_bytes = (size_t)row * sizeof(Torus);
-      size_t chunk = ((size_t)64 << 20) / row_bytes;
-      if (!chunk) chunk = 1;
-      Torus *buf = (Torus *)mc_xmalloc(chunk * row_bytes);
-      for (size_t r = 0; r < rows; r += chunk) {
-        const size_t c = rows - r < chunk ? rows - r : chunk;
-        if (mosfhet_hip_ksk_export_rows(src, r, c, buf) || mosfhet_hip_ksk_import_rows(dst, r, c, buf)) mc_die("key replication");
-      }
-      free(buf);
+    } else if (kind == MC_KEY_KSK) {
+      mosfhet_hip_ksk_t dst = NULL;
+      if (mosfhet_hip_ksk_clone(ctx, &dst, (mosfhet_hip_ksk_t)primary)) mc_die("key replication (table key)");
+      bytes = mosfhet_hip_ksk_bytes(dst);
+      slot->rep[d] = dst;
+    } else {
+      mosfhet_hip_gak_t dst = NULL;
+      if (mosfhet_hip_gak_clone(ctx, &dst, (mosfhet_hip_gak_t)primary)) mc_die("key replication (FFT key-switch keys)");
+      bytes = mosfhet_hip_gak_bytes(dst);
       slot->rep[d] = dst;
     }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    const int route = mosfhet_hip_last_clone_route() & 3;
+    g_rep_bytes[route] += bytes;
+    g_rep_seconds[route] += (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    g_rep_keys[route]++;
   }
   void *r = slot->rep[d];
   pthread_mutex_unlock(&g_rep_lock);
@@ -106,7 +115,8 @@ void mc_replicas_free(void *primary) {
       for (int d = 1; d < MC_MAX_DEVICES; d++)
         if (g_reps[i].rep[d]) {
           if (g_reps[i].kind == MC_KEY_BSK) mosfhet_hip_bsk_destroy((mosfhet_hip_bsk_t)g_reps[i].rep[d]);
-          else mosfhet_hip_ksk_destroy((mosfhet_hip_ksk_t)g_reps[i].rep[d]);
+          else if (g_reps[i].kind == MC_KEY_KSK) mosfhet_hip_ksk_destroy((mosfhet_hip_ksk_t)g_reps[i].rep[d]);
+          else mosfhet_hip_gak_destroy((mosfhet_hip_gak_t)g_reps[i].rep[d]);
         }
       memset(&g_reps[i], 0, sizeof(g_reps[i]));
     }

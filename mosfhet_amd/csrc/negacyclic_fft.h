@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace mosfhet {
 
 typedef double __attribute__((ext_vector_type(2))) d2;
@@ -138,6 +140,7 @@ __device__ __forceinline__ PassTw load_pass_tw(const d2 *__restrict__ tw, int le
 // ------------------------------------------------------------------------------------------------
 struct Fft1024 {
   static constexpr int N = 1024, M = 512, LOGM = 9, THREADS = 64, P = 8;
+  static constexpr bool kLtw = false, kForward2 = false;
   static __device__ __forceinline__ void sync() { wave_lds_sync(); }
   PassTw wa, wb, wc;  // wa is lane-uniform (lives in SGPRs), wb / wc are per lane
 
@@ -263,24 +266,62 @@ __device__ __forceinline__ void team_sync() { __syncthreads(); }
 // loads (forward_tail) is then a full three-level one, as at N = 1024.  Same layouts, same exchanges, same butterflies with the same twiddles in the
 // same order per element -- bit-identical results (oracle_fft.c), same slot order.  Which one is faster depends on the registers the caller has left
 // under the last pass: l = 1 bootstraps gain 2 % (SET_2) to 6 % (SET_3), the l = 4 kernel of lvl2 loses 5 % (experiments/README.md, round 2).
-template <bool TAIL3>
-struct Fft2048T {
+// LTW = true: the per-lane twiddles of passes B and C (32 VGPRs) live in a 4.5 KiB LDS table of the workgroup instead -- 8 sets of pass B (one per
+// j[9:7]) and 64 of pass C (one per j[9:4]), 4 complex each -- and are read where a pass needs them (4 ds_read_b128).  For kernels that are short of
+// registers and have the LDS to spare (same-box A/B, experiments/README.md round 4: the lvl2 external product -6 %; the fused bootstrap, whose LDS
+// pipe is the second-busiest unit, +1 %).  Same values, same butterflies: bit-identical.  Kernels set such a transform up with fft_setup().
+struct Fft2048TwRegs {
+  static constexpr bool kLtw = false;
+  PassTw wb, wc;
+  __device__ __forceinline__ const PassTw &WB() const { return wb; }
+  __device__ __forceinline__ const PassTw &WC() const { return wc; }
+};
+struct Fft2048TwLds {
+  static constexpr bool kLtw = true;
+  static constexpr int LTW_SLOTS = 4 * (8 + 64);
+  const d2 *lb, *lc;
+  static __device__ __forceinline__ PassTw lds_tw(const d2 *q) {
+    const d2 a = q[0], b = q[1], c = q[2], d = q[3];
+    PassTw w;
+    w.w0r = a.x; w.w0i = a.y; w.w1r = b.x; w.w1i = b.y; w.w2ar = c.x; w.w2ai = c.y; w.w2br = d.x; w.w2bi = d.y;
+    return w;
+  }
+  __device__ __forceinline__ PassTw WB() const { return lds_tw(lb); }
+  __device__ __forceinline__ PassTw WC() const { return lds_tw(lc); }
+  // fills the table (threads 0..71 of the workgroup, one set each) and points this thread at its sets; the caller synchronises the workgroup
+  __device__ __forceinline__ void init_ltw(const d2 *__restrict__ tw, int t, d2 *tab) {
+    if (t < 72) {
+      const int lev = t < 8 ? 3 : 6, nu = t < 8 ? t : t - 8;
+      tab[4 * t + 0] = tw[(1 << lev) - 1 + nu];
+      tab[4 * t + 1] = tw[(2 << lev) - 1 + 2 * nu];
+      tab[4 * t + 2] = tw[(4 << lev) - 1 + 4 * nu];
+      tab[4 * t + 3] = tw[(4 << lev) - 1 + 4 * nu + 2];
+    }
+    lb = tab + 4 * (t >> 4);
+    lc = tab + 4 * (8 + (t >> 1));
+  }
+};
+
+template <bool TAIL3, bool LTW = false>
+struct Fft2048T : std::conditional<LTW, Fft2048TwLds, Fft2048TwRegs>::type {
+  static_assert(!(TAIL3 && LTW), "the LDS table holds full three-level sets");
   static constexpr int N = 2048, M = 1024, LOGM = 10, THREADS = 128, P = 8;
   static constexpr int XCH_SLOTS = 1152;
+  static constexpr bool kForward2 = true;
   static __device__ __forceinline__ void sync() { team_sync(); }
-  PassTw wa, wb, wc;
+  PassTw wa;
   PassTw wd;   // TAIL3: levels 7-9 of layout D (and only w0 of wc is used); else only w2a / w2b: level 9, nodes 4t and 4t+2 (4t+1, 4t+3 are i times those)
 
   __device__ __forceinline__ void init(const d2 *__restrict__ tw, int t) {
     wa = load_pass_tw(tw, 0, 0);
-    wb = load_pass_tw(tw, 3, t >> 4);
+    if constexpr (!LTW) this->wb = load_pass_tw(tw, 3, t >> 4);
     if constexpr (TAIL3) {
       const d2 c = tw[(1 << 6) - 1 + (t >> 1)];
-      wc.w0r = c.x; wc.w0i = c.y;
-      wc.w1r = wc.w1i = wc.w2ar = wc.w2ai = wc.w2br = wc.w2bi = 0.0;
+      this->wc.w0r = c.x; this->wc.w0i = c.y;
+      this->wc.w1r = this->wc.w1i = this->wc.w2ar = this->wc.w2ai = this->wc.w2br = this->wc.w2bi = 0.0;
       wd = load_pass_tw(tw, 7, t);
     } else {
-      wc = load_pass_tw(tw, 6, t >> 1);
+      if constexpr (!LTW) this->wc = load_pass_tw(tw, 6, t >> 1);
       const d2 a = tw[(1 << 9) - 1 + 4 * t], b = tw[(1 << 9) - 1 + 4 * t + 2];
       wd.w0r = wd.w0i = wd.w1r = wd.w1i = 0.0;
       wd.w2ar = a.x; wd.w2ai = a.y; wd.w2br = b.x; wd.w2bi = b.y;
@@ -298,12 +339,12 @@ struct Fft2048T {
   static __device__ __forceinline__ constexpr int off_c3(int m) { return 2 * m + (m >> 2); }
 
   __device__ __forceinline__ void pass_c_fwd(double (&re)[8], double (&im)[8]) const {
-    if constexpr (TAIL3) pass_fwd_top1(re, im, wc);
-    else pass_fwd(re, im, wc);
+    if constexpr (TAIL3) pass_fwd_top1(re, im, this->WC());
+    else pass_fwd(re, im, this->WC());
   }
   __device__ __forceinline__ void pass_c_inv(double (&re)[8], double (&im)[8]) const {
-    if constexpr (TAIL3) pass_inv_top1(re, im, wc);
-    else pass_inv(re, im, wc);
+    if constexpr (TAIL3) pass_inv_top1(re, im, this->WC());
+    else pass_inv(re, im, this->WC());
   }
   __device__ __forceinline__ void pass_d_fwd(double (&re)[8], double (&im)[8]) const {
     if constexpr (TAIL3) {
@@ -338,7 +379,7 @@ struct Fft2048T {
 #pragma unroll
       for (int m = 0; m < 8; m++) { const d2 v = r[16 * m]; re[m] = v.x; im[m] = v.y; }
     }
-    pass_fwd(re, im, wb);
+    pass_fwd(re, im, this->WB());
     team_sync();
     // From here on the wavefront index is j[9] in every layout (B: t = 16 j[9:7] + j[3:0], C: t = 2 j[9:4] + j[0], D: t = j[9:3]) and
     // both slot maps send j < 512 to slots < 576 and j >= 512 to slots >= 576: the B<->C and C<->D exchanges stay inside a wavefront
@@ -371,6 +412,62 @@ struct Fft2048T {
     forward_tail(re, im);
   }
 
+  // Two forward transforms (two consecutive TRGSW rows' digit polynomials) software-pipelined through the ONE buffer, the mirror image of inverse2:
+  // every register pass of one transform runs while the other's exchange is in flight, and the cross-wavefront A -> B exchanges cost 4 workgroup
+  // barriers for the pair (+ 1 in forward2_done) instead of 6.  Same butterflies on the same elements in the same order as forward(): bit-identical.
+  // On return x is in layout D in front of its last pass (as after forward_head) and y is PARKED in the buffer in layout C (slot map j + (j >> 3)):
+  // its registers are free until forward2_fetch reads it back in layout D.  The scheduling barriers keep the compiler from interleaving the stages
+  // any further (it then holds both transforms' temporaries at once and spills).
+  __device__ __forceinline__ void forward2_head(double (&xr)[8], double (&xi)[8], double (&yr)[8], double (&yi)[8], d2 *xch, int t) const {
+    d2 *pa = xch + base_a(t), *pb1 = xch + base_b1(t), *pb2 = xch + base_b2(t), *pc2 = xch + base_c2(t), *pc3 = xch + base_c3(t), *pd = xch + base_d3(t);
+    pass_fwd(xr, xi, wa);
+#pragma unroll
+    for (int m = 0; m < 8; m++) pa[128 * m] = d2{xr[m], xi[m]};
+    team_sync(); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < 8; m++) { const d2 v = pb1[16 * m]; xr[m] = v.x; xi[m] = v.y; }
+    pass_fwd(yr, yi, wa);
+    team_sync(); __builtin_amdgcn_sched_barrier(0);   // both wavefronts have read x
+#pragma unroll
+    for (int m = 0; m < 8; m++) pa[128 * m] = d2{yr[m], yi[m]};
+    team_sync(); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < 8; m++) { const d2 v = pb1[16 * m]; yr[m] = v.x; yi[m] = v.y; }
+    pass_fwd(xr, xi, this->WB());
+    team_sync(); __builtin_amdgcn_sched_barrier(0);   // both wavefronts have read y; from here on every exchange stays inside a wavefront and its half of the buffer (see forward_head)
+#pragma unroll
+    for (int m = 0; m < 8; m++) pb2[18 * m] = d2{xr[m], xi[m]};
+    wave_lds_sync(); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < 8; m++) { const d2 v = pc2[2 * m]; xr[m] = v.x; xi[m] = v.y; }
+    pass_fwd(yr, yi, this->WB());
+    wave_lds_sync(); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < 8; m++) pb2[18 * m] = d2{yr[m], yi[m]};
+    wave_lds_sync(); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < 8; m++) { const d2 v = pc2[2 * m]; yr[m] = v.x; yi[m] = v.y; }
+    pass_c_fwd(xr, xi);
+    wave_lds_sync(); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < 8; m++) pc3[off_c3(m)] = d2{xr[m], xi[m]};
+    wave_lds_sync(); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < 8; m++) { const d2 v = pd[m]; xr[m] = v.x; xi[m] = v.y; }
+    pass_c_fwd(yr, yi);
+    wave_lds_sync(); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < 8; m++) pc3[off_c3(m)] = d2{yr[m], yi[m]};
+    wave_lds_sync(); __builtin_amdgcn_sched_barrier(0);
+  }
+  // y back from the buffer, in layout D in front of its last pass.  The caller runs pass_d_fwd on it and then forward2_done().
+  __device__ __forceinline__ void forward2_fetch(double (&yr)[8], double (&yi)[8], d2 *xch, int t) const {
+    const d2 *pd = xch + base_d3(t);
+#pragma unroll
+    for (int m = 0; m < 8; m++) { const d2 v = pd[m]; yr[m] = v.x; yi[m] = v.y; }
+  }
+  static __device__ __forceinline__ void forward2_done() { team_sync(); }   // nobody reads the buffer any more (entry condition of the next transform)
+
   // inverse: input in layout D, output in layout A, UNSCALED
   __device__ __forceinline__ void inverse(double (&re)[8], double (&im)[8], d2 *xch, int t) const {
     pass_d_inv(re, im);
@@ -392,7 +489,7 @@ struct Fft2048T {
 #pragma unroll
       for (int m = 0; m < 8; m++) { const d2 v = r[18 * m]; re[m] = v.x; im[m] = v.y; }
     }
-    pass_inv(re, im, wb);
+    pass_inv(re, im, this->WB());
     team_sync();
     {
       d2 *w = xch + base_b1(t), *r = xch + base_a(t);
@@ -444,14 +541,14 @@ struct Fft2048T {
 #pragma unroll
     for (int m = 0; m < 8; m++) pc2[2 * m] = d2{yr[m], yi[m]};
     wave_lds_sync();
-    pass_inv(xr, xi, wb);
+    pass_inv(xr, xi, this->WB());
 #pragma unroll
     for (int m = 0; m < 8; m++) { const d2 v = pb2[18 * m]; yr[m] = v.x; yi[m] = v.y; }
     team_sync();
 #pragma unroll
     for (int m = 0; m < 8; m++) pb1[16 * m] = d2{xr[m], xi[m]};
     team_sync();
-    pass_inv(yr, yi, wb);
+    pass_inv(yr, yi, this->WB());
 #pragma unroll
     for (int m = 0; m < 8; m++) { const d2 v = pa[128 * m]; xr[m] = v.x; xi[m] = v.y; }
     team_sync();
@@ -467,6 +564,18 @@ struct Fft2048T {
 };
 using Fft2048 = Fft2048T<false>;
 using Fft2048W = Fft2048T<true>;
+using Fft2048L = Fft2048T<false, true>;   // twiddles of passes B and C in LDS
+
+// transform set-up of a kernel: twiddles into registers and, for a transform that keeps some in LDS, the workgroup's table
+template <class F>
+__device__ __forceinline__ void fft_setup(F &fft, const d2 *__restrict__ tw, int t) {
+  fft.init(tw, t);
+  if constexpr (F::kLtw) {
+    __shared__ __attribute__((aligned(16))) d2 ltw_tab[F::LTW_SLOTS];
+    fft.init_ltw(tw, t, ltw_tab);
+    __syncthreads();
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // N = 4096 (M = 2048; the reference's SET_3, test/tests.c:48): four wavefronts (256 threads) x 8 points.
@@ -485,6 +594,7 @@ using Fft2048W = Fft2048T<true>;
 template <bool TAIL3>
 struct Fft4096T {
   static constexpr int N = 4096, M = 2048, LOGM = 11, THREADS = 256, P = 8;
+  static constexpr bool kLtw = false, kForward2 = false;
   static constexpr int XCH_SLOTS = 2304;
   static __device__ __forceinline__ void sync() { team_sync(); }
   PassTw wa, wb, wc, wd;  // TAIL3: wc = levels 6-7 (w0, w1), wd = levels 8-10; else wc = levels 6-8, wd: only w1 (level 9, node 2t) and w2a / w2b (level 10)
