@@ -920,12 +920,11 @@ static int launch_ga_f(int l, int Bg_bit, const GaParams &g, int count, hipStrea
     }
   }
   if constexpr (std::is_same<F, Fft2048>::value) {
-    // N = 2048: the pass twiddles in LDS (Fft2048L) take the 2 x 2^9 ... 4 x 2^9 kernels out of scratch (68 bytes -> 0 at lvl2)
+    // lvl2: the pass twiddles in LDS (Fft2048L) take the kernel out of scratch (68 bytes -> 0, 250 registers; same speed: experiments/README.md round 4).
+    // The run-time-gadget instantiations spill with either transform and stay where they were.  MOSFHET_HIP_GA_LTW=0: the register-twiddle kernel.
     static int ltw = -1;
     if (ltw < 0) { const char *e = getenv("MOSFHET_HIP_GA_LTW"); ltw = (e && e[0] == '0') ? 0 : 1; }
     if (ltw && l == 4 && Bg_bit == 9) { launch_ga<Fft2048L, 4, 9>(g, count, s); HIP_TRY(hipGetLastError()); return MOSFHET_HIP_OK; }
-    if (ltw && l == 4) { launch_ga<Fft2048L, 4, 0>(g, count, s); HIP_TRY(hipGetLastError()); return MOSFHET_HIP_OK; }
-    if (ltw && l == 2) { launch_ga<Fft2048L, 2, 0>(g, count, s); HIP_TRY(hipGetLastError()); return MOSFHET_HIP_OK; }
   }
   if (l == 2 && Bg_bit == 8) launch_ga<F, 2, 8>(g, count, s);
   else if (l == 4 && Bg_bit == 9) launch_ga<F, 4, 9>(g, count, s);
