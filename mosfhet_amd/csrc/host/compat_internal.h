@@ -19,6 +19,12 @@ extern int hipStreamCreate(void **stream);
 extern int hipStreamSynchronize(void *stream);
 extern int hipMemcpyAsync(void *dst, const void *src, size_t size, int kind, void *stream);
 extern int hipHostFree(void *ptr);
+extern int hipEventCreateWithFlags(void **event, unsigned flags);
+extern int hipEventRecord(void *event, void *stream);
+extern int hipEventSynchronize(void *event);
+extern int hipEventDestroy(void *event);
+extern int hipStreamWaitEvent(void *stream, void *event, unsigned flags);
+#define HIP_EVENT_DISABLE_TIMING 2u
 extern int hipSetDevice(int device);
 extern int hipGetDevice(int *device);
 #define HIP_H2D 1

@@ -11,6 +11,7 @@
 
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
@@ -519,7 +520,7 @@ void mc_trlwe_from_flat(TRLWE c, const Torus *flat) {
  * The reference's callers hold batches as arrays of separately allocated TLWE structs (applications/multi-ciphertext-arith/src/lut.c:12-17); turning
  * 4096 of them into the flat device layout and back is 53 MB of pointer-chasing copies -- 2.5 ms on one core next to a 15.5 ms kernel.  A small pool
  * of helper threads (plain memcpy workers: they never touch HIP) splits those loops; the calling thread takes part.  One job at a time: a second
- * caller thread that finds the pool busy simply copies on its own.  MOSFHET_HIP_MARSHAL_THREADS = helpers (default 3, 0 disables). */
+ * caller thread that finds the pool busy simply copies on its own.  MOSFHET_HIP_MARSHAL_THREADS = helpers (default 1 .. 7 by core count, 0 disables). */
 typedef void (*mc_range_fn)(void *arg, int lo, int hi);
 static struct {
   pthread_mutex_t user, lock;
@@ -569,7 +570,12 @@ static void pool_atfork_child(void) {
 }
 static void pool_init_once(void) {
   const char *e = getenv("MOSFHET_HIP_MARSHAL_THREADS");
-  int want = e ? atoi(e) : 3;
+  /* default: half of the cores this process may use, less the caller, between 1 and 7 helpers (3 on an 8-core host; a GPU node has far more cores than
+   * the copies can use: 7 helpers measured 251.8 against 246 - 250 k bootstraps/s with 3) */
+  int cores = 8;
+  cpu_set_t set;
+  if (!sched_getaffinity(0, sizeof(set), &set)) cores = CPU_COUNT(&set);
+  int want = e ? atoi(e) : (cores / 2 - 1 < 1 ? 1 : (cores / 2 - 1 > 7 ? 7 : cores / 2 - 1));
   if (want < 0) want = 0;
   if (want > 15) want = 15;
   __atomic_store_n(&g_pool.helpers, want, __ATOMIC_RELEASE);
@@ -846,7 +852,22 @@ static int pipe_chunk(void) {   /* MOSFHET_HIP_PIPE_CHUNK overrides (tools/compa
   }
   return v;
 }
+/* Two streams of the calling thread, chunks alternate; a chunk's upload, kernel and download are queued on ITS stream.  That keeps the residency rounds
+ * aligned: the kernel of chunk c + 2 sits behind the download of chunk c, which ends about when chunk c + 1's kernel does, so the two kernels of a round
+ * start together (round 4 measured the alternative -- dedicated copy streams, every chunk uploaded as early as the host packs it, kernels waiting for
+ * nothing but their own upload: 19.5 instead of 16.8 ms per 4096; queued back to back, the blocks of the next round trickle in as the blocks of this one
+ * finish and the workgroups no longer walk the key together: experiments/README.md).  A chunk comes back in pieces of 512 ciphertexts, an event behind
+ * each, so the host unpacks one piece while the next lands -- what is left exposed at the end is one piece, not a chunk. */
 static __thread void *g_pipe_streams[2];
+static int pipe_piece(void) {   /* MOSFHET_HIP_PIPE_PIECE overrides (ciphertexts per download piece) */
+  static int v = 0;
+  if (!v) {
+    const char *e = getenv("MOSFHET_HIP_PIPE_PIECE");
+    v = e ? atoi(e) : 512;
+    if (v < 32) v = 32;
+  }
+  return v;
+}
 static void bootstrap_pipelined(int mode, TLWE *out, TRLWE tv, TLWE *in, int count, Bootstrap_Key key, int a0, int kappa, int theta) {
   mosfhet_hip_ctx_t ctx = (mosfhet_hip_ctx_t)mosfhet_engine_ctx();
   mosfhet_hip_bsk_t bsk = (mosfhet_hip_bsk_t)mc_key_here(key->device, MC_KEY_BSK);
@@ -859,28 +880,41 @@ static void bootstrap_pipelined(int mode, TLWE *out, TRLWE tv, TLWE *in, int cou
   Torus *h = (Torus *)mc_hstage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
   Torus *d = (Torus *)mc_stage_alloc(sizeof(Torus) * (in_w + tv_w + out_w));
   Torus *h_tv = h + in_w, *h_out = h + in_w + tv_w, *d_tv = d + in_w, *d_out = d + in_w + tv_w;
+  const int piece = pipe_piece(), n_pieces = (count + piece - 1) / piece + (count + PIPE_CHUNK - 1) / PIPE_CHUNK;
+  void **ev = (void **)mc_xmalloc(sizeof(void *) * (size_t)n_pieces);
+  int made = 0, taken = 0;   /* events recorded / waited for; pieces are unpacked in the order they were queued */
   mc_trlwe_to_flat(h_tv, tv);
   mc_dev_copy(d_tv, h_tv, sizeof(Torus) * tv_w, HIP_H2D);
-  int prev_lo = -1, prev_c = 0;
-  for (int lo = 0, c = 0; lo < count; lo += PIPE_CHUNK, c++) {
-    const int cnt = count - lo < PIPE_CHUNK ? count - lo : PIPE_CHUNK;
-    void *st = g_pipe_streams[c & 1];
-    tlwe_array_to_flat(h + (size_t)lo * in_row, in + lo, cnt, n);
-    if (hipMemcpyAsync(d + (size_t)lo * in_row, h + (size_t)lo * in_row, sizeof(Torus) * (size_t)cnt * in_row, HIP_H2D, st)) mc_die("bootstrap (copy in)");
-    const int rc = mode == MODE_PROGRAMMABLE
-                       ? mosfhet_hip_programmable_bootstrap_batch(ctx, bsk, d_out + (size_t)lo * out_row, d_tv, 1, d + (size_t)lo * in_row, cnt, a0, kappa, theta, st)
-                       : mosfhet_hip_functional_bootstrap_batch(ctx, bsk, d_out + (size_t)lo * out_row, d_tv, 1, d + (size_t)lo * in_row, cnt, a0, st);
-    if (rc) mc_die("bootstrap");
-    if (hipMemcpyAsync(h_out + (size_t)lo * out_row, d_out + (size_t)lo * out_row, sizeof(Torus) * (size_t)cnt * out_row, HIP_D2H, st)) mc_die("bootstrap (copy out)");
-    if (prev_lo >= 0) {   /* the previous chunk's results: wait for its stream, unpack while this chunk runs */
-      if (hipStreamSynchronize(g_pipe_streams[prev_c & 1])) mc_die("bootstrap");
-      tlwe_array_from_flat(out + prev_lo, h_out + (size_t)prev_lo * out_row, lo - prev_lo, k * N);
+  int prev_lo = -1, prev_cnt = 0;
+  for (int lo = 0, c = 0;; lo += PIPE_CHUNK, c++) {   /* one more turn than there are chunks: the last one only unpacks */
+    const int cnt = lo < count ? (count - lo < PIPE_CHUNK ? count - lo : PIPE_CHUNK) : 0;
+    if (cnt) {
+      void *st = g_pipe_streams[c & 1];
+      tlwe_array_to_flat(h + (size_t)lo * in_row, in + lo, cnt, n);
+      if (hipMemcpyAsync(d + (size_t)lo * in_row, h + (size_t)lo * in_row, sizeof(Torus) * (size_t)cnt * in_row, HIP_H2D, st)) mc_die("bootstrap (copy in)");
+      const int rc = mode == MODE_PROGRAMMABLE
+                         ? mosfhet_hip_programmable_bootstrap_batch(ctx, bsk, d_out + (size_t)lo * out_row, d_tv, 1, d + (size_t)lo * in_row, cnt, a0, kappa, theta, st)
+                         : mosfhet_hip_functional_bootstrap_batch(ctx, bsk, d_out + (size_t)lo * out_row, d_tv, 1, d + (size_t)lo * in_row, cnt, a0, st);
+      if (rc) mc_die("bootstrap");
+      for (int p = lo; p < lo + cnt; p += piece) {
+        const int pc = lo + cnt - p < piece ? lo + cnt - p : piece;
+        if (hipMemcpyAsync(h_out + (size_t)p * out_row, d_out + (size_t)p * out_row, sizeof(Torus) * (size_t)pc * out_row, HIP_D2H, st)) mc_die("bootstrap (copy out)");
+        if (hipEventCreateWithFlags(&ev[made], HIP_EVENT_DISABLE_TIMING) || hipEventRecord(ev[made], st)) mc_die("bootstrap (event)");
+        made++;
+      }
     }
-    prev_lo = lo;
-    prev_c = c;
+    if (prev_lo >= 0)   /* the previous chunk's results, piece by piece, while this chunk runs */
+      for (int p = prev_lo; p < prev_lo + prev_cnt; p += piece, taken++) {
+        const int pc = prev_lo + prev_cnt - p < piece ? prev_lo + prev_cnt - p : piece;
+        if (hipEventSynchronize(ev[taken])) mc_die("bootstrap");
+        tlwe_array_from_flat(out + p, h_out + (size_t)p * out_row, pc, k * N);
+      }
+    prev_lo = cnt ? lo : -1;
+    prev_cnt = cnt;
+    if (!cnt) break;
   }
-  if (hipStreamSynchronize(g_pipe_streams[prev_c & 1])) mc_die("bootstrap");
-  tlwe_array_from_flat(out + prev_lo, h_out + (size_t)prev_lo * out_row, count - prev_lo, k * N);
+  for (int i = 0; i < made; i++) hipEventDestroy(ev[i]);
+  free(ev);
   stage_free(d);
   mc_hstage_free(h);
 }
