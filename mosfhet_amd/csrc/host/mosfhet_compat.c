@@ -1487,6 +1487,19 @@ void trlwe_packing1_keyswitch(TRLWE out, TLWE in, Generic_KS_Key ks) {
   mc_hstage_free(h);
 }
 
+/* TRGSW outputs of a circuit-bootstrap batch: [count][2l][2][N] flat -> the structs' 2l (k + 1) separately allocated polynomials, over the helper threads
+ * (256 KiB per output at lvl2: 268 MB per 1024 -- serial, that copy took as long as the kernels) */
+typedef struct { TRGSW *out; const Torus *flat; int rows; size_t row; } TrgswSpan;
+static void trgsw_from_flat_range(void *pv, int lo, int hi) {
+  const TrgswSpan *a = (const TrgswSpan *)pv;
+  for (int b = lo; b < hi; b++)
+    for (int q = 0; q < a->rows; q++) mc_trlwe_from_flat(a->out[b]->samples[q], a->flat + ((size_t)b * a->rows + q) * a->row);
+}
+static void trgsw_array_from_flat(TRGSW *out, const Torus *flat, int count, int rows, size_t row) {
+  TrgswSpan a = {out, flat, rows, row};
+  mc_parallel_for(trgsw_from_flat_range, &a, count, 1);
+}
+
 typedef struct { TRGSW *out; TLWE *in; Bootstrap_Key key; TRLWE_KS_Key *kska; Generic_KS_Key kskb; } Cb3Slice;
 static void cb3_slice(void *pv, int lo, int hi) {
   Cb3Slice *a = (Cb3Slice *)pv;
@@ -1513,8 +1526,7 @@ void circuit_bootstrap_3_batch(TRGSW *out, TLWE *in, int count, Bootstrap_Key ke
       mosfhet_hip_ctx_sync(ctx, NULL))
     mc_die("circuit_bootstrap_3");
   mc_dev_copy(h + in_w, d + in_w, sizeof(Torus) * out_w, HIP_D2H);
-  for (int b = 0; b < count; b++)
-    for (int q = 0; q < 2 * l; q++) mc_trlwe_from_flat(out[b]->samples[q], h + in_w + ((size_t)b * 2 * l + q) * row);
+  trgsw_array_from_flat(out, h + in_w, count, 2 * l, row);
   stage_free(d);
   mc_hstage_free(h);
 }
@@ -1593,8 +1605,7 @@ static void circuit_bootstrap_many(TRGSW *out, TLWE *in, int count, Bootstrap_Ke
   check_rc(mosfhet_hip_circuit_bootstrap_batch(ectx(), (mosfhet_hip_bsk_t)mc_key_here(key->device, MC_KEY_BSK), (mosfhet_hip_ksk_t)mc_key_here(kska->device, MC_KEY_KSK),
                                                (mosfhet_hip_ksk_t)mc_key_here(kskb->device, MC_KEY_KSK), b.d + in_w, b.d, count, variant, NULL), "circuit_bootstrap");
   buf_down(&b, in_w, out_w);
-  for (int c = 0; c < count; c++)
-    for (int q = 0; q < 2 * l; q++) mc_trlwe_from_flat(out[c]->samples[q], b.h + in_w + ((size_t)c * 2 * l + q) * row);
+  trgsw_array_from_flat(out, b.h + in_w, count, 2 * l, row);
   buf_free(&b);
 }
 

@@ -10,6 +10,9 @@ workload on rank 0.  Usage: python tools/bench_configs.py [--steps K] [--warmup 
   multivalue      configs[4]: multivalue_bootstrap_CLOT21, 8 LUTs of 2 slots, at N=2048, 1024 per GPU
   ga              configs[4]: functional_bootstrap_ga at N=2048 (automorphism keys 256 MiB), 1024 per GPU
   keyswitch_lvl2  LWE key switch N=2048 -> n=632, t=8 bb=4 (1.2 GB table), 4096 per GPU
+
+  --in-api-devices 0,1,...   the same configs[3] / [4] workloads through the drop-in C API (host structs, *_batch entry points) with several devices behind
+                  it in ONE process (mosfhet_set_devices: the library shards every batch and replicates the keys device to device): tools/in_api_devices.c
 """
 import argparse
 import json
@@ -27,7 +30,19 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--only", default=None)
+    ap.add_argument("--in-api-devices", default=None, metavar="IDS",
+                    help="instead: configs[3] / [4] through the drop-in C API in ONE process with these devices behind it (mosfhet_set_devices; e.g. 0,1,2,3,4,5,6,7, "
+                         "or 0,0 for two contexts on one GPU): compiles and runs tools/in_api_devices.c and relays its JSON lines")
     args = ap.parse_args()
+    if args.in_api_devices:
+        import subprocess
+        from mosfhet_amd import build
+        build.build()
+        exe = os.path.join(ROOT, "tools", "in_api_devices_bin")
+        libdir = os.path.join(ROOT, "mosfhet_amd")
+        subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "in_api_devices.c"), "-o", exe, "-L" + libdir, "-lmosfhet_hip", "-lm",
+                               "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+        sys.exit(subprocess.call([exe, args.in_api_devices, str(args.steps)]))
     import torch
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
     if not torch.cuda.is_available():
