@@ -431,6 +431,21 @@ class Engine:
         _check(lib().mosfhet_hip_bsk_import(self.h, C.byref(h), image.ctypes.data_as(C.c_void_p), n, k, N, l, Bg_bit, unfolding))
         return BootstrapKey(self, h, n, k, N, l, Bg_bit)
 
+    def clone_key(self, key):
+        """A copy of a key handle of ANOTHER engine (or this one) on this engine's device, device to device (mosfhet_hip_*_clone: SURVEY 8(e), keys
+        replicated per GPU).  Returns (handle of the same class, route: 0 same device, 1 peer to peer, 2 device to device without peer access, 3 host bounce)."""
+        h = C.c_void_p()
+        if isinstance(key, BootstrapKey):
+            _check(lib().mosfhet_hip_bsk_clone(self.h, C.byref(h), key.h))
+            out = BootstrapKey(self, h, key.n, key.k, key.N, key.l, key.Bg_bit)
+        elif isinstance(key, KeySwitchKey):
+            _check(lib().mosfhet_hip_ksk_clone(self.h, C.byref(h), key.h))
+            out = KeySwitchKey(self, h, key.n_in, key.n_out, key.t, key.base_bit)
+        else:
+            _check(lib().mosfhet_hip_gak_clone(self.h, C.byref(h), key.h))
+            out = AutomorphismKeys(self, h, key.N, key.t, key.base_bit)
+        return out, int(lib().mosfhet_hip_last_clone_route())
+
     def bootstrap_key_info(self, bsk):
         v = (C.c_int * 6)()
         _check(lib().mosfhet_hip_bsk_info(bsk.h, v))
