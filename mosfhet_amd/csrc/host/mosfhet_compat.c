@@ -1499,6 +1499,29 @@ static void trgsw_array_from_flat(TRGSW *out, const Torus *flat, int count, int 
   TrgswSpan a = {out, flat, rows, row};
   mc_parallel_for(trgsw_from_flat_range, &a, count, 1);
 }
+/* ... straight from the device: the batch comes back in pieces of 64 outputs (16.8 MB at lvl2), an event behind each, and a piece is unpacked while the next
+ * one lands (the kernels have finished: the caller synchronised) */
+static void trgsw_array_download(TRGSW *out, Torus *h_flat, const Torus *d_flat, int count, int rows, size_t row) {
+  enum { PIECE = 64 };
+  const size_t item = (size_t)rows * row;
+  const int n_pieces = (count + PIECE - 1) / PIECE;
+  mc_use_device();
+  if (!g_pipe_streams[0] && hipStreamCreate(&g_pipe_streams[0])) mc_die("circuit bootstrap (stream)");
+  void **ev = (void **)mc_xmalloc(sizeof(void *) * (size_t)(n_pieces ? n_pieces : 1));
+  for (int p = 0; p < n_pieces; p++) {
+    const int lo = p * PIECE, cnt = count - lo < PIECE ? count - lo : PIECE;
+    if (hipMemcpyAsync(h_flat + (size_t)lo * item, d_flat + (size_t)lo * item, sizeof(Torus) * (size_t)cnt * item, HIP_D2H, g_pipe_streams[0]) ||
+        hipEventCreateWithFlags(&ev[p], HIP_EVENT_DISABLE_TIMING) || hipEventRecord(ev[p], g_pipe_streams[0]))
+      mc_die("circuit bootstrap (copy out)");
+  }
+  for (int p = 0; p < n_pieces; p++) {
+    const int lo = p * PIECE, cnt = count - lo < PIECE ? count - lo : PIECE;
+    if (hipEventSynchronize(ev[p])) mc_die("circuit bootstrap (copy out)");
+    trgsw_array_from_flat(out + lo, h_flat + (size_t)lo * item, cnt, rows, row);
+    hipEventDestroy(ev[p]);
+  }
+  free(ev);
+}
 
 typedef struct { TRGSW *out; TLWE *in; Bootstrap_Key key; TRLWE_KS_Key *kska; Generic_KS_Key kskb; } Cb3Slice;
 static void cb3_slice(void *pv, int lo, int hi) {
@@ -1525,8 +1548,7 @@ void circuit_bootstrap_3_batch(TRGSW *out, TLWE *in, int count, Bootstrap_Key ke
                                             (mosfhet_hip_ksk_t)mc_key_here(kskb->device, MC_KEY_KSK), d + in_w, d, count, NULL) ||
       mosfhet_hip_ctx_sync(ctx, NULL))
     mc_die("circuit_bootstrap_3");
-  mc_dev_copy(h + in_w, d + in_w, sizeof(Torus) * out_w, HIP_D2H);
-  trgsw_array_from_flat(out, h + in_w, count, 2 * l, row);
+  trgsw_array_download(out, h + in_w, d + in_w, count, 2 * l, row);
   stage_free(d);
   mc_hstage_free(h);
 }
@@ -1604,8 +1626,7 @@ static void circuit_bootstrap_many(TRGSW *out, TLWE *in, int count, Bootstrap_Ke
   buf_up(&b, 0, in_w);
   check_rc(mosfhet_hip_circuit_bootstrap_batch(ectx(), (mosfhet_hip_bsk_t)mc_key_here(key->device, MC_KEY_BSK), (mosfhet_hip_ksk_t)mc_key_here(kska->device, MC_KEY_KSK),
                                                (mosfhet_hip_ksk_t)mc_key_here(kskb->device, MC_KEY_KSK), b.d + in_w, b.d, count, variant, NULL), "circuit_bootstrap");
-  buf_down(&b, in_w, out_w);
-  trgsw_array_from_flat(out, b.h + in_w, count, 2 * l, row);
+  trgsw_array_download(out, b.h + in_w, b.d + in_w, count, 2 * l, row);
   buf_free(&b);
 }
 

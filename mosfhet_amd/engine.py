@@ -427,6 +427,10 @@ class Engine:
 
     def import_bootstrap_key(self, image, n, k, N, l, Bg_bit, unfolding=1):
         image = np.ascontiguousarray(image, dtype=np.uint8)
+        # the C ABI takes a bare pointer: the length is checked here (an image is mosfhet_hip_bsk_bytes long: DFT entries, or the torus-domain samples of an unfolded key)
+        want = n * (k + 1) * l * (k + 1) * N * 8 if unfolding == 1 else (n << unfolding) // unfolding * 2 * l * 2 * N * 8
+        if image.nbytes != want:
+            raise MosfhetHipError("bootstrap-key image of %d bytes, %d expected for n=%d k=%d N=%d l=%d unfolding=%d" % (image.nbytes, want, n, k, N, l, unfolding))
         h = C.c_void_p()
         _check(lib().mosfhet_hip_bsk_import(self.h, C.byref(h), image.ctypes.data_as(C.c_void_p), n, k, N, l, Bg_bit, unfolding))
         return BootstrapKey(self, h, n, k, N, l, Bg_bit)
