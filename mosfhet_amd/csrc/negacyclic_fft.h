@@ -279,26 +279,31 @@ struct Fft2048TwRegs {
 struct Fft2048TwLds {
   static constexpr bool kLtw = true;
   static constexpr int LTW_SLOTS = 4 * (8 + 64);
+  // table layout: [4 twiddles][8 sets] of pass B, then [4][64] of pass C -- the sets of one twiddle side by side, so that the 16 lanes the LDS serves
+  // together read 16-byte entries of DIFFERENT sets from different banks (set-major, [set][4], the 8 sets a service group touches collide two ways:
+  // SQ_LDS_BANK_CONFLICT 5 % of the LDS cycles of the first build)
   const d2 *lb, *lc;
+  template <int SETS>
   static __device__ __forceinline__ PassTw lds_tw(const d2 *q) {
-    const d2 a = q[0], b = q[1], c = q[2], d = q[3];
+    const d2 a = q[0], b = q[SETS], c = q[2 * SETS], d = q[3 * SETS];
     PassTw w;
     w.w0r = a.x; w.w0i = a.y; w.w1r = b.x; w.w1i = b.y; w.w2ar = c.x; w.w2ai = c.y; w.w2br = d.x; w.w2bi = d.y;
     return w;
   }
-  __device__ __forceinline__ PassTw WB() const { return lds_tw(lb); }
-  __device__ __forceinline__ PassTw WC() const { return lds_tw(lc); }
+  __device__ __forceinline__ PassTw WB() const { return lds_tw<8>(lb); }
+  __device__ __forceinline__ PassTw WC() const { return lds_tw<64>(lc); }
   // fills the table (threads 0..71 of the workgroup, one set each) and points this thread at its sets; the caller synchronises the workgroup
   __device__ __forceinline__ void init_ltw(const d2 *__restrict__ tw, int t, d2 *tab) {
     if (t < 72) {
-      const int lev = t < 8 ? 3 : 6, nu = t < 8 ? t : t - 8;
-      tab[4 * t + 0] = tw[(1 << lev) - 1 + nu];
-      tab[4 * t + 1] = tw[(2 << lev) - 1 + 2 * nu];
-      tab[4 * t + 2] = tw[(4 << lev) - 1 + 4 * nu];
-      tab[4 * t + 3] = tw[(4 << lev) - 1 + 4 * nu + 2];
+      const int lev = t < 8 ? 3 : 6, nu = t < 8 ? t : t - 8, sets = t < 8 ? 8 : 64;
+      d2 *dst = (t < 8 ? tab : tab + 32) + nu;
+      dst[0] = tw[(1 << lev) - 1 + nu];
+      dst[sets] = tw[(2 << lev) - 1 + 2 * nu];
+      dst[2 * sets] = tw[(4 << lev) - 1 + 4 * nu];
+      dst[3 * sets] = tw[(4 << lev) - 1 + 4 * nu + 2];
     }
-    lb = tab + 4 * (t >> 4);
-    lc = tab + 4 * (8 + (t >> 1));
+    lb = tab + (t >> 4);
+    lc = tab + 32 + (t >> 1);
   }
 };
 

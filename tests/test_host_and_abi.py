@@ -244,6 +244,23 @@ def test_compat_c_suite_compiles_and_links(native_lib, tmp_path):
                            "-L" + libdir, "-lmosfhet_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
 
 
+def test_multi_device_programs_compile_and_link(native_lib, tmp_path):
+    """tests/c/multi_device.c (every sharded *_batch entry point against its single calls; run under -m gpu) and tools/in_api_devices.c (BASELINE configs[3] / [4]
+    through the drop-in API with a device list) build against the header and library: the sharded entry points, multivalue_bootstrap_CLOT21_batch and
+    mosfhet_replication_stats are declared and exported."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "mosfhet_amd")
+    for src in (os.path.join(root, "tests", "c", "multi_device.c"), os.path.join(root, "tools", "in_api_devices.c")):
+        subprocess.check_call(["gcc", "-O1", "-std=gnu11", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), src, "-o", str(tmp_path / "prog"), "-pthread",
+                               "-L" + libdir, "-lmosfhet_hip", "-lm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    exported = subprocess.run(["nm", "-D", "--defined-only", os.path.join(libdir, "libmosfhet_hip.so")], capture_output=True, text=True, check=True).stdout
+    for name in ("mosfhet_hip_bsk_clone", "mosfhet_hip_ksk_clone", "mosfhet_hip_gak_clone", "mosfhet_hip_last_clone_route", "multivalue_bootstrap_CLOT21_batch",
+                 "mosfhet_replication_stats"):
+        assert (" " + name + "\n") in exported, name
+
+
 def _build_fileio_helper(tmp_path):
     import os
     import subprocess
