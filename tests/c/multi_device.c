@@ -24,7 +24,7 @@ static int same_trgsw(TRGSW a, TRGSW b, int rows, int N) {
  * (plain and Galois), the automorphism key set, the private FFT key-switch pair, the relinearisation key, the packing and private table keys
  * (seed-compressed: they travel as their b halves). */
 static void wider_callers(TLWE_Key lwe_key, int n_dev) {
-  enum { N = 1024, k = 1, wl = 4, wBg = 9, C = 9 };
+  enum { N = 1024, k = 1, wl = 4, wBg = 9, C = 19 };   /* >= 2 x 8 devices: every batch below is sharded even over eight contexts */
   (void)n_dev;
   const int n = lwe_key->n;
   TRLWE_Key wkey = trlwe_new_binary_key(N, k, 5.684341886080802e-14);
@@ -128,8 +128,9 @@ static void wider_callers(TLWE_Key lwe_key, int n_dev) {
 
 int main(int argc, char **argv) {
   enum { n = 64, N = 1024, k = 1, l = 2, Bg_bit = 8, COUNT = 301, BIG = 2 * 4096 + 11 };
-  const int devs[2] = {0, 0};
+  const int devs[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* up to eight contexts on GPU 0: the slice arithmetic, worker threads and replicas of an 8-GPU node */
   const int n_dev = argc > 1 ? atoi(argv[1]) : 2;
+  if (n_dev < 1 || n_dev > 8) { printf("usage: multi_device [1 .. 8]\n"); return 255; }
   setvbuf(stdout, NULL, _IOLBF, 0);
   mosfhet_set_devices(n_dev, devs);
   mosfhet_seed(0x4D4F5346);
@@ -153,7 +154,11 @@ int main(int argc, char **argv) {
   int bad = 0;
   for (int i = 0; i < COUNT; i++) bad += tdist(lut[i % 4], tlwe_phase(out[i], extracted)) >= (1ULL << 58);
   CHECK(bad == 0, "%d of %d sharded bootstraps do not decrypt", bad, COUNT);
-  const int probe[6] = {0, 149, 150, 151, 152, COUNT - 1};
+  int probe[6] = {0, 149, 150, 151, 152, COUNT - 1};
+  if (n_dev > 2) {   /* both sides of the first and of the last slice boundary (mosfhet_amd/shard.py: the first COUNT % n slices get one more) */
+    const int base = COUNT / n_dev, extra = COUNT % n_dev, first_end = base + (extra > 0), last_begin = COUNT - base;
+    probe[1] = first_end - 1; probe[2] = first_end; probe[3] = last_begin - 1; probe[4] = last_begin;
+  }
   for (int q = 0; q < 6; q++) {
     programmable_bootstrap(one, tv, in[probe[q]], bk, 3, 0, 0);
     CHECK(same_tlwe(one, out[probe[q]]), "sample %d of the sharded batch differs from its single call on the primary device", probe[q]);
@@ -193,7 +198,7 @@ int main(int argc, char **argv) {
   wider_callers(lwe_key, n_dev);
   /* a key of the general-ring path (k = 2, N = 512: csrc/general_kernels.h) replicates and shards like the tuned ones */
   {
-    enum { gN = 512, gk = 2, gl = 2, gBg = 10, GC = 12 };
+    enum { gN = 512, gk = 2, gl = 2, gBg = 10, GC = 18 };
     TRLWE_Key grk = trlwe_new_binary_key(gN, gk, 2.989e-11);
     TRGSW_Key ggk = trgsw_new_key(grk, gl, gBg);
     TLWE_Key gex = tlwe_alloc_key(gk * gN, 2.989e-11);
