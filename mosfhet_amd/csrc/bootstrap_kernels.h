@@ -347,6 +347,9 @@ __device__ __forceinline__ void cmux_rows2(const typename Digits<L, BG>::word_t 
 // the transpose buffer that is 17 KiB of LDS per wavefront and <= 256 VGPRs, i.e. two wavefronts per SIMD /
 // eight per CU.  (Both components in LDS: 25 KiB -> 6 per CU, measured 22 % slower; both in registers spills.)
 // F = Fft1024: one wavefront per ciphertext; F = Fft2048: two wavefronts (128 threads) per ciphertext.
+#ifndef MOSFHET_PBS_PAIRS
+#define MOSFHET_PBS_PAIRS 1
+#endif
 template <class F, int L, int BG>
 __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
   constexpr int N = F::N, M = F::M, T = F::THREADS, LOG2N2 = F::LOGM + 2;
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
   const int Bg_bit = BG > 0 ? BG : p.Bg_bit;
 
   F fft;
-  fft.init(p.tw, t);
+  fft_setup(fft, p.tw, t);
 
   uint64_t al[8], ah[8];
   if (p.skip_init) {
@@ -415,7 +418,10 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
         typename Digits<L, BG>::word_t w_lo[8], w_hi[8];
         uint32_t ext[8];
         cmux_digits<F, L, BG>(w_lo, w_hi, ext, al, ah, q ? acc1 : nullptr, xch, a_lo, flip, off, t);
-        cmux_rows<F, L, BG>(w_lo, w_hi, ext, q, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
+        // rows two at a time where the transform keeps its pass twiddles in LDS: an A/B switch only (tools/ab/pbs_ab.hip with -DAB_LTW) -- at two wavefronts
+        // per SIMD the pairs gain nothing here (experiments/README.md round 4), production instantiates pbs_kernel on the register-twiddle transforms
+        if constexpr (F::kLtw && F::kForward2 && L % 2 == 0 && MOSFHET_PBS_PAIRS) cmux_rows2<F, L, BG>(w_lo, w_hi, ext, q, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
+        else cmux_rows<F, L, BG>(w_lo, w_hi, ext, q, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
       }
     }
     fft.inverse2(o_re[0], o_im[0], o_re[1], o_im[1], xch, t);

@@ -14,7 +14,11 @@ using namespace mosfhet;
 #if AB_N == 1024
 using ABF = Fft1024;
 #elif AB_N == 2048
+#ifdef AB_LTW
+using ABF = Fft2048L;          // pass twiddles in LDS; rows two at a time unless -DMOSFHET_PBS_PAIRS=0
+#else
 using ABF = Fft2048T<AB_WIDE>;
+#endif
 #else
 using ABF = Fft4096T<AB_WIDE>;
 #endif
