@@ -47,7 +47,38 @@ struct PbsParams {
   int count = 0;                     // host-side launch hint only (capi.hip: launch_pbs), not read by the kernels
   int rows = 1;                      // > 1: TRGSW accumulator (blind_rotate_trgsw, src/bootstrap.c:267-282): groups of `rows` consecutive
                                      // blocks share input ciphertext b / rows and start from test vector b % rows of one shared set
+  unsigned int *pace = nullptr;      // != nullptr: the teams of the launch re-align every `pace_every` CMUX steps (pace_teams(): a bounded wait on a device-wide
+  int pace_every = 0, pace_limit = 4000;   // counter, {arrivals, give-up flag}, zeroed by the launcher) so that they keep walking the bootstrap key TOGETHER when one
+                                     // step's rows are a sizeable part of an L2 (N >= 2048); purely a matter of timing -- results do not depend on it
 };
+
+// Re-alignment of the teams of one launch (all of them resident: the launcher sends one residency round per launch).  What has to stay together is
+// the set of teams that share an L2, so the rendezvous is per XCD: every team adds itself to the counter of the XCD it runs on (HW_REG_XCC_ID; one
+// 128-byte line per XCD, so that the eight counters do not queue behind each other at the memory side) and waits until all the teams dealt to that XCD
+// have arrived at rendezvous number `round` -- but never longer than `limit` timer ticks: a launch whose teams are NOT all resident (another stream's
+// kernel holds some CUs), or one that is not dealt round-robin over the XCDs (`mine` assumes blocks b and b + 8 share one), must not hang on it.  The
+// first team that times out raises the give-up flag and nobody waits again in this launch.  Memory order: relaxed device-scope atomics, nothing is
+// communicated but time.  Layout of `pace`: 8 counters at 32-word spacing, then the flag at word 256.
+__device__ __forceinline__ void pace_teams(unsigned int *pace, unsigned int round, int t, int limit) {
+  __syncthreads();
+  if (t == 0 && __hip_atomic_load(pace + 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+    unsigned int xcd;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcd));
+    unsigned int *cnt = pace + 32 * (xcd & 7u);
+    const unsigned int mine = (gridDim.x - (blockIdx.x & 7u) + 7u) / 8u;   // teams whose index is congruent to this one's mod 8
+    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned int want = round * mine;
+    const long long t0 = wall_clock64();                      // 100 MHz constant-rate timer
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+      if (wall_clock64() - t0 > limit) {
+        __hip_atomic_store(pace + 256, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(32);
+    }
+  }
+  __syncthreads();
+}
 
 // src/misc.c:18-22 with log_scale = log2(2N)
 template <int LOG2N>
@@ -401,6 +432,7 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
   const size_t row_sz = (size_t)2 * L * 2 * M;
 
   for (int i = 0; i < p.n; i++) {
+    if (T > 64 && p.pace && i > 0 && i % p.pace_every == 0) pace_teams(p.pace, (unsigned)(i / p.pace_every), t, p.pace_limit);   // (before the skip: every team counts every step)
     const int abar = (int)modswitch<LOG2N2>(pbs_pre(ct[i], p, LOG2N2));
     if (abar == 0) continue;  // src/bootstrap.c:114
     const d2 *__restrict__ bkrow = p.bk + (size_t)i * row_sz;
@@ -889,6 +921,7 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_ga_kernel(GaParams g) {
       ga_eval_automorphism<F, L, BG>(al, ah, acc1, xch, fft, g.ak + (size_t)((gen - 1) >> 1) * ak_sz, gen, off, Bg_bit, scale, t);
     }
     for (int i = 0; i < p.n; i++) {
+      if (T > 64 && p.pace && i > 0 && i % p.pace_every == 0) pace_teams(p.pace, (unsigned)(i / p.pace_every), t, p.pace_limit);
       // :46-58: acc = BK_i (.) acc ; gen = a_i * (a_{i+1})^-1 (last step: a_{n-1}) ; acc = Auto_gen(acc)
       int gen;
       if (i + 1 < p.n) {

@@ -481,13 +481,60 @@ static int round_chunk(int threads) {
   return threads == 128 ? 4 * cus : 0;   // N = 4096 (2 teams per CU) measured slower in rounds (tail idling): single launch
 }
 
+// Teams of one residency round re-align every K CMUX steps (pace_teams, bootstrap_kernels.h): kernel boundaries alone leave them drifting apart inside
+// a launch, and how far depends on what ran before (lvl2, 1024 per launch: 17.6 ms back to back but 19.5-20.3 ms after any other full-chip kernel, with
+// twice the fabric reads -- the state every composition runs in).  Re-aligned every 32 steps: 17.3 ms in both cases (tools/gpu_perf_modes3.py;
+// experiments/README.md "Round 4", pacing).  MOSFHET_HIP_PACE=K overrides (0 = off), MOSFHET_HIP_PACE_LIMIT the bounded wait in 10 ns ticks.
+static int pace_every() {
+  static std::atomic<int> v{-1};
+  int r = v.load(std::memory_order_relaxed);
+  if (r < 0) { const char *e = getenv("MOSFHET_HIP_PACE"); r = e ? atoi(e) : 32; if (r < 0) r = 0; v.store(r, std::memory_order_relaxed); }
+  return r;
+}
+static int pace_limit() {
+  static std::atomic<int> v{-1};
+  int r = v.load(std::memory_order_relaxed);
+  if (r < 0) { const char *e = getenv("MOSFHET_HIP_PACE_LIMIT"); r = e ? atoi(e) : 100000; if (r < 1) r = 1; v.store(r, std::memory_order_relaxed); }
+  return r;
+}
+constexpr int PACE_WORDS = 288;   // 8 per-XCD counters on 128-byte lines of their own + the give-up flag (word 256)
+static unsigned int *pace_slot(hipStream_t s) {
+  // a ring of 256 counter blocks per device (allocated on first use, kept for the life of the process), handed out round-robin to all host threads and
+  // zeroed on the launch stream in front of the launch that uses it.  A block comes round again 256 paced launches later; should the earlier launch
+  // still be running then, the two share a block and the rendezvous misfires -- a timing matter only (results never depend on it), ended by the
+  // bounded wait.
+  constexpr int MAX_DEV = 64, SLOTS = 256;
+  static std::mutex mu;
+  static std::atomic<unsigned int *> ring[MAX_DEV];
+  static std::atomic<unsigned> next[MAX_DEV];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+  unsigned int *mem = ring[dev].load(std::memory_order_acquire);
+  if (!mem) {
+    std::lock_guard<std::mutex> g(mu);
+    mem = ring[dev].load(std::memory_order_relaxed);
+    if (!mem) {
+      if (hipMalloc((void **)&mem, (size_t)SLOTS * PACE_WORDS * 4) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+      ring[dev].store(mem, std::memory_order_release);
+    }
+  }
+  unsigned int *slot = mem + (size_t)PACE_WORDS * (next[dev].fetch_add(1u, std::memory_order_relaxed) % SLOTS);
+  if (hipMemsetAsync(slot, 0, PACE_WORDS * 4, s) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return slot;
+}
+
 template <class F, int L, int BG>
-static void launch_pbs(const PbsParams &p, int count, hipStream_t s) {
+static void launch_pbs(const PbsParams &p_in, int count, hipStream_t s) {
+  PbsParams p = p_in;
   const int chunk = F::THREADS > 64 && p.rows == 1 && p.count < 0 ? round_chunk(F::THREADS) : 0;   // p.count < 0: key larger than the L2s
+  const bool pace = F::THREADS > 64 && pace_every() > 0 && chunk > 0 && count >= 64;   // (all teams of a launch of <= chunk are resident)
+  p.pace_every = pace ? pace_every() : 0;
+  p.pace_limit = pace_limit();
   if (chunk > 0 && count > chunk) {
     const size_t out_row = p.extract ? (size_t)F::N + 1 : (size_t)2 * F::N;
     for (int lo = 0; lo < count; lo += chunk) {
       PbsParams q = p;
+      q.pace = pace ? pace_slot(s) : nullptr;
       q.in = p.in + (size_t)lo * (p.n + 1);
       q.out = p.out + (size_t)lo * out_row;
       q.tv = p.tv ? p.tv + (size_t)lo * p.tv_stride : p.tv;
@@ -496,6 +543,7 @@ static void launch_pbs(const PbsParams &p, int count, hipStream_t s) {
     }
     return;
   }
+  p.pace = pace && count <= chunk ? pace_slot(s) : nullptr;
   hipLaunchKernelGGL((pbs_kernel<F, L, BG>), dim3((unsigned)count), dim3(F::THREADS), 0, s, p);
 }
 
@@ -901,7 +949,15 @@ extern "C" int mosfhet_hip_gak_destroy(mosfhet_hip_gak_t gak) {
 }
 
 template <class F, int L, int BG>
-static void launch_ga(const GaParams &g, int count, hipStream_t s) {
+static void launch_ga(const GaParams &g_in, int count, hipStream_t s) {
+  GaParams g = g_in;
+  // one residency round or less of N >= 2048 teams: re-aligned on the bootstrap key like launch_pbs's rounds
+  const int round = F::THREADS > 64 ? round_chunk(F::THREADS) : 0;
+  if (g.mode == 0 && round > 0 && count >= 64 && count <= round && pace_every() > 0) {
+    g.p.pace_every = pace_every();
+    g.p.pace_limit = pace_limit();
+    g.p.pace = pace_slot(s);
+  }
   hipLaunchKernelGGL((pbs_ga_kernel<F, L, BG>), dim3((unsigned)count), dim3(F::THREADS), 0, s, g);
 }
 

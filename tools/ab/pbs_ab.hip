@@ -46,10 +46,28 @@ extern "C" int ab_pbs(const double *d_bk, const double *d_tw, const uint64_t *d_
   p.prec_offset = (uint64_t)((int64_t)(18446744073709551616.0 * (1. / (4 * (double)(1 << (precision - 1))))));
   p.extract = 1;
   p.skip_init = 0;
+#ifdef AB_PACE
+  static unsigned int *d_pace = nullptr;
+  if (!d_pace && hipMalloc((void **)&d_pace, 288 * 4) != hipSuccess) return -4;   // pace_teams' block: 8 per-XCD counters + flag
+  p.pace = d_pace;
+  p.pace_every = AB_PACE;
+#endif
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1;
   hipEventRecord(e0, nullptr);
-  for (int r = 0; r < reps; r++) hipLaunchKernelGGL((pbs_kernel<ABF, AB_L, AB_BG>), dim3((unsigned)count), dim3(ABF::THREADS), 0, nullptr, p);
+#ifdef AB_DISTURB
+  static void *d_big = nullptr;   // a 256 MB fill in front of every launch: what a composition's other kernels do to the caches (experiments/README.md round 4)
+  if (!d_big && hipMalloc(&d_big, (size_t)256 << 20) != hipSuccess) return -5;
+#endif
+  for (int r = 0; r < reps; r++) {
+#ifdef AB_DISTURB
+    (void)hipMemsetAsync(d_big, r, (size_t)256 << 20, nullptr);
+#endif
+#ifdef AB_PACE
+    (void)hipMemsetAsync(d_pace, 0, 288 * 4, nullptr);
+#endif
+    hipLaunchKernelGGL((pbs_kernel<ABF, AB_L, AB_BG>), dim3((unsigned)count), dim3(ABF::THREADS), 0, nullptr, p);
+  }
   hipEventRecord(e1, nullptr);
   if (hipEventSynchronize(e1) != hipSuccess) return -2;
   float ms = 0.f;
