@@ -189,6 +189,11 @@ int mosfhet_hip_trlwe_packing1_keyswitch_batch(mosfhet_hip_ctx_t ctx, mosfhet_hi
 int mosfhet_hip_circuit_bootstrap_3_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, mosfhet_hip_gak_t kska, mosfhet_hip_ksk_t kskb,
                                           uint64_t *d_out /*[count][2l][2][N]*/, const uint64_t *d_in /*[count][n+1]*/, int count,
                                           void *stream);
+/* The same with progress events: level_done = l caller-created hipEvent_t (as void *, entries may be NULL) or NULL; level_done[i] is recorded on the
+ * launch stream when gadget level i is finished, i.e. rows i and l + i of EVERY output are final -- a host that wants the TRGSWs back can copy a level
+ * out (hipMemcpy2DAsync on a stream that waits for the event) while the next level's key switches run: 268 MB per 1024 outputs at lvl2. */
+int mosfhet_hip_circuit_bootstrap_3_batch_ev(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, mosfhet_hip_gak_t kska, mosfhet_hip_ksk_t kskb,
+                                             uint64_t *d_out, const uint64_t *d_in, int count, void *stream, void *const *level_done);
 
 /* ---- callers either side of the bootstrap ---- */
 /* public_mux over a batch (src/bootstrap.c:369-389): d_out[b] = (0, p0) + sum_i sel[b][i] * dec_i(p1 - p0); selector rows are
@@ -216,6 +221,9 @@ int mosfhet_hip_trlwe_priv_keyswitch_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_ks
  * key (priv_ksk_create, n = N), kskb = packing key. */
 int mosfhet_hip_circuit_bootstrap_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, mosfhet_hip_ksk_t kska, mosfhet_hip_ksk_t kskb,
                                         uint64_t *d_out /*[count][2l][2][N]*/, const uint64_t *d_in, int count, int variant, void *stream);
+int mosfhet_hip_circuit_bootstrap_batch_ev(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, mosfhet_hip_ksk_t kska, mosfhet_hip_ksk_t kskb,
+                                           uint64_t *d_out, const uint64_t *d_in, int count, int variant, void *stream,
+                                           void *const *level_done /* as in mosfhet_hip_circuit_bootstrap_3_batch_ev */);
 
 /* functional_bootstrap_trgsw_phase1 (src/bootstrap.c:284-295): blind rotation with a TRGSW accumulator; d_out_dft[b] = TRGSW_DFT(X^-phase)
  * as [2l][2][N/2] complex in the engine's slot order (the layout of one bootstrap-key entry).  phase2 (:297-306): d_out[b] =

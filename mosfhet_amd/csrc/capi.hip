@@ -1103,8 +1103,8 @@ __global__ void circuit_bootstrap_lut_kernel(uint64_t *__restrict__ tv, int N, i
   tv[N + i] = slot >= l ? (1ull << (64 - (slot - l + 1) * Bg_bit)) : 0;
 }
 
-extern "C" int mosfhet_hip_circuit_bootstrap_3_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, mosfhet_hip_gak_t kska, mosfhet_hip_ksk_t kskb,
-                                                     uint64_t *d_out, const uint64_t *d_in, int count, void *stream) {
+extern "C" int mosfhet_hip_circuit_bootstrap_3_batch_ev(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, mosfhet_hip_gak_t kska, mosfhet_hip_ksk_t kskb,
+                                                        uint64_t *d_out, const uint64_t *d_in, int count, void *stream, void *const *level_done) {
   TUNED_ONLY(bsk, "circuit_bootstrap_3");
   if (!ctx || !bsk || !kska || !kskb || (count > 0 && !d_out) || (count > 0 && !d_in) || count < 0) return fail(MOSFHET_HIP_EINVAL, "circuit_bootstrap_3: bad argument");
   const int N = bsk->N, l = bsk->l;
@@ -1128,9 +1128,15 @@ extern "C" int mosfhet_hip_circuit_bootstrap_3_batch(mosfhet_hip_ctx_t ctx, mosf
     uint64_t *row_b = d_out + (size_t)(l + i) * 2 * N, *row_a = d_out + (size_t)i * 2 * N;
     HIP_TRY(launch_tlwe_keyswitch(kskb->d_ksk, row_b, trgsw, ext, (size_t)N + 1, count, N, 2 * N, N, kskb->t, kskb->base_bit, tl_ws(ctx->device), s, kskb->compressed, kskb->seed));
     if ((rc = launch_fft_ks(ctx, kska, kska->d_ak, kska->d_ak + esz, row_a, trgsw, row_b, trgsw, count, 1, s))) return rc;
+    if (level_done && level_done[i]) HIP_TRY(hipEventRecord((hipEvent_t)level_done[i], s));   // rows i and l + i of every output are final
   }
   HIP_TRY(hipGetLastError());
   return MOSFHET_HIP_OK;
+}
+
+extern "C" int mosfhet_hip_circuit_bootstrap_3_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, mosfhet_hip_gak_t kska, mosfhet_hip_ksk_t kskb,
+                                                     uint64_t *d_out, const uint64_t *d_in, int count, void *stream) {
+  return mosfhet_hip_circuit_bootstrap_3_batch_ev(ctx, bsk, kska, kskb, d_out, d_in, count, stream, nullptr);
 }
 
 // ---- timing hook ----

@@ -18,6 +18,7 @@ extern int hipHostMalloc(void **ptr, size_t size, unsigned int flags);
 extern int hipStreamCreate(void **stream);
 extern int hipStreamSynchronize(void *stream);
 extern int hipMemcpyAsync(void *dst, const void *src, size_t size, int kind, void *stream);
+extern int hipMemcpy2DAsync(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, int kind, void *stream);
 extern int hipHostFree(void *ptr);
 extern int hipEventCreateWithFlags(void **event, unsigned flags);
 extern int hipEventRecord(void *event, void *stream);

@@ -1488,39 +1488,60 @@ void trlwe_packing1_keyswitch(TRLWE out, TLWE in, Generic_KS_Key ks) {
 }
 
 /* TRGSW outputs of a circuit-bootstrap batch: [count][2l][2][N] flat -> the structs' 2l (k + 1) separately allocated polynomials, over the helper threads
- * (256 KiB per output at lvl2: 268 MB per 1024 -- serial, that copy took as long as the kernels) */
-typedef struct { TRGSW *out; const Torus *flat; int rows; size_t row; } TrgswSpan;
-static void trgsw_from_flat_range(void *pv, int lo, int hi) {
-  const TrgswSpan *a = (const TrgswSpan *)pv;
-  for (int b = lo; b < hi; b++)
-    for (int q = 0; q < a->rows; q++) mc_trlwe_from_flat(a->out[b]->samples[q], a->flat + ((size_t)b * a->rows + q) * a->row);
+ * (256 KiB per output at lvl2: 268 MB per 1024 -- serial, that copy took as long as the kernels), level by level while the kernels still run.  A circuit bootstrap finishes gadget level i -- rows i and l + i of EVERY output -- long before level i + 1
+ * (a packing key switch of the whole batch lies between them), and the C ABI records an event per level (mosfhet_hip_circuit_bootstrap_*_batch_ev).  The copy
+ * stream waits for it and brings the two row sets back as strided copies (width one row, pitch one TRGSW), in pieces of PIECE outputs with an event each; the
+ * host unpacks a piece while the next one lands.  Only the last level's copy is left behind the kernels (64 of 268 MB per 1024 outputs at lvl2). */
+typedef struct { TRGSW *out; const Torus *flat; int rows, q0, q1; size_t row; } TrgswRows;
+static void trgsw_rows_from_flat_range(void *pv, int lo, int hi) {
+  const TrgswRows *a = (const TrgswRows *)pv;
+  for (int b = lo; b < hi; b++) {
+    mc_trlwe_from_flat(a->out[b]->samples[a->q0], a->flat + ((size_t)b * a->rows + a->q0) * a->row);
+    mc_trlwe_from_flat(a->out[b]->samples[a->q1], a->flat + ((size_t)b * a->rows + a->q1) * a->row);
+  }
 }
-static void trgsw_array_from_flat(TRGSW *out, const Torus *flat, int count, int rows, size_t row) {
-  TrgswSpan a = {out, flat, rows, row};
-  mc_parallel_for(trgsw_from_flat_range, &a, count, 1);
-}
-/* ... straight from the device: the batch comes back in pieces of 64 outputs (16.8 MB at lvl2), an event behind each, and a piece is unpacked while the next
- * one lands (the kernels have finished: the caller synchronised) */
-static void trgsw_array_download(TRGSW *out, Torus *h_flat, const Torus *d_flat, int count, int rows, size_t row) {
-  enum { PIECE = 64 };
-  const size_t item = (size_t)rows * row;
-  const int n_pieces = (count + PIECE - 1) / PIECE;
+typedef struct { void **level, **piece; int l, n_pieces; } LevelEvents;
+enum { LEVEL_PIECE = 256 };
+static LevelEvents level_events_new(int l, int count) {
+  LevelEvents e;
+  e.l = l;
+  e.n_pieces = (count + LEVEL_PIECE - 1) / LEVEL_PIECE;
   mc_use_device();
+  e.level = (void **)mc_xmalloc(sizeof(void *) * (size_t)l);
+  e.piece = (void **)mc_xmalloc(sizeof(void *) * (size_t)l * (size_t)(e.n_pieces ? e.n_pieces : 1));
+  for (int i = 0; i < l; i++)
+    if (hipEventCreateWithFlags(&e.level[i], HIP_EVENT_DISABLE_TIMING)) mc_die("circuit bootstrap (event)");
+  for (int i = 0; i < l * e.n_pieces; i++)
+    if (hipEventCreateWithFlags(&e.piece[i], HIP_EVENT_DISABLE_TIMING)) mc_die("circuit bootstrap (event)");
+  return e;
+}
+static void trgsw_levels_download(TRGSW *out, Torus *h_flat, const Torus *d_flat, int count, int l, size_t row, LevelEvents *e) {
+  const int rows = 2 * l;
+  const size_t item = (size_t)rows * row, pitch = sizeof(Torus) * item, width = sizeof(Torus) * row;
   if (!g_pipe_streams[0] && hipStreamCreate(&g_pipe_streams[0])) mc_die("circuit bootstrap (stream)");
-  void **ev = (void **)mc_xmalloc(sizeof(void *) * (size_t)(n_pieces ? n_pieces : 1));
-  for (int p = 0; p < n_pieces; p++) {
-    const int lo = p * PIECE, cnt = count - lo < PIECE ? count - lo : PIECE;
-    if (hipMemcpyAsync(h_flat + (size_t)lo * item, d_flat + (size_t)lo * item, sizeof(Torus) * (size_t)cnt * item, HIP_D2H, g_pipe_streams[0]) ||
-        hipEventCreateWithFlags(&ev[p], HIP_EVENT_DISABLE_TIMING) || hipEventRecord(ev[p], g_pipe_streams[0]))
-      mc_die("circuit bootstrap (copy out)");
+  void *cs = g_pipe_streams[0];
+  for (int i = 0; i < l; i++) {
+    if (hipStreamWaitEvent(cs, e->level[i], 0)) mc_die("circuit bootstrap (copy out)");
+    for (int p = 0; p < e->n_pieces; p++) {
+      const int lo = p * LEVEL_PIECE, cnt = count - lo < LEVEL_PIECE ? count - lo : LEVEL_PIECE;
+      const size_t at = (size_t)lo * item;
+      if (hipMemcpy2DAsync(h_flat + at + (size_t)i * row, pitch, d_flat + at + (size_t)i * row, pitch, width, (size_t)cnt, HIP_D2H, cs) ||
+          hipMemcpy2DAsync(h_flat + at + (size_t)(l + i) * row, pitch, d_flat + at + (size_t)(l + i) * row, pitch, width, (size_t)cnt, HIP_D2H, cs) ||
+          hipEventRecord(e->piece[i * e->n_pieces + p], cs))
+        mc_die("circuit bootstrap (copy out)");
+    }
   }
-  for (int p = 0; p < n_pieces; p++) {
-    const int lo = p * PIECE, cnt = count - lo < PIECE ? count - lo : PIECE;
-    if (hipEventSynchronize(ev[p])) mc_die("circuit bootstrap (copy out)");
-    trgsw_array_from_flat(out + lo, h_flat + (size_t)lo * item, cnt, rows, row);
-    hipEventDestroy(ev[p]);
-  }
-  free(ev);
+  for (int i = 0; i < l; i++)
+    for (int p = 0; p < e->n_pieces; p++) {
+      const int lo = p * LEVEL_PIECE, cnt = count - lo < LEVEL_PIECE ? count - lo : LEVEL_PIECE;
+      if (hipEventSynchronize(e->piece[i * e->n_pieces + p])) mc_die("circuit bootstrap (copy out)");
+      TrgswRows a = {out + lo, h_flat + (size_t)lo * item, rows, i, l + i, row};
+      mc_parallel_for(trgsw_rows_from_flat_range, &a, cnt, 1);
+    }
+  for (int i = 0; i < l; i++) hipEventDestroy(e->level[i]);
+  for (int i = 0; i < l * e->n_pieces; i++) hipEventDestroy(e->piece[i]);
+  free(e->level);
+  free(e->piece);
 }
 
 typedef struct { TRGSW *out; TLWE *in; Bootstrap_Key key; TRLWE_KS_Key *kska; Generic_KS_Key kskb; } Cb3Slice;
@@ -1544,11 +1565,12 @@ void circuit_bootstrap_3_batch(TRGSW *out, TLWE *in, int count, Bootstrap_Key ke
   tlwe_array_to_flat(h, in, count, n);
   Torus *d = (Torus *)mc_stage_alloc(sizeof(Torus) * (in_w + out_w));
   mc_dev_copy(d, h, sizeof(Torus) * in_w, HIP_H2D);
-  if (mosfhet_hip_circuit_bootstrap_3_batch(ctx, (mosfhet_hip_bsk_t)mc_key_here(key->device, MC_KEY_BSK), (mosfhet_hip_gak_t)mc_key_here(kska[0]->device, MC_KEY_GAK),
-                                            (mosfhet_hip_ksk_t)mc_key_here(kskb->device, MC_KEY_KSK), d + in_w, d, count, NULL) ||
-      mosfhet_hip_ctx_sync(ctx, NULL))
+  LevelEvents ev = level_events_new(l, count);
+  if (mosfhet_hip_circuit_bootstrap_3_batch_ev(ctx, (mosfhet_hip_bsk_t)mc_key_here(key->device, MC_KEY_BSK), (mosfhet_hip_gak_t)mc_key_here(kska[0]->device, MC_KEY_GAK),
+                                               (mosfhet_hip_ksk_t)mc_key_here(kskb->device, MC_KEY_KSK), d + in_w, d, count, NULL, ev.level))
     mc_die("circuit_bootstrap_3");
-  trgsw_array_download(out, h + in_w, d + in_w, count, 2 * l, row);
+  trgsw_levels_download(out, h + in_w, d + in_w, count, l, row, &ev);
+  if (mosfhet_hip_ctx_sync(ctx, NULL)) mc_die("circuit_bootstrap_3");
   stage_free(d);
   mc_hstage_free(h);
 }
@@ -1624,9 +1646,12 @@ static void circuit_bootstrap_many(TRGSW *out, TLWE *in, int count, Bootstrap_Ke
   Buf b = buf_new(in_w + out_w);
   tlwe_array_to_flat(b.h, in, count, n);
   buf_up(&b, 0, in_w);
-  check_rc(mosfhet_hip_circuit_bootstrap_batch(ectx(), (mosfhet_hip_bsk_t)mc_key_here(key->device, MC_KEY_BSK), (mosfhet_hip_ksk_t)mc_key_here(kska->device, MC_KEY_KSK),
-                                               (mosfhet_hip_ksk_t)mc_key_here(kskb->device, MC_KEY_KSK), b.d + in_w, b.d, count, variant, NULL), "circuit_bootstrap");
-  trgsw_array_download(out, b.h + in_w, b.d + in_w, count, 2 * l, row);
+  LevelEvents ev = level_events_new(l, count);
+  if (mosfhet_hip_circuit_bootstrap_batch_ev(ectx(), (mosfhet_hip_bsk_t)mc_key_here(key->device, MC_KEY_BSK), (mosfhet_hip_ksk_t)mc_key_here(kska->device, MC_KEY_KSK),
+                                             (mosfhet_hip_ksk_t)mc_key_here(kskb->device, MC_KEY_KSK), b.d + in_w, b.d, count, variant, NULL, ev.level))
+    mc_die("circuit_bootstrap");
+  trgsw_levels_download(out, b.h + in_w, b.d + in_w, count, l, row, &ev);
+  check_rc(0, "circuit_bootstrap");
   buf_free(&b);
 }
 
