@@ -16,6 +16,8 @@ extern int hipMemcpy(void *dst, const void *src, size_t size, int kind);
 extern int hipMemset(void *dst, int value, size_t size);
 extern int hipHostMalloc(void **ptr, size_t size, unsigned int flags);
 extern int hipStreamCreate(void **stream);
+extern int hipStreamCreateWithFlags(void **stream, unsigned int flags);
+#define HIP_STREAM_NON_BLOCKING 1u
 extern int hipStreamSynchronize(void *stream);
 extern int hipMemcpyAsync(void *dst, const void *src, size_t size, int kind, void *stream);
 extern int hipMemcpy2DAsync(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, int kind, void *stream);

@@ -1031,6 +1031,45 @@ void full_domain_functional_bootstrap(TLWE out, TRLWE tv, TLWE in, Bootstrap_Key
   full_domain_functional_bootstrap_batch(&out, tv, &in, 1, key, ksk, precision);
 }
 
+/* The copy-out stream of the batch wrappers, one per host thread: NON-BLOCKING -- the launches sit on the default stream, and an ordinary stream's copies
+ * queue up behind ALL of them (measured on circuit bootstraps: the first piece landed when the last kernel had finished); this one is ordered by events alone. */
+static void *mc_copy_stream(void) {
+  static __thread void *st;
+  mc_use_device();
+  if (!st && hipStreamCreateWithFlags(&st, HIP_STREAM_NON_BLOCKING)) mc_die("copy stream");
+  return st;
+}
+
+/* A large batch of TLWE results (the kernels have finished: the caller synchronised): back in pieces with an event behind each, a piece unpacked into the
+ * structs while the next one lands (8192 outputs of 16 KB for 1024 multi-value bootstraps at lvl2: 134 MB). */
+static void tlwe_array_download(TLWE *out, Torus *h_flat, const Torus *d_flat, int count, int n_out) {
+  static int piece_env = -1;   /* MOSFHET_COMPAT_TLWE_PIECE: outputs per piece (0 = one copy, then unpack) */
+  if (piece_env < 0) { const char *e = getenv("MOSFHET_COMPAT_TLWE_PIECE"); piece_env = e ? atoi(e) : 1024; if (piece_env < 0) piece_env = 0; }
+  const int PIECE = piece_env;
+  const size_t item = (size_t)n_out + 1;
+  if (PIECE == 0 || count <= PIECE) {
+    mc_dev_copy(h_flat, d_flat, sizeof(Torus) * (size_t)count * item, HIP_D2H);
+    tlwe_array_from_flat(out, h_flat, count, n_out);
+    return;
+  }
+  const int n_pieces = (count + PIECE - 1) / PIECE;
+  void *cs = mc_copy_stream();
+  void **ev = (void **)mc_xmalloc(sizeof(void *) * (size_t)n_pieces);
+  for (int p = 0; p < n_pieces; p++) {
+    const int lo = p * PIECE, cnt = count - lo < PIECE ? count - lo : PIECE;
+    if (hipMemcpyAsync(h_flat + (size_t)lo * item, d_flat + (size_t)lo * item, sizeof(Torus) * (size_t)cnt * item, HIP_D2H, cs) ||
+        hipEventCreateWithFlags(&ev[p], HIP_EVENT_DISABLE_TIMING) || hipEventRecord(ev[p], cs))
+      mc_die("copy out");
+  }
+  for (int p = 0; p < n_pieces; p++) {
+    const int lo = p * PIECE, cnt = count - lo < PIECE ? count - lo : PIECE;
+    if (hipEventSynchronize(ev[p])) mc_die("copy out");
+    tlwe_array_from_flat(out + lo, h_flat + (size_t)lo * item, cnt, n_out);
+    hipEventDestroy(ev[p]);
+  }
+  free(ev);
+}
+
 /* Every sharded entry point below follows bootstrap_many: with several devices in use (and not already inside a slice) the batch is cut by
  * mc_run_sharded into one contiguous slice per device, each slice re-enters the same function on its device's host thread, and every key handle is
  * looked up with mc_key_here (the replica on the calling thread's device).  SURVEY 8(e); src/bootstrap.c:222-230,346-366,391-517, src/bootstrap_ga.c:62-76
@@ -1062,8 +1101,7 @@ void multivalue_bootstrap_CLOT21_batch(TLWE *out, TRLWE tv, TLWE *in, int count,
                                                     count, torus_base, n_luts, NULL) ||
       mosfhet_hip_ctx_sync(ctx, NULL))
     mc_die("multivalue_bootstrap_CLOT21");
-  mc_dev_copy(h + in_w + tv_w, d + in_w + tv_w, sizeof(Torus) * out_w, HIP_D2H);
-  tlwe_array_from_flat(out, h + in_w + tv_w, count * n_luts, k * N);
+  tlwe_array_download(out, h + in_w + tv_w, d + in_w + tv_w, count * n_luts, k * N);
   stage_free(d);
   mc_hstage_free(h);
 }
@@ -1515,11 +1553,17 @@ static LevelEvents level_events_new(int l, int count) {
     if (hipEventCreateWithFlags(&e.piece[i], HIP_EVENT_DISABLE_TIMING)) mc_die("circuit bootstrap (event)");
   return e;
 }
+static double timeline_ms(void) {
+  struct timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return (double)t.tv_sec * 1e3 + (double)t.tv_nsec * 1e-6;
+}
 static void trgsw_levels_download(TRGSW *out, Torus *h_flat, const Torus *d_flat, int count, int l, size_t row, LevelEvents *e) {
   const int rows = 2 * l;
+  const int timeline = getenv("MOSFHET_COMPAT_TIMELINE") != NULL;   /* debugging aid: when each piece landed and was unpacked, on stderr */
+  const double t0 = timeline ? timeline_ms() : 0.0;
   const size_t item = (size_t)rows * row, pitch = sizeof(Torus) * item, width = sizeof(Torus) * row;
-  if (!g_pipe_streams[0] && hipStreamCreate(&g_pipe_streams[0])) mc_die("circuit bootstrap (stream)");
-  void *cs = g_pipe_streams[0];
+  void *cs = mc_copy_stream();
   for (int i = 0; i < l; i++) {
     if (hipStreamWaitEvent(cs, e->level[i], 0)) mc_die("circuit bootstrap (copy out)");
     for (int p = 0; p < e->n_pieces; p++) {
@@ -1535,8 +1579,10 @@ static void trgsw_levels_download(TRGSW *out, Torus *h_flat, const Torus *d_flat
     for (int p = 0; p < e->n_pieces; p++) {
       const int lo = p * LEVEL_PIECE, cnt = count - lo < LEVEL_PIECE ? count - lo : LEVEL_PIECE;
       if (hipEventSynchronize(e->piece[i * e->n_pieces + p])) mc_die("circuit bootstrap (copy out)");
+      const double t1 = timeline ? timeline_ms() : 0.0;
       TrgswRows a = {out + lo, h_flat + (size_t)lo * item, rows, i, l + i, row};
       mc_parallel_for(trgsw_rows_from_flat_range, &a, cnt, 1);
+      if (timeline) fprintf(stderr, "[timeline] level %d piece %d: landed at %.2f ms, unpacked at %.2f ms after the launches were queued\n", i, p, t1 - t0, timeline_ms() - t0);
     }
   for (int i = 0; i < l; i++) hipEventDestroy(e->level[i]);
   for (int i = 0; i < l * e->n_pieces; i++) hipEventDestroy(e->piece[i]);
