@@ -435,7 +435,11 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
     if (T > 64 && p.pace && i > 0 && i % p.pace_every == 0) pace_teams(p.pace, (unsigned)(i / p.pace_every), t, p.pace_limit);   // (before the skip: every team counts every step)
     const int abar = (int)modswitch<LOG2N2>(pbs_pre(ct[i], p, LOG2N2));
     if (abar == 0) continue;  // src/bootstrap.c:114
+#ifdef MOSFHET_AB_KEYWRAP   // A/B only (tools/ab): walk the first MOSFHET_AB_KEYWRAP entries over and over -- every key request an L2 hit (results are wrong; timing only)
+    const d2 *__restrict__ bkrow = p.bk + (size_t)(i % MOSFHET_AB_KEYWRAP) * row_sz;
+#else
     const d2 *__restrict__ bkrow = p.bk + (size_t)i * row_sz;
+#endif
     const int a_lo = abar & (N - 1);
     const bool flip = (abar & N) != 0;
     double o_re[2][8], o_im[2][8];
