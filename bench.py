@@ -18,6 +18,8 @@ Prints ONE JSON line (rank 0) with the contract fields plus
                  key entry, 32 KiB of ciphertext I/O per unit) against HBM bandwidth, timed live the same way; a sample of its outputs is checked
                  by phase (BK_i = TRGSW(s_i): phase(BK_i (.) c) = s_i phase(c), within the reference's 2^54);
   roofline_external_product_lvl2 : the same at N = 2048, l = 4 (64 KiB per unit, 256 KiB key entry);
+  lvl2_bootstraps : BASELINE.json configs[2] for the record (4096 programmable bootstraps at N = 2048, l = 4 on this GPU: rate, FP64-model fraction,
+                 outputs checked by phase); not part of `value`;
   value_regime : how `value` was launched (steps alternate over --streams HIP streams) next to roofline.kernel_ms (the launch alone, timed right
                  after the timed region) and roofline.kernel_ms_in_stream_regime (an event pair around every launch of the same alternating schedule);
   sustained    : the same step back to back for >= 2.5 s (N = 1);
@@ -55,6 +57,32 @@ def flops_per_cmux(P):
     M = N // 2
     fft = 5 * M * (M.bit_length() - 1)
     return ((k + 1) * l + (k + 1)) * fft + 8 * (k + 1) ** 2 * l * M
+
+
+def lvl2_bootstrap_leg(eng, ma, host, torch, B2=4096):
+    """BASELINE.json configs[2] beside the headline: B2 programmable bootstraps at the TFHEpp lvl2 set (N = 2048, l = 4, n = 632) on this GPU, key generated on
+    the device, launches timed with events on the launch stream (one launch per residency round of 1024, the teams of a round re-aligned per XCD: DESIGN.md 4.1);
+    every output checked by PHASE against its LUT slot (the reference's criterion, test/tests.c:1560 -- no oracle on the measured path)."""
+    P2 = dict(ma.PARAMS_LVL2)
+    host.seed(SEED + 2)
+    lk2 = host.LweKey(P2["n"], P2["lwe_sigma"])
+    rk2 = host.RlweKey(P2["N"], 1, P2["rlwe_sigma"])
+    bsk2 = eng.generate_bootstrap_key(rk2.s[0], lk2.s, P2["l"], P2["Bg_bit"], P2["rlwe_sigma"], seed=SEED)
+    lut = np.array([1 << 60, 5 << 60, 9 << 60, 13 << 60], dtype=np.uint64)
+    d_tv2 = ma.to_device(host.torus_packing(lut, 1, P2["N"])[None], eng.device)
+    d_ct2 = ma.to_device(host.tlwe_samples([host.double2torus((b % 4) / 8.0) for b in range(B2)], lk2), eng.device)
+    out2 = eng.programmable_bootstrap(bsk2, d_tv2, d_ct2, 3)
+    torch.cuda.synchronize()
+    ph = host.tlwe_phase(ma.to_numpy(out2), rk2.extracted_lwe_key().s)
+    err = np.abs((ph - lut[np.arange(B2) % 4]).astype(np.int64).astype(np.float64)).max()
+    ms = min(eng.time_programmable_bootstrap(bsk2, d_tv2, d_ct2, 3, 3, out=out2) for _ in range(3))
+    tflops = flops_per_cmux(P2) * P2["n"] * B2 / (ms * 1e-3) / 1e12
+    res = {"workload": "batch of %d programmable bootstraps, TFHEpp lvl2 n=632 N=2048 k=1 l=4 Bg=2^9 (BASELINE.json configs[2])" % B2,
+           "bootstraps_per_s": B2 / (ms * 1e-3), "ms_per_batch": ms, "kernel": "mosfhet::pbs_kernel<mosfhet::Fft2048T<false, false>, 4, 9>",
+           "launches_per_batch": (B2 + 1023) // 1024, "bound": "fp64_valu", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, "max_phase_error_log2": float(np.log2(err + 1)), "decrypts": bool(err < 2.0 ** 58)}
+    bsk2.free()
+    return res
 
 
 def ffnt_single_ms(P, bk, tv, ct):
@@ -196,6 +224,7 @@ def main():
     ap.add_argument("--ep-batch", type=int, default=65536, help="TRLWE samples of the external-product roofline line")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-lvl2", action="store_true", help="skip the configs[2] leg (4096 lvl2 bootstraps, ~2 s)")
     args = ap.parse_args()
 
     import torch
@@ -370,6 +399,8 @@ def main():
         ep2 = external_product_leg(eng, ma, host, dict(ma.PARAMS_LVL2), max(64, args.ep_batch // 4), measured_traffic, "latest_traffic_ep_lvl2.json",
                                    "mosfhet::external_product_kernel<mosfhet::Fft2048T<false, true>, 4, 9, false>", torch)
 
+    lvl2 = lvl2_bootstrap_leg(eng, ma, host, torch) if rank == 0 and not args.no_lvl2 else None
+
     # one bootstrap alone (the latency kernel: one workgroup of 2l wavefronts for the ciphertext), same key, same timing method as roofline.kernel_ms
     latency_ms = eng.time_programmable_bootstrap(bsk, d_tv, d_ct[:1], 3, 5, out=d_out[:1]) if rank == 0 else None
 
@@ -420,6 +451,7 @@ def main():
                                                      "key is shared by the batch through L2 (see `traffic` for measured memory-side bytes)"}},
             "roofline_external_product": ep,
             "roofline_external_product_lvl2": ep2,
+            "lvl2_bootstraps": lvl2,
             "sustained": sustained,
             "single_bootstrap_ms": latency_ms,
             "replicas": replicas,

@@ -234,11 +234,26 @@ class Engine:
         _check(lib().mosfhet_hip_trlwe_packing1_keyswitch_batch(self.h, ksk.h, _ptr(out), _ptr(ct), count, self._stream()))
         return out
 
-    def circuit_bootstrap_3(self, bsk, kska, kskb, ct, out=None):
+    @staticmethod
+    def _level_events(level_events, l):
+        """l torch.cuda.Event objects (or None entries) -> the void*[l] the *_batch_ev entry points take; an event is recorded when its gadget level is final"""
+        if level_events is None:
+            return None
+        if len(level_events) != l:
+            raise MosfhetHipError("level_events: %d events for %d gadget levels" % (len(level_events), l))
+        arr = (C.c_void_p * l)()
+        for i, e in enumerate(level_events):
+            if e is not None:
+                e.record()   # (a torch event has no handle before its first record; the engine records it again where it belongs)
+                arr[i] = e.cuda_event
+        return arr
+
+    def circuit_bootstrap_3(self, bsk, kska, kskb, ct, out=None, level_events=None):
         count = ct.shape[0]
         if out is None:
             out = self.empty(count, 2 * bsk.l, 2, bsk.N)
-        _check(lib().mosfhet_hip_circuit_bootstrap_3_batch(self.h, bsk.h, kska.h, kskb.h, _ptr(out), _ptr(ct), count, self._stream()))
+        ev = self._level_events(level_events, bsk.l)
+        _check(lib().mosfhet_hip_circuit_bootstrap_3_batch_ev(self.h, bsk.h, kska.h, kskb.h, _ptr(out), _ptr(ct), count, self._stream(), ev))
         return out
 
     def public_mux(self, p0, p1, sel, Bg_bit, out=None):
@@ -288,11 +303,12 @@ class Engine:
         _check(lib().mosfhet_hip_trlwe_priv_keyswitch_batch(self.h, ksk.h, _ptr(out), _ptr(ct), count, self._stream()))
         return out
 
-    def circuit_bootstrap(self, bsk, kska, kskb, ct, variant=0, out=None):
+    def circuit_bootstrap(self, bsk, kska, kskb, ct, variant=0, out=None, level_events=None):
         count = ct.shape[0]
         if out is None:
             out = self.empty(count, 2 * bsk.l, 2, bsk.N)
-        _check(lib().mosfhet_hip_circuit_bootstrap_batch(self.h, bsk.h, kska.h, kskb.h, _ptr(out), _ptr(ct), count, variant, self._stream()))
+        ev = self._level_events(level_events, bsk.l)
+        _check(lib().mosfhet_hip_circuit_bootstrap_batch_ev(self.h, bsk.h, kska.h, kskb.h, _ptr(out), _ptr(ct), count, variant, self._stream(), ev))
         return out
 
     def functional_bootstrap_trgsw_phase1(self, bsk, ct, torus_base, out=None):
