@@ -207,6 +207,8 @@ extern "C" int mosfhet_hip_twiddles(int N, double *h_out) {
   return MOSFHET_HIP_OK;
 }
 
+static unsigned int *pace_ring(int dev, bool may_allocate);   // counters of the N = 2048 rendezvous (launch_pbs)
+
 extern "C" int mosfhet_hip_ctx_create(mosfhet_hip_ctx_t *out, int device) {
   if (!out) return fail(MOSFHET_HIP_EINVAL, "ctx_create: null out");
   int ndev = 0;
@@ -239,6 +241,7 @@ extern "C" int mosfhet_hip_ctx_create(mosfhet_hip_ctx_t *out, int device) {
     HIP_TRY(hipMalloc((void **)&wd, w.size() * sizeof(double)));
     HIP_TRY(hipMemcpy(wd, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));
   }
+  (void)pace_ring(device, true);
   *out = c.release();
   return MOSFHET_HIP_OK;
 }
@@ -498,27 +501,32 @@ static int pace_limit() {
   return r;
 }
 constexpr int PACE_WORDS = 288;   // 8 per-XCD counters on 128-byte lines of their own + the give-up flag (word 256)
-static unsigned int *pace_slot(hipStream_t s) {
-  // a ring of 256 counter blocks per device (allocated on first use, kept for the life of the process), handed out round-robin to all host threads and
-  // zeroed on the launch stream in front of the launch that uses it.  A block comes round again 256 paced launches later; should the earlier launch
-  // still be running then, the two share a block and the rendezvous misfires -- a timing matter only (results never depend on it), ended by the
-  // bounded wait.
-  constexpr int MAX_DEV = 64, SLOTS = 256;
+// a ring of 256 counter blocks per device (allocated when the first context on the device is made -- not lazily at a launch, which could sit inside a stream
+// capture -- and kept for the life of the process), handed out round-robin to all host threads and zeroed on the launch stream in front of the launch that uses it.
+// A block comes round again 256 paced launches later; should the earlier launch still be running then, the two share a block and the rendezvous misfires -- a
+// timing matter only (results never depend on it), ended by the bounded wait.
+constexpr int PACE_MAX_DEV = 64, PACE_SLOTS = 256;
+static std::atomic<unsigned int *> g_pace_ring[PACE_MAX_DEV];
+static std::atomic<unsigned> g_pace_next[PACE_MAX_DEV];
+static unsigned int *pace_ring(int dev, bool may_allocate) {
   static std::mutex mu;
-  static std::atomic<unsigned int *> ring[MAX_DEV];
-  static std::atomic<unsigned> next[MAX_DEV];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
-  unsigned int *mem = ring[dev].load(std::memory_order_acquire);
+  if (dev < 0 || dev >= PACE_MAX_DEV) return nullptr;
+  unsigned int *mem = g_pace_ring[dev].load(std::memory_order_acquire);
+  if (mem || !may_allocate) return mem;
+  std::lock_guard<std::mutex> g(mu);
+  mem = g_pace_ring[dev].load(std::memory_order_relaxed);
   if (!mem) {
-    std::lock_guard<std::mutex> g(mu);
-    mem = ring[dev].load(std::memory_order_relaxed);
-    if (!mem) {
-      if (hipMalloc((void **)&mem, (size_t)SLOTS * PACE_WORDS * 4) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-      ring[dev].store(mem, std::memory_order_release);
-    }
+    if (hipMalloc((void **)&mem, (size_t)PACE_SLOTS * PACE_WORDS * 4) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    g_pace_ring[dev].store(mem, std::memory_order_release);
   }
-  unsigned int *slot = mem + (size_t)PACE_WORDS * (next[dev].fetch_add(1u, std::memory_order_relaxed) % SLOTS);
+  return mem;
+}
+static unsigned int *pace_slot(hipStream_t s) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  unsigned int *mem = pace_ring(dev, false);   // no ring (allocation failed at context creation): the launch runs unpaced
+  if (!mem) return nullptr;
+  unsigned int *slot = mem + (size_t)PACE_WORDS * (g_pace_next[dev].fetch_add(1u, std::memory_order_relaxed) % PACE_SLOTS);
   if (hipMemsetAsync(slot, 0, PACE_WORDS * 4, s) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   return slot;
 }
