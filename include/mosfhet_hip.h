@@ -135,6 +135,9 @@ int mosfhet_hip_tlwe_keyswitch_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t ks
 /* trlwe_extract_tlwe at coefficient idx over a batch (src/trlwe.c:540-552), k = 1. */
 int mosfhet_hip_trlwe_extract_tlwe_batch(mosfhet_hip_ctx_t ctx, uint64_t *d_out /*[count][N+1]*/, const uint64_t *d_in /*[count][2][N]*/,
                                          int N, int idx, int count, void *stream);
+/* ... for any k >= 1 (the loop over the k mask polynomials of src/trlwe.c:540-552) */
+int mosfhet_hip_trlwe_extract_tlwe_k_batch(mosfhet_hip_ctx_t ctx, uint64_t *d_out /*[count][kN+1]*/, const uint64_t *d_in /*[count][k+1][N]*/,
+                                           int k, int N, int idx, int count, void *stream);
 /* tlwe_addto over a batch (src/tlwe.c:170-173): d_out[b] += d_in[b], samples of n+1 words. */
 int mosfhet_hip_tlwe_addto_batch(mosfhet_hip_ctx_t ctx, uint64_t *d_out, const uint64_t *d_in, int n, int count, void *stream);
 

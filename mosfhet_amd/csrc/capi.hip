@@ -323,7 +323,7 @@ static int general_lds(K kernel, int N) {
   do {                                                                                                                                               \
     if ((bsk_) && (bsk_)->general)                                                                                                                   \
       return fail(MOSFHET_HIP_EINVAL, "%s: keys of the general-ring path (k > 1 or N outside 1024 / 2048 / 4096) serve bootstraps, the full-domain " \
-                                      "bootstrap, key-switch + bootstrap and external products only", who_);                                         \
+                                      "bootstrap, multi-value bootstraps (CLOT21), key-switch + bootstrap, external products and CMUX only", who_);                                         \
   } while (0)
 
 // ---- bootstrap key ----
@@ -736,6 +736,22 @@ extern "C" int mosfhet_hip_blind_rotate_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip
   return bootstrap_common("blind_rotate", ctx, bsk, d_acc, nullptr, 0, d_in, count, 0, 0, 0, 1, 0, 1, stream);
 }
 
+// external product / CMUX of the general-ring path (general_kernels.h): one workgroup per unit, products in the calling thread's pool
+static int external_product_general(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, int key_index, uint64_t *d_out, const uint64_t *d_in, const uint64_t *d_in0,
+                                    int count, void *stream) {
+  const int k = bsk->k, N = bsk->N, M = N / 2;
+  const d2 *tw = nullptr;
+  int rc = general_twiddles(ctx, N, &tw);
+  if (rc || (rc = general_lds(external_product_general_kernel, N))) return rc;
+  uint64_t *prod = nullptr;
+  if ((rc = pool_get(ctx->device, POOL_BSK, (size_t)count * (k + 1) * N, &prod))) return rc;
+  const d2 *g = bsk->d_bk + (size_t)key_index * (k + 1) * bsk->l * (k + 1) * M;
+  hipLaunchKernelGGL(external_product_general_kernel, dim3((unsigned)count), dim3(GEN_THREADS), (size_t)8 * N, pick(ctx, stream), g, (size_t)0, tw, d_in, d_out,
+                     reinterpret_cast<d2 *>(prod), k, N, ilog2(M), bsk->l, bsk->Bg_bit, d_in0);
+  HIP_TRY(hipGetLastError());
+  return MOSFHET_HIP_OK;
+}
+
 extern "C" int mosfhet_hip_external_product_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, int key_index, uint64_t *d_out,
                                                   const uint64_t *d_in, int count, void *stream) {
   if (!ctx || !bsk || (count > 0 && !d_out) || (count > 0 && !d_in) || count < 0 || key_index < 0 || key_index >= bsk->n)
@@ -743,19 +759,7 @@ extern "C" int mosfhet_hip_external_product_batch(mosfhet_hip_ctx_t ctx, mosfhet
   if (bsk->unfolding > 1) return fail(MOSFHET_HIP_EINVAL, "external_product: an unfolded key has no DFT entries");
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
-  if (bsk->general) {
-    const int k = bsk->k, N = bsk->N, M = N / 2;
-    const d2 *tw = nullptr;
-    int rc = general_twiddles(ctx, N, &tw);
-    if (rc || (rc = general_lds(external_product_general_kernel, N))) return rc;
-    uint64_t *prod = nullptr;
-    if ((rc = pool_get(ctx->device, POOL_BSK, (size_t)count * (k + 1) * N, &prod))) return rc;
-    const d2 *g = bsk->d_bk + (size_t)key_index * (k + 1) * bsk->l * (k + 1) * M;
-    hipLaunchKernelGGL(external_product_general_kernel, dim3((unsigned)count), dim3(GEN_THREADS), (size_t)8 * N, pick(ctx, stream), g, (size_t)0, tw, d_in, d_out,
-                       reinterpret_cast<d2 *>(prod), k, N, ilog2(M), bsk->l, bsk->Bg_bit);
-    HIP_TRY(hipGetLastError());
-    return MOSFHET_HIP_OK;
-  }
+  if (bsk->general) return external_product_general(ctx, bsk, key_index, d_out, d_in, nullptr, count, stream);
   const d2 *row = bsk->d_bk + (size_t)key_index * (2 * bsk->l * 2 * (bsk->N / 2));
   hipStream_t s = pick(ctx, stream);
   RING_DISPATCH(ctx, bsk->N, launch_external_product<F>(bsk->l, bsk->Bg_bit, s, row, TW, d_in, d_out, count, (size_t)0, (size_t)2 * F::N, nullptr, nullptr, bsk->owns));
@@ -859,6 +863,16 @@ extern "C" int mosfhet_hip_trlwe_extract_tlwe_batch(mosfhet_hip_ctx_t ctx, uint6
   return MOSFHET_HIP_OK;
 }
 
+extern "C" int mosfhet_hip_trlwe_extract_tlwe_k_batch(mosfhet_hip_ctx_t ctx, uint64_t *d_out, const uint64_t *d_in, int k, int N, int idx, int count, void *stream) {
+  if (!ctx || (count > 0 && !d_out) || (count > 0 && !d_in) || k < 1 || N < 1 || idx < 0 || idx >= N || count < 0) return fail(MOSFHET_HIP_EINVAL, "trlwe_extract: bad argument");
+  if (count == 0) return MOSFHET_HIP_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(trlwe_extract_k_kernel, dim3((unsigned)(((size_t)k * N + 255) / 256), count), dim3(256), 0, pick(ctx, stream), d_out, (size_t)k * N + 1, d_in,
+                     (size_t)(k + 1) * N, N, k, idx);
+  HIP_TRY(hipGetLastError());
+  return MOSFHET_HIP_OK;
+}
+
 extern "C" int mosfhet_hip_tlwe_addto_batch(mosfhet_hip_ctx_t ctx, uint64_t *d_out, const uint64_t *d_in, int n, int count, void *stream) {
   if (!ctx || (count > 0 && !d_out) || (count > 0 && !d_in) || n < 0 || count < 0) return fail(MOSFHET_HIP_EINVAL, "tlwe_addto: bad argument");
   const size_t words = (size_t)count * (n + 1);
@@ -902,22 +916,28 @@ extern "C" int mosfhet_hip_full_domain_functional_bootstrap_batch(mosfhet_hip_ct
 extern "C" int mosfhet_hip_multivalue_bootstrap_CLOT21_batch(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t bsk, uint64_t *d_out,
                                                              const uint64_t *d_tv, int tv_count, const uint64_t *d_in, int count,
                                                              int torus_base, int n_luts, void *stream) {
-  TUNED_ONLY(bsk, "multivalue_bootstrap_CLOT21");
   if (!ctx || !bsk || (count > 0 && !d_out) || (count > 0 && !d_tv) || (count > 0 && !d_in) || count < 0 || torus_base < 1 || n_luts < 1)
     return fail(MOSFHET_HIP_EINVAL, "multivalue_CLOT21: bad argument");
-  const int N = bsk->N;
+  const int N = bsk->N, k = bsk->k;
   if (N % (n_luts * torus_base)) return fail(MOSFHET_HIP_EINVAL, "multivalue_CLOT21: N not divisible by n_luts * torus_base");
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
   uint64_t *rotated = nullptr;
-  int rc = bsk_scratch(bsk, (size_t)count * 2 * N, &rotated);
+  const size_t trlwe = (size_t)(k + 1) * N, tlwe = (size_t)k * N + 1;
+  // (general keys keep their accumulators in the POOL_BSK slot: this composition's temporaries take another one)
+  int rc = bsk->general ? pool_get(ctx->device, POOL_EXT0, (size_t)count * trlwe, &rotated) : bsk_scratch(bsk, (size_t)count * trlwe, &rotated);
   if (rc) return rc;
   if ((rc = mosfhet_hip_functional_bootstrap_wo_extract_batch(ctx, bsk, rotated, d_tv, tv_count, d_in, count, torus_base * n_luts, stream)))
     return rc;
   const int slot = N / (n_luts * torus_base);
-  for (int i = 0; i < n_luts; i++)
-    hipLaunchKernelGGL(trlwe_extract_kernel, dim3((N + 255) / 256, count), dim3(256), 0, pick(ctx, stream), d_out + (size_t)i * (N + 1),
-                       (size_t)n_luts * (N + 1), rotated, (size_t)2 * N, N, i * slot);
+  for (int i = 0; i < n_luts; i++) {
+    if (k == 1)
+      hipLaunchKernelGGL(trlwe_extract_kernel, dim3((N + 255) / 256, count), dim3(256), 0, pick(ctx, stream), d_out + (size_t)i * tlwe, (size_t)n_luts * tlwe, rotated, trlwe, N,
+                         i * slot);
+    else   // src/trlwe.c:540-552 over the k mask polynomials
+      hipLaunchKernelGGL(trlwe_extract_k_kernel, dim3((k * N + 255) / 256, count), dim3(256), 0, pick(ctx, stream), d_out + (size_t)i * tlwe, (size_t)n_luts * tlwe, rotated,
+                         trlwe, N, k, i * slot);
+  }
   HIP_TRY(hipGetLastError());
   return MOSFHET_HIP_OK;
 }

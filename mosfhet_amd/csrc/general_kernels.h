@@ -168,14 +168,17 @@ __global__ __launch_bounds__(GEN_THREADS) void pbs_general_kernel(GeneralParams 
   }
 }
 
-// out[b] = TRGSW (.) in[b] for a batch against one TRGSW_DFT (key_stride = 0) or one per unit
+// out[b] = TRGSW (.) in[b] for a batch against one TRGSW_DFT (key_stride = 0) or one per unit; in0 != nullptr: the CMUX
+// out[b] = in0[b] + TRGSW (.) (in[b] - in0[b]) (trlwe_sub + trgsw_mul_trlwe_DFT + trlwe_from_DFT + trlwe_add, applications/leveled_lut/vertical_packing.c:24-33;
+// out may be in0: a block reads its in0 words for the digits before it writes anything, and the last read of a word is the add that overwrites it)
 __global__ __launch_bounds__(GEN_THREADS) void external_product_general_kernel(const d2 *__restrict__ trgsw, size_t key_stride, const d2 *__restrict__ tw,
-                                                                            const uint64_t *__restrict__ in, uint64_t *__restrict__ out, d2 *__restrict__ prod_all,
-                                                                            int k, int N, int logM, int l, int Bg) {
+                                                                            const uint64_t *in, uint64_t *out, d2 *__restrict__ prod_all,
+                                                                            int k, int N, int logM, int l, int Bg, const uint64_t *in0) {
   extern __shared__ __attribute__((aligned(16))) d2 z[];
   const int M = N / 2;
   const size_t b = blockIdx.x;
   const uint64_t *src_all = in + b * (size_t)(k + 1) * N;
+  const uint64_t *base_all = in0 ? in0 + b * (size_t)(k + 1) * N : nullptr;
   d2 *prod = prod_all + b * (size_t)(k + 1) * M;
   const d2 *__restrict__ g = trgsw + b * key_stride;
   uint64_t off = 1ull << (63 - l * Bg);
@@ -183,8 +186,12 @@ __global__ __launch_bounds__(GEN_THREADS) void external_product_general_kernel(c
   const RoundCtx scale(logM);
   for (int q = 0; q <= k; q++) {
     const uint64_t *src = src_all + (size_t)q * N;
+    const uint64_t *sub = base_all ? base_all + (size_t)q * N : nullptr;
     for (int j = 0; j < l; j++) {
-      for (int x = threadIdx.x; x < M; x += GEN_THREADS) z[x] = d2{digit_rt(src[x] + off, j, Bg), digit_rt(src[x + M] + off, j, Bg)};
+      for (int x = threadIdx.x; x < M; x += GEN_THREADS) {
+        const uint64_t lo = sub ? src[x] - sub[x] : src[x], hi = sub ? src[x + M] - sub[x + M] : src[x + M];
+        z[x] = d2{digit_rt(lo + off, j, Bg), digit_rt(hi + off, j, Bg)};
+      }
       __syncthreads();
       general_forward(z, tw, logM);
       const d2 *__restrict__ row = g + (size_t)(q * l + j) * (k + 1) * M;
@@ -205,10 +212,12 @@ __global__ __launch_bounds__(GEN_THREADS) void external_product_general_kernel(c
     __syncthreads();
     general_inverse(z, tw, logM);
     uint64_t *dst = out + (b * (size_t)(k + 1) + c) * N;
+    const uint64_t *add = base_all ? base_all + (size_t)c * N : nullptr;
     for (int x = threadIdx.x; x < M; x += GEN_THREADS) {
       const d2 v = z[x];
-      dst[x] = round_mod_2_64(v.x, scale);
-      dst[x + M] = round_mod_2_64(v.y, scale);
+      const uint64_t r0 = round_mod_2_64(v.x, scale), r1 = round_mod_2_64(v.y, scale);
+      dst[x] = add ? add[x] + r0 : r0;
+      dst[x + M] = add ? add[x + M] + r1 : r1;
     }
     __syncthreads();
   }

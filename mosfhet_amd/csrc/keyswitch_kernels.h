@@ -206,6 +206,20 @@ __global__ void trlwe_extract_kernel(uint64_t *__restrict__ out, size_t out_stri
   if (j == 0) o[N] = c[N + idx];
 }
 
+// the same for k >= 1 mask polynomials [src/trlwe.c:540-552 loops over i < k]: in = [k+1][N] words, out = [kN+1]
+__global__ void trlwe_extract_k_kernel(uint64_t *__restrict__ out, size_t out_stride, const uint64_t *__restrict__ in, size_t in_stride,
+                                       int N, int k, int idx) {
+  const uint64_t *c = in + (size_t)blockIdx.y * in_stride;
+  uint64_t *o = out + (size_t)blockIdx.y * out_stride;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x < k * N) {
+    const int i = x / N, j = x - i * N;
+    const uint64_t *a = c + (size_t)i * N;
+    o[x] = (j <= idx) ? a[idx - j] : (0 - a[N + idx - j]);
+  }
+  if (x == 0) o[(size_t)k * N] = c[(size_t)k * N + idx];
+}
+
 struct KsWorkspace {
   uint64_t *inT = nullptr, *outT = nullptr;
   size_t words_in = 0, words_out = 0;

@@ -500,7 +500,7 @@ class Engine:
         """out[b] = in0[b] + key[key_index] (.) (in1[b] - in0[b]); out may be in0."""
         count = in0.shape[0]
         if out is None:
-            out = self.empty(count, 2, bsk.N)
+            out = self.empty(count, bsk.k + 1, bsk.N)
         _check(lib().mosfhet_hip_cmux_batch(self.h, bsk.h, int(key_index), _ptr(out), _ptr(in0), _ptr(in1), count, self._stream()))
         return out
 
@@ -644,10 +644,12 @@ class Engine:
 
     def trlwe_extract_tlwe(self, trlwe, idx, out=None):
         count, k1, N = trlwe.shape
-        assert k1 == 2
         if out is None:
-            out = self.empty(count, N + 1)
-        _check(lib().mosfhet_hip_trlwe_extract_tlwe_batch(self.h, _ptr(out), _ptr(trlwe), N, idx, count, self._stream()))
+            out = self.empty(count, (k1 - 1) * N + 1)
+        if k1 == 2:
+            _check(lib().mosfhet_hip_trlwe_extract_tlwe_batch(self.h, _ptr(out), _ptr(trlwe), N, idx, count, self._stream()))
+        else:
+            _check(lib().mosfhet_hip_trlwe_extract_tlwe_k_batch(self.h, _ptr(out), _ptr(trlwe), k1 - 1, N, idx, count, self._stream()))
         return out
 
     def tlwe_addto_(self, out, ct):
