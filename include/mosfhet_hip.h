@@ -26,7 +26,8 @@
  *                    general path (csrc/general_kernels.h; the reference is generic in k and N, src/trgsw.c:385-423): k <= 3 and any power-of-two
  *                    N in 256 .. 16384 -- a correctness path, one workgroup per ciphertext, bit-identical to the same oracle.  A bootstrap key with such
  *                    parameters (mosfhet_hip_bsk_create[_from_device]) serves programmable / functional bootstraps (+ wo_extract), blind_rotate, the
- *                    full-domain bootstrap, key switch + bootstrap and external products; the other entry points return MOSFHET_HIP_EINVAL for it.
+ *                    full-domain bootstrap, key switch + bootstrap, external products, CMUX and multivalue_bootstrap_CLOT21; the other entry points
+ *                    return MOSFHET_HIP_EINVAL for it.
  *                    mosfhet_hip_torus_to_dft_batch / _dft_to_torus_batch take any such N (natural slot order outside 1024 / 2048 / 4096).
  *   threading        re-entrant, like the reference (thread-local scratch there, src/polynomial.c:269-352): a context and its key
  *                    handles are read-only after creation and may be shared by any number of host threads; device temporaries of
