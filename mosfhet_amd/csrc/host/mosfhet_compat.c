@@ -1043,9 +1043,14 @@ static void *mc_copy_stream(void) {
 /* A large batch of TLWE results (the kernels have finished: the caller synchronised): back in pieces with an event behind each, a piece unpacked into the
  * structs while the next one lands (8192 outputs of 16 KB for 1024 multi-value bootstraps at lvl2: 134 MB). */
 static void tlwe_array_download(TLWE *out, Torus *h_flat, const Torus *d_flat, int count, int n_out) {
-  static int piece_env = -1;   /* MOSFHET_COMPAT_TLWE_PIECE: outputs per piece (0 = one copy, then unpack) */
-  if (piece_env < 0) { const char *e = getenv("MOSFHET_COMPAT_TLWE_PIECE"); piece_env = e ? atoi(e) : 1024; if (piece_env < 0) piece_env = 0; }
-  const int PIECE = piece_env;
+  static int piece_env = -1;   /* MOSFHET_COMPAT_TLWE_PIECE: outputs per piece (0 = one copy, then unpack); read once, by whichever thread comes first */
+  int PIECE = __atomic_load_n(&piece_env, __ATOMIC_RELAXED);
+  if (PIECE < 0) {
+    const char *e = getenv("MOSFHET_COMPAT_TLWE_PIECE");
+    PIECE = e ? atoi(e) : 1024;
+    if (PIECE < 0) PIECE = 0;
+    __atomic_store_n(&piece_env, PIECE, __ATOMIC_RELAXED);
+  }
   const size_t item = (size_t)n_out + 1;
   if (PIECE == 0 || count <= PIECE) {
     mc_dev_copy(h_flat, d_flat, sizeof(Torus) * (size_t)count * item, HIP_D2H);
