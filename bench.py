@@ -242,7 +242,10 @@ def main():
     backend = os.environ.get("MOSFHET_BENCH_BACKEND", "nccl")
     dev_index = 0 if share_gpu else local_rank
     torch.cuda.set_device(dev_index)
-    if world > 1:
+    # MOSFHET_BENCH_FORCE_DIST=1 (test hook): make the process group at world size 1 too, so that the RCCL branch -- communicator on this rank's device, the
+    # barriers and the max-reduction of the timed region on a device tensor -- executes on a 1-GPU box exactly as the driver's N > 1 launches run it
+    force_dist = os.environ.get("MOSFHET_BENCH_FORCE_DIST", "0") == "1" and "RANK" in os.environ
+    if world > 1 or force_dist:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
@@ -332,7 +335,7 @@ def main():
     # N > 1: what makes the ranks replicas of one job -- the SAME bootstrap key on every GPU (same seed), DIFFERENT ciphertexts per rank, every rank's
     # outputs decrypting -- gathered once, outside the timed region
     replicas = None
-    if world > 1:
+    if world > 1 or force_dist:
         import zlib
         mine = torch.tensor([zlib.crc32(bk.tobytes()), zlib.crc32(cts.tobytes()), int(np.log2(err + 1) * 1000)], dtype=torch.int64,
                             device=eng.device if backend == "nccl" else "cpu")
@@ -436,6 +439,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "process_group": (backend if (world > 1 or force_dist) else None),
             "config": {"workload": "batch of %d programmable bootstraps per GPU, SET_1 n=585 N=1024 k=1 l=2 Bg=2^8 "
                                    "(BASELINE.json configs[1])" % B,
                        "batch_per_gpu": B, "streams": len(streams), "parallelism": "batch sharded over %d GPU(s), bootstrap key replicated, "
@@ -460,7 +464,7 @@ def main():
             "host_buffer_rate_per_gpu": host_rate,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 
