@@ -311,6 +311,10 @@ size_t mosfhet_hip_ksk_bytes(mosfhet_hip_ksk_t ksk);                     /* devi
  * encrypted in the torus domain by the counter-based generator (exact a * s, Gaussian noise sigma), then transformed -- no host key, no upload. */
 int mosfhet_hip_bsk_generate(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t *out, const uint64_t *h_s_rlwe, int N, const uint64_t *h_s_lwe, int n, int l, int Bg_bit,
                              double sigma, uint64_t seed, int ga);
+/* ... for any k <= 3 and any ring the engine serves up to N = 8192 (keys of the general-ring path): h_s_rlwe = the k key polynomials [k][N]; the k + 1 components of a
+ * row as trgsw_monomial_sample makes them (src/trgsw.c:152-168).  k = 1 on a tuned ring is mosfhet_hip_bsk_generate(.., ga = 0). */
+int mosfhet_hip_bsk_generate_k(mosfhet_hip_ctx_t ctx, mosfhet_hip_bsk_t *out, const uint64_t *h_s_rlwe /*[k][N]*/, int k, int N, const uint64_t *h_s_lwe, int n, int l,
+                               int Bg_bit, double sigma, uint64_t seed);
 /* On-device generation of FFT-based TRLWE key-switch keys: entry e, row r < t = TRLWE_{s_out}(h_msgs[e](X) * 2^(64 - (r+1) base_bit)), then the
  * engine's forward transform.  h_msgs = Torus[entries][N] holds the polynomial each entry switches FROM: the other key (trlwe_new_KS_key,
  * src/keyswitch.c:12-37), its Galois images s(X^(2e+1)) for e < N (trlwe_new_automorphism_KS_keyset, :500-511), (-s * s_in, -s) (trlwe_new_priv_KS_key,

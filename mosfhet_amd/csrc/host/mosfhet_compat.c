@@ -792,18 +792,27 @@ Bootstrap_Key new_bootstrap_key(TRGSW_Key out_key, TLWE_Key in_key, int unfoldin
   mosfhet_hip_bsk_t dev = NULL;
   if (k != 1 || (N != 1024 && N != 2048 && N != 4096)) {
     /* k > 1 or a ring without a tuned kernel (the reference is generic in both, src/trgsw.c:385-423): the engine's general path (csrc/general_kernels.h)
-     * serves functional / programmable bootstraps (+ wo_extract), the full-domain bootstrap and key switch + bootstrap with such a key.  Encrypted on
-     * the host (trgsw_monomial_sample), transformed on the device.  Bootstrap_Key.s (the array legacy callers hand to blind_rotate) is not provided. */
+     * serves functional / programmable bootstraps (+ wo_extract), the full-domain bootstrap, multi-value bootstraps and key switch + bootstrap with such a
+     * key.  Bootstrap_Key.s (the array legacy callers hand to blind_rotate) is not provided. */
     if (unfolding != 1 || k < 1 || k > 3 || N < 256 || N > 16384 || (N & (N - 1))) {
       fprintf(stderr, "mosfhet_amd: new_bootstrap_key: k = %d, N = %d, unfolding = %d has no kernel (k <= 3, N a power of two in 256 .. 16384, unfolding 1 "
                       "outside k = 1, N in 1024 / 2048 / 4096)\n", k, N, unfolding);
       abort();
     }
-    const size_t words = (size_t)n * (k + 1) * l * (k + 1) * N;
-    Torus *flat = (Torus *)mc_xmalloc(sizeof(Torus) * words);
-    mosfhet_gen_bootstrap_key_flat(flat, out_key, in_key);
-    if (mosfhet_hip_bsk_create((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, flat, n, k, N, l, out_key->Bg_bit)) mc_die("new_bootstrap_key (general ring)");
-    free(flat);
+    if (N <= 8192) {
+      /* encrypted on the device like the tuned rings' keys (mosfhet_hip_bsk_generate_k: exact a * s over the k key polynomials, ChaCha20 noise) */
+      Torus *s_all = (Torus *)mc_xmalloc(sizeof(Torus) * (size_t)k * N);
+      for (int m = 0; m < k; m++) memcpy(s_all + (size_t)m * N, out_key->trlwe_key->s[m]->coeffs, sizeof(Torus) * (size_t)N);
+      if (mosfhet_hip_bsk_generate_k((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, s_all, k, N, in_key->s, n, l, out_key->Bg_bit, out_key->trlwe_key->sigma, mc_rnd64()))
+        mc_die("new_bootstrap_key (general ring)");
+      free(s_all);
+    } else {   /* N = 16384: encrypted on the host (trgsw_monomial_sample), transformed on the device */
+      const size_t words = (size_t)n * (k + 1) * l * (k + 1) * N;
+      Torus *flat = (Torus *)mc_xmalloc(sizeof(Torus) * words);
+      mosfhet_gen_bootstrap_key_flat(flat, out_key, in_key);
+      if (mosfhet_hip_bsk_create((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, flat, n, k, N, l, out_key->Bg_bit)) mc_die("new_bootstrap_key (general ring)");
+      free(flat);
+    }
     res->device = dev;
     res->s = NULL;
     remember_key(res);

@@ -168,6 +168,48 @@ __global__ __launch_bounds__(256) void trgsw_bk_keygen_kernel(uint64_t *__restri
   }
 }
 
+// The same for ANY k >= 1 and power-of-two N (keys of the general-ring path): row r = i (k+1) l + c l + j is a fresh TRLWE_k(0) -- masks a_0 .. a_{k-1} uniform (mask m of a
+// row: generator stream m), b = sum_m a_m * s_m + e, every product exact -- with s_lwe[i] 2^(64 - (j+1) Bg) added to coefficient 0 of component c <= k
+// (trgsw_monomial_sample, src/trgsw.c:152-168 loops over the k + 1 components; new_bootstrap_key, src/bootstrap.c:14-18).  One workgroup per row, one mask at a time in LDS.
+__global__ __launch_bounds__(256) void trgsw_bk_keygen_k_kernel(uint64_t *__restrict__ rows, const uint64_t *__restrict__ s_out /*[k][N]*/, const uint64_t *__restrict__ s_in,
+                                                              int k, int N, int l, int Bg_bit, double sigma, uint64_t seed, NoiseKey nkey) {
+  extern __shared__ uint64_t sh[];
+  uint64_t *a = sh;
+  uint16_t *ones = reinterpret_cast<uint16_t *>(sh + N);
+  int16_t *vals = reinterpret_cast<int16_t *>(ones + N);
+  __shared__ int n_ones;
+  const int tid = threadIdx.x;
+  const size_t r = blockIdx.x;
+  const int per = (k + 1) * l, q = (int)(r % per), c = q / l, j = q % l;
+  const size_t i = r / per;
+  uint64_t *dst = rows + r * (size_t)(k + 1) * N, *dst_b = dst + (size_t)k * N;
+  const uint64_t val = s_in[i] * (1ull << (64 - (j + 1) * Bg_bit));
+  for (int m = 0; m < k; m++) {
+    __syncthreads();   // the previous mask's LDS image is consumed
+    const uint64_t *s_m = s_out + (size_t)m * N;
+    if (tid == 0) {
+      int cnt = 0;
+      for (int x = 0; x < N; x++)
+        if (s_m[x]) { vals[cnt] = (int16_t)(int64_t)s_m[x]; ones[cnt++] = (uint16_t)x; }
+      n_ones = cnt;
+    }
+    for (int x = tid; x < N; x += 256) a[x] = keygen_mix(seed, r, x, (uint64_t)m);
+    __syncthreads();
+    const int cnt = n_ones;
+    for (int x = tid; x < N; x += 256) {   // (a thread owns the same words x in every pass: the read-modify-write of dst_b needs no barrier)
+      uint64_t acc = m ? dst_b[x] : 0;
+      for (int u = 0; u < cnt; u++) {
+        const int p = ones[u], src = x - p;
+        const uint64_t w = a[src & (N - 1)] * (uint64_t)(int64_t)vals[u];
+        acc += src < 0 ? (uint64_t)0 - w : w;
+      }
+      dst[(size_t)m * N + x] = a[x] + ((c == m && x == 0) ? val : 0);     // the gadget goes on the mask AFTER b was formed from the plain mask
+      dst_b[x] = acc;
+    }
+  }
+  for (int x = tid; x < N; x += 256) dst_b[x] += keygen_noise(nkey, r, (uint64_t)x, sigma) + ((c == k && x == 0) ? val : 0);
+}
+
 // FFT-based TRLWE key-switch keys in the torus domain (trlwe_new_KS_key, src/keyswitch.c:12-37; the automorphism key set, :500-511; the private
 // pair, :39-50; the relinearisation key, :3-10 -- they differ only in the polynomial being switched from): entry e, row r < t is
 // TRLWE_{s_out}(msg_e(X) * 2^(64 - (r+1) bb)).  One workgroup per row; the caller transforms the rows afterwards.

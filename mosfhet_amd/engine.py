@@ -412,6 +412,13 @@ class Engine:
         s_rlwe = np.ascontiguousarray(s_rlwe, dtype=np.uint64)
         s_lwe = np.ascontiguousarray(s_lwe, dtype=np.uint64)
         h = C.c_void_p()
+        if s_rlwe.ndim == 2:   # [k][N]: any k <= 3 / any ring the engine serves (general-ring path included)
+            k, N = s_rlwe.shape
+            if ga:
+                raise MosfhetHipError("generate_bootstrap_key: the Galois form exists for k = 1 only")
+            _check(lib().mosfhet_hip_bsk_generate_k(self.h, C.byref(h), s_rlwe.ctypes.data_as(C.c_void_p), k, N, s_lwe.ctypes.data_as(C.c_void_p), s_lwe.size,
+                                                    l, Bg_bit, C.c_double(sigma), C.c_uint64(seed)))
+            return BootstrapKey(self, h, s_lwe.size, k, N, l, Bg_bit)
         _check(lib().mosfhet_hip_bsk_generate(self.h, C.byref(h), s_rlwe.ctypes.data_as(C.c_void_p), s_rlwe.size, s_lwe.ctypes.data_as(C.c_void_p), s_lwe.size,
                                               l, Bg_bit, C.c_double(sigma), C.c_uint64(seed), int(ga)))
         return BootstrapKey(self, h, s_lwe.size, 1, s_rlwe.size, l, Bg_bit)
