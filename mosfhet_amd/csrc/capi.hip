@@ -1122,6 +1122,20 @@ extern "C" int mosfhet_hip_trlwe_packing1_keyswitch_batch(mosfhet_hip_ctx_t ctx,
   return MOSFHET_HIP_OK;
 }
 
+// circuit bootstraps: one packing switch for all l levels when that saves table sweeps (a tile of the switch is 512 ciphertexts wide); MOSFHET_HIP_CB_TOGETHER=0 / 1 forces
+static bool cb_levels_together(int count, int l) {
+  static std::atomic<int> v{-2};
+  int r = v.load(std::memory_order_relaxed);
+  if (r == -2) { const char *e = getenv("MOSFHET_HIP_CB_TOGETHER"); r = e ? atoi(e) : -1; v.store(r, std::memory_order_relaxed); }
+  if (r >= 0) return r != 0 && l > 1;
+  return l > 1 && ((size_t)l * count + 511) / 512 < (size_t)l * (((size_t)count + 511) / 512);
+}
+// circuit_bootstrap (one bootstrap per level): the l bootstraps of an input as one row-mode launch while they fit one residency round (capi_ext.inc)
+static bool cb_bootstraps_together(int count, int l) {
+  const char *e = getenv("MOSFHET_HIP_CB_TOGETHER");
+  return l > 1 && (size_t)l * count <= 1024 && !(e && atoi(e) == 0);
+}
+
 // test vector of circuit_bootstrap_3 (src/bootstrap.c:350-355): 2l slots, slot l + i = 2^(64 - (i+1) Bg), slots < l zero
 __global__ void circuit_bootstrap_lut_kernel(uint64_t *__restrict__ tv, int N, int l, int Bg_bit) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1141,16 +1155,37 @@ extern "C" int mosfhet_hip_circuit_bootstrap_3_batch_ev(mosfhet_hip_ctx_t ctx, m
   if (N % (2 * l)) return fail(MOSFHET_HIP_EINVAL, "circuit_bootstrap_3: N not divisible by 2l");
   if (count == 0) return MOSFHET_HIP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
-  const size_t w_tv = (size_t)2 * N, w_acc = (size_t)count * 2 * N, w_ext = (size_t)count * (N + 1);
+  // Few ciphertexts (fewer than one 512-wide tile of the packing switch): every level's switch would sweep the whole table (3 - 6 GB) for a fraction of a tile, so the
+  // l levels' samples are extracted first and switched TOGETHER -- ceil(l count / 512) sweeps instead of l -- into a staging block, from where the private switch reads
+  // them and a strided copy puts them into their TRGSW rows.  Large batches keep one switch per level: same number of sweeps, and the levels finish one after the
+  // other (what the level events are for).  Same operations on the same words either way: same bits.
+  const bool together = cb_levels_together(count, l);
+  const size_t w_tv = (size_t)2 * N, w_acc = (size_t)count * 2 * N, w_ext = ((size_t)count * (N + 1) * (together ? l : 1) + 1) & ~(size_t)1 /* keeps the staging block 16-byte aligned */,
+               w_stage = together ? (size_t)l * count * 2 * N : 0;
   uint64_t *tv = nullptr;
-  int rc = bsk_scratch(bsk, w_tv + w_acc + w_ext, &tv);
+  int rc = bsk_scratch(bsk, w_tv + w_acc + w_ext + w_stage, &tv);
   if (rc) return rc;
-  uint64_t *acc = tv + w_tv, *ext = acc + w_acc;
+  uint64_t *acc = tv + w_tv, *ext = acc + w_acc, *stage = ext + w_ext;
   hipStream_t s = pick(ctx, stream);
   hipLaunchKernelGGL(circuit_bootstrap_lut_kernel, dim3((N + 255) / 256), dim3(256), 0, s, tv, N, l, bsk->Bg_bit);
   if ((rc = mosfhet_hip_functional_bootstrap_wo_extract_batch(ctx, bsk, acc, tv, 1, d_in, count, 2 * l, stream))) return rc;
   const int slot = N / (2 * l);
   const size_t trgsw = (size_t)2 * l * 2 * N, esz = (size_t)kska->t * 2 * (N / 2);
+  if (together) {
+    for (int i = 0; i < l; i++)
+      hipLaunchKernelGGL(trlwe_extract_kernel, dim3((N + 255) / 256, count), dim3(256), 0, s, ext + (size_t)i * count * (N + 1), (size_t)N + 1, acc, (size_t)2 * N, N, i * slot);
+    HIP_TRY(launch_tlwe_keyswitch(kskb->d_ksk, stage, (size_t)2 * N, ext, (size_t)N + 1, l * count, N, 2 * N, N, kskb->t, kskb->base_bit, tl_ws(ctx->device), s, kskb->compressed,
+                                  kskb->seed));
+    for (int i = 0; i < l; i++) {
+      const uint64_t *sw = stage + (size_t)i * count * 2 * N;
+      uint64_t *row_b = d_out + (size_t)(l + i) * 2 * N, *row_a = d_out + (size_t)i * 2 * N;
+      HIP_TRY(hipMemcpy2DAsync(row_b, trgsw * sizeof(uint64_t), sw, (size_t)2 * N * sizeof(uint64_t), (size_t)2 * N * sizeof(uint64_t), (size_t)count, hipMemcpyDeviceToDevice, s));
+      if ((rc = launch_fft_ks(ctx, kska, kska->d_ak, kska->d_ak + esz, row_a, trgsw, sw, (size_t)2 * N, count, 1, s))) return rc;
+      if (level_done && level_done[i]) HIP_TRY(hipEventRecord((hipEvent_t)level_done[i], s));
+    }
+    HIP_TRY(hipGetLastError());
+    return MOSFHET_HIP_OK;
+  }
   for (int i = 0; i < l; i++) {
     hipLaunchKernelGGL(trlwe_extract_kernel, dim3((N + 255) / 256, count), dim3(256), 0, s, ext, (size_t)N + 1, acc, (size_t)2 * N, N, i * slot);
     uint64_t *row_b = d_out + (size_t)(l + i) * 2 * N, *row_a = d_out + (size_t)i * 2 * N;
