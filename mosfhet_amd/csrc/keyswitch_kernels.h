@@ -190,6 +190,12 @@ __global__ void tlwe_add_to_b_kernel(uint64_t *__restrict__ ct, int count, size_
   if (b < count) ct[(size_t)b * row + row - 1] += delta;
 }
 
+// the same with the samples `stride` words apart and the b word at `word` (samples interleaved with others: capi_ext.inc, the KS21 level layout)
+__global__ void tlwe_add_to_word_kernel(uint64_t *__restrict__ ct, int count, size_t stride, size_t word, uint64_t delta) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < count) ct[(size_t)b * stride + word] += delta;
+}
+
 // fill a trivial TRLWE whose b polynomial is the constant `value` (trlwe_torus_packing with one slot, src/trlwe.c:662-667)
 __global__ void trlwe_constant_kernel(uint64_t *__restrict__ tv, int N, uint64_t value) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -21,3 +21,12 @@ for variant in (0, 1):
     for _ in range(3):
         t = time.time(); f(); torch.cuda.synchronize(); ts.append((time.time() - t) * 1e3)
     print("circuit_bootstrap variant %d  B=%d ms=%s" % (variant, B, ["%.2f" % x for x in ts]))
+d_tv2 = ma.to_device(rnd(2 * N), eng.device)
+o = eng.empty(B, N + 1)
+for variant in (0, 1):
+    f = lambda: eng.full_domain_functional_bootstrap_KS21(bsk, pk, d_tv2, d_ct, 8, variant, out=o)
+    f(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        t = time.time(); f(); torch.cuda.synchronize(); ts.append((time.time() - t) * 1e3)
+    print("full_domain_functional_bootstrap_KS21 variant %d  B=%d ms=%s" % (variant, B, ["%.2f" % x for x in ts]))
