@@ -534,11 +534,11 @@ static unsigned int *pace_slot(hipStream_t s) {
 template <class F, int L, int BG>
 static void launch_pbs(const PbsParams &p_in, int count, hipStream_t s) {
   PbsParams p = p_in;
-  const int chunk = F::THREADS > 64 && p.rows == 1 && p.count < 0 ? round_chunk(F::THREADS) : 0;   // p.count < 0: key larger than the L2s
+  const int chunk = F::THREADS > 64 && p.count < 0 ? round_chunk(F::THREADS) : 0;   // p.count < 0: key larger than the L2s
   const bool pace = F::THREADS > 64 && pace_every() > 0 && chunk > 0 && count >= 64;   // (all teams of a launch of <= chunk are resident)
   p.pace_every = pace ? pace_every() : 0;
   p.pace_limit = pace_limit();
-  if (chunk > 0 && count > chunk) {
+  if (chunk > 0 && count > chunk && p.rows == 1) {   // (row mode -- TRGSW accumulators, per-level test vectors -- stays one launch: paced when it fits a round, as it was otherwise)
     const size_t out_row = p.extract ? (size_t)F::N + 1 : (size_t)2 * F::N;
     for (int lo = 0; lo < count; lo += chunk) {
       PbsParams q = p;
