@@ -538,15 +538,17 @@ static void launch_pbs(const PbsParams &p_in, int count, hipStream_t s) {
   const bool pace = F::THREADS > 64 && pace_every() > 0 && chunk > 0 && count >= 64;   // (all teams of a launch of <= chunk are resident)
   p.pace_every = pace ? pace_every() : 0;
   p.pace_limit = pace_limit();
-  if (chunk > 0 && count > chunk && p.rows == 1) {   // (row mode -- TRGSW accumulators, per-level test vectors -- stays one launch: paced when it fits a round, as it was otherwise)
+  if (chunk > 0 && count > chunk) {
+    // row mode (TRGSW accumulators, per-level test vectors: block b takes input b / rows and test vector b % rows of ONE shared set): rounds of whole inputs
+    const int rows = p.rows > 1 ? p.rows : 1, step = chunk - chunk % rows;
     const size_t out_row = p.extract ? (size_t)F::N + 1 : (size_t)2 * F::N;
-    for (int lo = 0; lo < count; lo += chunk) {
+    for (int lo = 0; lo < count; lo += step) {
       PbsParams q = p;
       q.pace = pace ? pace_slot(s) : nullptr;
-      q.in = p.in + (size_t)lo * (p.n + 1);
+      q.in = p.in + (size_t)(lo / rows) * (p.n + 1);
       q.out = p.out + (size_t)lo * out_row;
-      q.tv = p.tv ? p.tv + (size_t)lo * p.tv_stride : p.tv;
-      const int c = count - lo < chunk ? count - lo : chunk;
+      q.tv = rows > 1 ? p.tv : (p.tv ? p.tv + (size_t)lo * p.tv_stride : p.tv);
+      const int c = count - lo < step ? count - lo : step;
       hipLaunchKernelGGL((pbs_kernel<F, L, BG>), dim3((unsigned)c), dim3(F::THREADS), 0, s, q);
     }
     return;
@@ -1130,10 +1132,11 @@ static bool cb_levels_together(int count, int l) {
   if (r >= 0) return r != 0 && l > 1;
   return l > 1 && ((size_t)l * count + 511) / 512 < (size_t)l * (((size_t)count + 511) / 512);
 }
-// circuit_bootstrap (one bootstrap per level): the l bootstraps of an input as one row-mode launch while they fit one residency round (capi_ext.inc)
+// circuit_bootstrap / FDFB KS21_2 (one bootstrap per level): the l bootstraps of an input side by side in row mode -- one launch, or residency rounds of whole inputs
+// (launch_pbs) -- instead of l launches of fewer than a round's worth of ciphertexts (capi_ext.inc)
 static bool cb_bootstraps_together(int count, int l) {
   const char *e = getenv("MOSFHET_HIP_CB_TOGETHER");
-  return l > 1 && (size_t)l * count <= 1024 && !(e && atoi(e) == 0);
+  return l > 1 && count < 1024 && !(e && atoi(e) == 0);   // (from 1024 on, l launches of count ARE l count / 1024 residency rounds)
 }
 
 // test vector of circuit_bootstrap_3 (src/bootstrap.c:350-355): 2l slots, slot l + i = 2^(64 - (i+1) Bg), slots < l zero
