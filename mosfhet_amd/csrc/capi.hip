@@ -981,13 +981,27 @@ extern "C" int mosfhet_hip_gak_destroy(mosfhet_hip_gak_t gak) {
 template <class F, int L, int BG>
 static void launch_ga(const GaParams &g_in, int count, hipStream_t s) {
   GaParams g = g_in;
-  // one residency round or less of N >= 2048 teams: re-aligned on the bootstrap key like launch_pbs's rounds
-  const int round = F::THREADS > 64 ? round_chunk(F::THREADS) : 0;
-  if (g.mode == 0 && round > 0 && count >= 64 && count <= round && pace_every() > 0) {
+  // Galois bootstraps at N = 2048 (the bootstrap key does not fit the L2s): one launch per residency round, its teams re-aligned on the bootstrap-key walk, like launch_pbs
+  const int round = F::THREADS > 64 && F::N == 2048 && g.mode == 0 ? round_chunk(F::THREADS) : 0;
+  const bool pace = round > 0 && count >= 64 && pace_every() > 0;
+  if (pace) {
     g.p.pace_every = pace_every();
     g.p.pace_limit = pace_limit();
-    g.p.pace = pace_slot(s);
   }
+  if (round > 0 && count > round) {
+    const size_t out_row = g.p.extract ? (size_t)F::N + 1 : (size_t)2 * F::N;
+    for (int lo = 0; lo < count; lo += round) {
+      GaParams q = g;
+      q.p.pace = pace ? pace_slot(s) : nullptr;
+      q.p.in = g.p.in + (size_t)lo * (g.p.n + 1);
+      q.p.out = g.p.out + (size_t)lo * out_row;
+      q.p.tv = g.p.tv ? g.p.tv + (size_t)lo * g.p.tv_stride : g.p.tv;
+      const int c = count - lo < round ? count - lo : round;
+      hipLaunchKernelGGL((pbs_ga_kernel<F, L, BG>), dim3((unsigned)c), dim3(F::THREADS), 0, s, q);
+    }
+    return;
+  }
+  if (pace) g.p.pace = pace_slot(s);
   hipLaunchKernelGGL((pbs_ga_kernel<F, L, BG>), dim3((unsigned)count), dim3(F::THREADS), 0, s, g);
 }
 
