@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--only", default=None)
+    ap.add_argument("--share", type=int, default=1, metavar="S",
+                    help="size every batch as ONE GPU's share when the configs' batches are split over S GPUs (strong scaling: 1024 / S circuit, FDFB, multi-value and "
+                         "Galois bootstraps, 4096 / S lvl2 bootstraps) -- what a GPU of an S-GPU node would run, measured on this one")
     ap.add_argument("--in-api-devices", default=None, metavar="IDS",
                     help="instead: configs[3] / [4] through the drop-in C API in ONE process with these devices behind it (mosfhet_set_devices; e.g. 0,1,2,3,4,5,6,7, "
                          "or 0,0 for two contexts on one GPU): compiles and runs tools/in_api_devices.c and relays its JSON lines")
@@ -77,12 +80,13 @@ def main():
             total = unit_count * args.steps * (world if scaling == "weak" else 1)
             print(json.dumps({"metric": metric, "value": total / elapsed, "unit": "units/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64",
-                              "data": "synthetic", "config": {"workload": workload, "name": name}, "decrypts": ok}), flush=True)
+                              "data": "synthetic", "config": {"workload": workload + ("" if args.share == 1 else " -- sized as ONE GPU's share of %d: %d units per step" % (args.share, unit_count)),
+                                                              "name": name}, "decrypts": ok}), flush=True)
 
     lut4 = np.array([host.double2torus(x) for x in (0.0625, 0.3125, -0.1875, 0.4375)], dtype=np.uint64)
 
     # ---- configs[2] ----
-    B = 4096
+    B = 4096 // args.share
     cts = host.tlwe_samples([host.double2torus((b % 4) / 8.0) for b in range(B)], lk)
     d_ct = ma.to_device(cts, eng.device)
     d_tv = ma.to_device(host.torus_packing(lut4, 1, N)[None], eng.device)
@@ -99,16 +103,16 @@ def main():
     if not args.only or args.only == "circuit":
         kska = eng.load_trlwe_ks_keys(host.gen_priv_ks_key(rk, rk, 20, 2), 2)
         pk = eng.generate_table_key(0, s, s, 6, 4, P["rlwe_sigma"], seed=99, compressed=True)   # seed-compressed rows: 3 GB in HBM, masks regenerated in the kernel (same results, 2-3 % faster)
-        lo, hi = shard.shard_bounds(1024, rank, world)
+        lo, hi = shard.shard_bounds(1024, rank, world) if args.share == 1 else shard.shard_bounds(1024, 0, args.share)
         d_cb_in = ma.to_device(host.tlwe_samples([host.double2torus(0.25 * (b & 1)) for b in range(lo, hi)], lk), eng.device)
         d_cb_out = eng.empty(hi - lo, 2 * l, 2, N)
-        emit("circuit", "circuit bootstraps/sec (circuit_bootstrap_3), N=2048 l=4", 1024, lambda: eng.circuit_bootstrap_3(bsk, kska, pk, d_cb_in, out=d_cb_out),
+        emit("circuit", "circuit bootstraps/sec (circuit_bootstrap_3), N=2048 l=4", 1024 if args.share == 1 else hi - lo, lambda: eng.circuit_bootstrap_3(bsk, kska, pk, d_cb_in, out=d_cb_out),
              "strong", "circuit_bootstrap_3, batch of 1024 split over the GPUs, packing key t=6 bb=4 (6 GB), private key t=20 bb=2 (BASELINE.json configs[3])")
         pk.free()
         kska.free()
 
     # ---- configs[4] ----
-    B5 = 1024
+    B5 = 1024 // args.share
     if not args.only or args.only in ("fdfb", "multivalue", "keyswitch_lvl2"):
         ksk = eng.load_keyswitch_key(host.gen_tlwe_ks_key(lk, rk.extracted_lwe_key(), P["t"], P["base_bit"]), P["base_bit"])
         lut8 = np.array([host.double2torus(((3 * i + 1) % 8) / 8.0) for i in range(8)], dtype=np.uint64)
