@@ -739,6 +739,137 @@ __global__ __launch_bounds__(F::THREADS * WideTeams<L>::value) void pbs_wide_tea
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// pbs_wide_team_kernel with each team taking its rows TWO AT A TIME (N = 2048, even gadget length, the transform with its pass twiddles in LDS): the two
+// forward transforms of a team's pair are software-pipelined through the team's one exchange buffer (Fft2048T::forward2_head: every register pass of one runs
+// while the other's exchange is in flight -- at ONE wavefront per SIMD, which is what this kernel runs at, that is where the idle time was), both teams hand
+// their pair over through LDS and multiply-accumulate the four rows of the double phase in row order: the same butterflies, digits and fma chain as
+// pbs_wide_team_kernel, pbs_kernel and the oracle -- bit-identical.  A double phase is 4 rows: team w owns rows 4 d + w (x) and 4 d + 2 + w (y) (one accumulator
+// component, two levels: the rotated accumulator words are read once for both), so that both x rows -- rows 0 and 1 of the chain -- are handed over first and are
+// multiplied while the y rows land.  One workgroup per CU (137 KiB of LDS: two exchange buffers, four
+// hand-over buffers, the accumulator, the twiddle table) and up to 512 registers per lane: all four key rows of a double phase are requested before its transforms.
+// ------------------------------------------------------------------------------------------------------------
+template <class F, int L, int BG>
+__global__ __launch_bounds__(2 * F::THREADS) void pbs_wide_pair_kernel(PbsParams p) {
+  static_assert(F::kForward2 && F::kLtw && L % 2 == 0, "row pairs need the pipelined forward pair and an even gadget length");
+  constexpr int N = F::N, M = F::M, T = F::THREADS, LOG2N2 = F::LOGM + 2, R = 2 * L, DPH = R / 4, WG = 2 * T;
+  constexpr bool kReduce = !(BG > 0 && kCeilLog2<2 * L>::value + (F::LOGM + 1) + BG - 1 + 63 < 83);   // see pbs_kernel
+  extern __shared__ __attribute__((aligned(16))) unsigned char wide_lds[];
+  d2 *xch_all = reinterpret_cast<d2 *>(wide_lds);                                   // [2][F::XCH_SLOTS]
+  d2 *hand = xch_all + (size_t)2 * F::XCH_SLOTS;                                    // [4][M]: row r of the double phase
+  uint64_t *acc = reinterpret_cast<uint64_t *>(hand + (size_t)4 * M);               // [2][N]
+  const int tid = threadIdx.x, team = __builtin_amdgcn_readfirstlane(tid / T), t = tid % T;
+  d2 *xch = xch_all + (size_t)team * F::XCH_SLOTS;
+  const size_t b = blockIdx.x;
+  const uint64_t *__restrict__ ct = p.in + (p.rows > 1 ? b / (size_t)p.rows : b) * (size_t)(p.n + 1);
+  const int Bg_bit = BG > 0 ? BG : p.Bg_bit;
+  F fft;
+  fft_setup(fft, p.tw, t);
+  if (p.skip_init) {
+    const uint64_t *src = p.out + b * (size_t)(2 * N);
+    for (int x = tid; x < 2 * N; x += WG) acc[x] = src[x];
+  } else {
+    const uint64_t *__restrict__ tv = p.rows > 1 ? p.tv + (b % (size_t)p.rows) * (size_t)(2 * N) : p.tv + b * (size_t)p.tv_stride;
+    const uint32_t bbar = modswitch<LOG2N2>(pbs_pre(ct[p.n], p, LOG2N2) + p.prec_offset);
+    const int rot = (2 * N - (int)bbar) & (2 * N - 1);
+    const int a_lo = rot & (N - 1);
+    const bool flip = (rot & N) != 0;
+    for (int x = tid; x < 2 * N; x += WG) acc[x] = rot_coeff<N>(tv + (x / N) * N, x & (N - 1), a_lo, flip);
+  }
+  __syncthreads();
+  uint64_t off = 1ull << (63 - L * Bg_bit);
+#pragma unroll
+  for (int i = 0; i < L; i++) off += 1ull << (63 - i * Bg_bit);
+  const RoundCtx scale(0x1p-64 / (double)M);
+  const size_t row_sz = (size_t)2 * L * 2 * M;
+  const uint32_t mask = (1u << Bg_bit) - 1;
+  const int half = 1 << (Bg_bit - 1);
+  for (int i = 0; i < p.n; i++) {
+    const int abar = (int)modswitch<LOG2N2>(pbs_pre(ct[i], p, LOG2N2));
+    if (!abar) continue;   // src/bootstrap.c:114 (uniform over the workgroup)
+    const d2 *__restrict__ bkrow = p.bk + (size_t)i * row_sz;
+    const int a_lo = abar & (N - 1);
+    const bool flip = (abar & N) != 0;
+    double o_re[8], o_im[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) { o_re[m] = 0.0; o_im[m] = 0.0; }
+#pragma unroll
+    for (int dp = 0; dp < DPH; dp++) {
+      d2 kk[4][8];   // this team's output component of the double phase's four key rows
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int m = 0; m < 8; m++) kk[r][m] = bkrow[(size_t)(4 * dp + r) * (2 * M) + (size_t)team * M + m * T + t];
+      // rows rx (x) and rx + 2 (y): L is even, so both teams' x rows lie in one accumulator component and both y rows in one (the same one unless L % 4 != 0)
+      const int rx = 4 * dp + team, ry = rx + 2, qx = (4 * dp) / L, qy = (4 * dp + 2) / L, sx = 64 - (rx % L + 1) * Bg_bit, sy = 64 - (ry % L + 1) * Bg_bit;
+      double xr[8], xi[8], yr[8], yi[8];
+      {
+        const uint64_t *accx = acc + (size_t)qx * N, *accy = acc + (size_t)qy * N;
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          const int j = m * T + t;
+          const uint64_t d_lo = rot_coeff<N>(accx, j, a_lo, flip) - accx[j] + off;
+          const uint64_t d_hi = rot_coeff<N>(accx, j + M, a_lo, flip) - accx[j + M] + off;
+          xr[m] = (double)((int)((uint32_t)(d_lo >> sx) & mask) - half);
+          xi[m] = (double)((int)((uint32_t)(d_hi >> sx) & mask) - half);
+          const uint64_t e_lo = qy == qx ? d_lo : rot_coeff<N>(accy, j, a_lo, flip) - accy[j] + off;
+          const uint64_t e_hi = qy == qx ? d_hi : rot_coeff<N>(accy, j + M, a_lo, flip) - accy[j + M] + off;
+          yr[m] = (double)((int)((uint32_t)(e_lo >> sy) & mask) - half);
+          yi[m] = (double)((int)((uint32_t)(e_hi >> sy) & mask) - half);
+        }
+      }
+      fft.forward2_head(xr, xi, yr, yi, xch, t);
+      fft.pass_d_fwd(xr, xi);
+      d2 *hx = hand + (size_t)team * M, *hy = hand + (size_t)(2 + team) * M;   // hand-over buffer r holds row 4 dp + r
+#pragma unroll
+      for (int m = 0; m < 8; m++) hx[m * T + t] = d2{xr[m], xi[m]};
+      fft.forward2_fetch(yr, yi, xch, t);
+      fft.pass_d_fwd(yr, yi);
+      F::forward2_done();   // (a workgroup barrier: both teams' x rows are handed over)
+#pragma unroll
+      for (int m = 0; m < 8; m++) hy[m * T + t] = d2{yr[m], yi[m]};
+#pragma unroll
+      for (int r = 0; r < 2; r++) {   // fma chain over the double phase's rows in order: the x rows (0, 1) while the y rows land
+        const d2 *__restrict__ dr = hand + (size_t)r * M;
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          const d2 d = dr[m * T + t], k = kk[r][m];
+          o_re[m] = __builtin_fma(-d.y, k.y, __builtin_fma(d.x, k.x, o_re[m]));
+          o_im[m] = __builtin_fma(d.y, k.x, __builtin_fma(d.x, k.y, o_im[m]));
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 2; r < 4; r++) {
+        const d2 *__restrict__ dr = hand + (size_t)r * M;
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          const d2 d = dr[m * T + t], k = kk[r][m];
+          o_re[m] = __builtin_fma(-d.y, k.y, __builtin_fma(d.x, k.x, o_re[m]));
+          o_im[m] = __builtin_fma(d.y, k.x, __builtin_fma(d.x, k.y, o_im[m]));
+        }
+      }
+      __syncthreads();   // the hand-over buffers are consumed
+    }
+    fft.inverse(o_re, o_im, xch, t);
+    uint64_t *accw = acc + (size_t)team * N;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      accw[m * T + t] = add_rounded<kReduce>(accw[m * T + t], o_re[m], scale);
+      accw[M + m * T + t] = add_rounded<kReduce>(accw[M + m * T + t], o_im[m], scale);
+    }
+    __syncthreads();
+  }
+  if (p.extract) {
+    uint64_t *dst = p.out + b * (size_t)(N + 1);
+    for (int j = tid; j < N; j += WG) dst[j] = (j == 0) ? acc[0] : (0 - acc[N - j]);
+    if (tid == 0) dst[N] = acc[N];
+  } else {
+    uint64_t *dst = p.out + b * (size_t)(2 * N);
+    for (int x = tid; x < 2 * N; x += WG) dst[x] = acc[x];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Galois-automorphism bootstrap [src/bootstrap_ga.c:39-76] and its building blocks:
 //   trlwe_keyswitch          [src/keyswitch.c:162-193]  out = (0, b) - IDFT(sum_j DFT(digit_j(a)) (.) KS[j])
 //   trlwe_eval_automorphism  [src/trlwe.c:775-781, src/polynomial.c:442-450]  X -> X^gen on both components, then

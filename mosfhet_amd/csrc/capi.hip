@@ -618,8 +618,45 @@ static int launch_wide_team(const PbsParams &p, int count, hipStream_t s) {
 }
 // bounded: see launch_external_product -- at N = 1024 the compile-time 2 x 2^8 instantiation rounds without the reduction mod 1, which only keys this
 // library transformed itself allow; key views over caller-held TRGSW_DFT sums take the reducing run-time-gadget instantiation
+// N = 2048, even gadget lengths, at most one workgroup per CU: the teams take their rows two at a time (pbs_wide_pair_kernel).  MOSFHET_HIP_WIDE_PAIRS=0 / 1.
+static int wide_pairs_enabled() {
+  static std::atomic<int> v{-1};
+  int r = v.load(std::memory_order_relaxed);
+  if (r < 0) { const char *e = getenv("MOSFHET_HIP_WIDE_PAIRS"); r = e ? (atoi(e) != 0) : 1; v.store(r, std::memory_order_relaxed); }
+  return r;
+}
+static int device_cus() {   // CUs of the current device (cached per device id)
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  int c = cache[dev].load(std::memory_order_relaxed);
+  if (c == 0) {
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) return 0;
+    cache[dev].store(c, std::memory_order_relaxed);
+  }
+  return c;
+}
+template <int LL, int BB>
+static int launch_wide_pair(const PbsParams &p, int count, hipStream_t s) {
+  using F = Fft2048L;
+  constexpr size_t lds = sizeof(d2) * ((size_t)2 * F::XCH_SLOTS + (size_t)4 * F::M) + sizeof(uint64_t) * 2 * F::N;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_wide_pair_kernel<F, LL, BB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((pbs_wide_pair_kernel<F, LL, BB>), dim3((unsigned)count), dim3(2 * F::THREADS), lds, s, p);
+  HIP_TRY(hipGetLastError());
+  return MOSFHET_HIP_OK;
+}
+
 template <class F>
 static int launch_wide_team_f(int l, int Bg, const PbsParams &p, int count, hipStream_t s, bool bounded) {
+  if constexpr (F::N == 2048) {
+    // one workgroup per CU (137 KiB of LDS each): up to as many ciphertexts as the device has CUs; beyond that pbs_wide_team_kernel runs two workgroups per CU
+    if (wide_pairs_enabled() && l % 2 == 0 && count <= device_cus()) {
+      if (l == 4 && Bg == 9) return launch_wide_pair<4, 9>(p, count, s);
+      if (l == 2) return launch_wide_pair<2, 0>(p, count, s);
+      if (l == 4) return launch_wide_pair<4, 0>(p, count, s);
+      if (l == 6) return launch_wide_pair<6, 0>(p, count, s);
+    }
+  }
   if (l == 4 && Bg == 9) return launch_wide_team<F, 4, 9>(p, count, s);
   if (l == 2 && Bg == 8 && (bounded || F::N != 1024)) return launch_wide_team<F, 2, 8>(p, count, s);
   if (l == 1 && Bg == 23) return launch_wide_team<F, 1, 23>(p, count, s);
