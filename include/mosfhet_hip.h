@@ -335,6 +335,14 @@ int mosfhet_hip_set_team_max_batch(int max_batch);
 /* the same switch-over for N = 2048 and, at half the value, N = 4096 (one workgroup of two transform teams per ciphertext; default 512, MOSFHET_HIP_WIDE_TEAM_MAX; 0 disables) */
 int mosfhet_hip_set_wide_team_max_batch(int max_batch);
 
+/* Unit-loop form of the external-product kernel on rings of two wavefronts per team (N = 2048, l = 4; trgsw_mul_trlwe_DFT, src/trgsw.c:385-423).  The
+ * software-pipelined loop is taken only by the instantiation that has been soaked clean and only while its build has no scratch (capi.hip: ep_go); the plain
+ * loop gives the same bits 11 % slower.  set_ep_plain_loop(1) forces the plain loop for every multi-wavefront instantiation (tests run both in one
+ * process; MOSFHET_HIP_EP_PAIRS=0 does the same for a whole process).  ep_kernel_info(i, ...) reports, for the i-th such instantiation launched so far,
+ * its name, the scratch bytes per lane of its pipelined build and whether the launcher takes that build; MOSFHET_HIP_EINVAL past the end. */
+int mosfhet_hip_set_ep_plain_loop(int on);
+int mosfhet_hip_ep_kernel_info(int i, const char **name, int *scratch_bytes, int *takes_pipelined);
+
 /* The canonical caller pattern in one call (applications/multi-ciphertext-arith/src/integer.c:94-95): tlwe_keyswitch kN -> n, then
  * functional_bootstrap (extract = 1: d_out [count][kN+1]) or functional_bootstrap_wo_extract (extract = 0: d_out [count][k+1][N]);
  * same stream, no host synchronisation in between. */

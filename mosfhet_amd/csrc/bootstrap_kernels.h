@@ -1443,9 +1443,6 @@ __global__ __launch_bounds__(F::THREADS) void dft_to_torus_kernel(const d2 *__re
 #ifndef EP_ONE_K
 #define EP_ONE_K false
 #endif
-#ifndef EP_PIPE_ALL
-#define EP_PIPE_ALL false   // experiment switch (tools/ab/ep_ab.hip): the software-pipelined unit loop on every ring
-#endif
 #ifdef MOSFHET_EP_NO_NT
 #define EP_NT_LOAD(p) (*(p))
 #define EP_NT_STORE(v, p) (*(p) = (v))
@@ -1456,7 +1453,16 @@ __global__ __launch_bounds__(F::THREADS) void dft_to_torus_kernel(const d2 *__re
 #ifndef EP_MIN_WAVES
 #define EP_MIN_WAVES 2
 #endif
-template <class F, int L, int BG, bool CMUX>
+// The unit loop comes in two forms: PLAIN (each component requested where it is used) and PIPELINED (the next component always in flight under the rows of the
+// current one).  FORM = 0 takes the form ep_pipelined_by_default() names, 1 forces the plain loop (the launcher's fall-back, capi.hip: ep_form), 2 forces the
+// pipelined one (experiments only: tools/ab/ep_ab.hip, tools/spill_hazard).
+template <class F, int L, bool CMUX>
+constexpr bool ep_pipelined_by_default() {
+  // one-wavefront teams always; two-wavefront teams with the rows taken in pairs (pass twiddles in LDS) at l = 4 without the CMUX operand -- the one multi-wavefront
+  // instantiation that is faster pipelined AND has been soaked (tools/soak.py); see the note in the kernel body
+  return F::THREADS == 64 || (F::kForward2 && F::kLtw && L % 2 == 0 && !CMUX && L == 4);
+}
+template <class F, int L, int BG, bool CMUX, int FORM = 0>
 __global__ __launch_bounds__(F::THREADS, EP_MIN_WAVES) void external_product_kernel(const d2 *__restrict__ bkrow0, const d2 *__restrict__ tw,
                                                                        const uint64_t *__restrict__ in, uint64_t *out, int Bg_bit_rt, int count,
                                                                        size_t key_stride = 0, size_t in_stride = 2 * F::N,
@@ -1477,7 +1483,7 @@ __global__ __launch_bounds__(F::THREADS, EP_MIN_WAVES) void external_product_ker
   // rows two at a time + the software-pipelined unit loop: transforms with the pass twiddles in LDS (Fft2048L: the registers that makes free are what
   // both need); the launcher picks that type for the gadgets where the build has no scratch
   constexpr bool kPairs = F::kForward2 && F::kLtw && L % 2 == 0;
-  constexpr bool kPipe = T == 64 || EP_PIPE_ALL || (kPairs && !CMUX && L == 4);   // (CMUX and other lengths keep the plain loop: pipelined, those builds spill)
+  constexpr bool kPipe = FORM == 2 || (FORM == 0 && ep_pipelined_by_default<F, L, CMUX>());
 
   // Software pipeline over the team's units: the 8 KiB of a component are requested one phase before they are needed and wait in registers as raw
   // words (32 VGPRs) only until they arrive, then as packed digit words (16) -- so a team always has half a ciphertext in flight from HBM.

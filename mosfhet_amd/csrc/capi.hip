@@ -125,8 +125,8 @@ struct mosfhet_hip_bsk {
   int unfolding = 1;          // > 1: d_bk is null and d_su holds the torus-domain samples of new_bootstrap_key (src/bootstrap.c:23-48)
   uint64_t *d_su = nullptr;   // [n 2^u / u][2l][2][N]
   d2 *d_su_dft = nullptr;     // unfolding 2: the same samples transformed, [n / 2][4][2l][2][8][T] (unfold_kernels.h); the rotation reads these, UBR phase 1 reads d_su
-  std::mutex su_dft_lock;     // ... made on the first rotation that reads them (unfold2_ready): a key that only ever takes the torus-domain path
-  std::atomic<int> su_dft_ready{0};   // (MOSFHET_HIP_UNFOLD2_DFT=0) never pays for the second copy
+  std::mutex su_dft_lock;     // ... made at creation / cloning (unfold2_ready); a key made under MOSFHET_HIP_UNFOLD2_DFT=0 (torus-domain path) does not pay
+  std::atomic<int> su_dft_ready{0};   // for the second copy unless the DFT path is switched on later
   size_t bytes = 0;
   bool general = false;       // k > 1 or a ring without a tuned kernel: natural slot order, general_kernels.h (bootstraps and external products only)
   bool owns = true;           // false: d_bk belongs to the caller (mosfhet_hip_bsk_view_create)
@@ -400,13 +400,70 @@ extern "C" int mosfhet_hip_bsk_export_dft(mosfhet_hip_bsk_t bsk, double *h_out) 
 // ---- external-product launches ----
 // Persistent teams (external_product_kernel): the grid is the chip's resident capacity -- 2 wavefronts per SIMD, i.e. CUs x 8 / (wavefronts per team)
 // teams -- capped by the batch; gadgets of the reference's parameter sets get the compile-time instantiation.
-static int resident_teams(int threads) {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+static int device_cus() {   // CUs of the current device (cached per device id)
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  int c = cache[dev].load(std::memory_order_relaxed);
+  if (c == 0) {
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) return 0;
+    cache[dev].store(c, std::memory_order_relaxed);
   }
-  return cus * 8 / (threads / 64);
+  return c;
+}
+static int resident_teams(int threads) {
+  const int cus = device_cus();
+  return (cus > 0 ? cus : 256) * 8 / (threads / 64);
+}
+
+// Scratch bytes per lane of a kernel of this library (hipFuncAttributes::localSizeBytes = the code object's private_segment_fixed_size), asked once per
+// instantiation: the code object is the same on every device.  -1 when the runtime cannot say.
+template <class K>
+static int kernel_scratch_bytes(K kernel) {
+  hipFuncAttributes a;
+  if (hipFuncGetAttributes(&a, reinterpret_cast<const void *>(kernel)) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  return (int)a.localSizeBytes;
+}
+
+// Which unit loop a multi-wavefront external-product instantiation takes (external_product_kernel: FORM).  The software-pipelined loop on rings of two or four
+// wavefronts has a failure mode that is not understood to the end (1 - 2 % of the units of a launch wrong on the l = 1 builds of N = 2048 / 4096 when several
+// workgroups share a CU; bootstrap_kernels.h, experiments/README.md "Round 5"): the launcher takes it only for the instantiation that has been soaked clean
+// (tools/soak.py) AND only while that instantiation is what was soaked -- a build without scratch.  A compiler that starts spilling there changes the schedule into one
+// nobody has measured: the plain loop then (always bit-exact, 11 % slower at lvl2).  MOSFHET_HIP_EP_PAIRS=0 forces the plain loop as well.
+struct EpKernelInfo { const char *name; int pipelined_by_default, scratch_bytes, takes_pipelined; };
+static std::mutex g_ep_info_lock;
+static std::vector<EpKernelInfo> g_ep_info;   // every instantiation that has been asked about (mosfhet_hip_ep_kernel_info)
+template <class F, int L, int BG, bool CMUX>
+static bool ep_multiwave_pipelined_ok(const char *name) {
+  static std::atomic<int> verdict{-1};
+  int v = verdict.load(std::memory_order_acquire);
+  if (v < 0) {
+    const char *e = getenv("MOSFHET_HIP_EP_PAIRS");
+    const int scratch = kernel_scratch_bytes(external_product_kernel<F, L, BG, CMUX, 0>);
+    v = (scratch == 0 && !(e && e[0] == '0')) ? 1 : 0;
+    std::lock_guard<std::mutex> hold(g_ep_info_lock);
+    if (verdict.load(std::memory_order_relaxed) < 0) g_ep_info.push_back(EpKernelInfo{name, 1, scratch, v});
+    verdict.store(v, std::memory_order_release);
+  }
+  return v == 1;
+}
+
+static std::atomic<int> g_ep_plain_loop{0};   // mosfhet_hip_set_ep_plain_loop: every multi-wavefront instantiation takes the plain loop (tests run both forms in one process)
+extern "C" int mosfhet_hip_set_ep_plain_loop(int on) {
+  g_ep_plain_loop.store(on ? 1 : 0, std::memory_order_relaxed);
+  return MOSFHET_HIP_OK;
+}
+
+template <class FF, int LL, int BB, bool CM>
+static void ep_go(const char *name, dim3 grid, dim3 block, hipStream_t s, const d2 *row, const d2 *tw, const uint64_t *d_in, uint64_t *d_out, int Bg_bit, int count, size_t key_stride,
+                  size_t in_stride, const uint64_t *d_in0, d2 *d_out_dft) {
+  if constexpr (FF::THREADS > 64 && ep_pipelined_by_default<FF, LL, CM>()) {
+    if (!ep_multiwave_pipelined_ok<FF, LL, BB, CM>(name) || g_ep_plain_loop.load(std::memory_order_relaxed)) {
+      hipLaunchKernelGGL((external_product_kernel<FF, LL, BB, CM, 1>), grid, block, 0, s, row, tw, d_in, d_out, Bg_bit, count, key_stride, in_stride, d_in0, d_out_dft);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((external_product_kernel<FF, LL, BB, CM, 0>), grid, block, 0, s, row, tw, d_in, d_out, Bg_bit, count, key_stride, in_stride, d_in0, d_out_dft);
 }
 
 template <class F>
@@ -439,20 +496,17 @@ static void launch_external_product(int l, int Bg_bit, hipStream_t s, const d2 *
   const bool unbounded_2x8 = Bg_bit < 0;
   if (unbounded_2x8) Bg_bit = -Bg_bit;
   const dim3 grid((unsigned)(count < cap ? count : cap)), block(F::THREADS);
-#define EP_GO_F(FF, LL, BB)                                                                                                                              \
-  do {                                                                                                                                                   \
-    if (d_in0) hipLaunchKernelGGL((external_product_kernel<FF, LL, BB, true>), grid, block, 0, s, row, tw, d_in, d_out, Bg_bit, count, key_stride, in_stride, d_in0, d_out_dft);   \
-    else hipLaunchKernelGGL((external_product_kernel<FF, LL, BB, false>), grid, block, 0, s, row, tw, d_in, d_out, Bg_bit, count, key_stride, in_stride, d_in0, d_out_dft);      \
+#define EP_GO_F(FF, LL, BB)                                                                                                                                        \
+  do {                                                                                                                                                             \
+    if (d_in0) ep_go<FF, LL, BB, true>("external_product_kernel<" #FF ", " #LL ", " #BB ", cmux>", grid, block, s, row, tw, d_in, d_out, Bg_bit, count, key_stride, in_stride, d_in0, d_out_dft); \
+    else ep_go<FF, LL, BB, false>("external_product_kernel<" #FF ", " #LL ", " #BB ">", grid, block, s, row, tw, d_in, d_out, Bg_bit, count, key_stride, in_stride, d_in0, d_out_dft);        \
   } while (0)
 #define EP_GO(LL, BB) EP_GO_F(F, LL, BB)
   if constexpr (std::is_same<F, Fft2048>::value) {
     // N = 2048, l = 4 (lvl2): rows two at a time with the pass twiddles in LDS and, outside the CMUX form, the pipelined unit loop
-    // (external_product_kernel: kPairs / kPipe; bit-identical, no scratch; lvl2: 0.437 against 0.492 ms per 16,384 units in a same-box A/B).
-    // MOSFHET_HIP_EP_PAIRS=0 keeps the plain kernel.
-    static int pairs = -1;
-    if (pairs < 0) { const char *e = getenv("MOSFHET_HIP_EP_PAIRS"); pairs = (e && e[0] == '0') ? 0 : 1; }
-    if (pairs && l == 4 && Bg_bit == 9) { EP_GO_F(Fft2048L, 4, 9); return; }
-    if (pairs && l == 4) { EP_GO_F(Fft2048L, 4, 0); return; }   // (other even lengths: not measured; their pipelined builds spill)
+    // (external_product_kernel: kPairs / kPipe; bit-identical; lvl2: 0.437 against 0.492 ms per 16,384 units in a same-box A/B), guarded by ep_go.
+    if (l == 4 && Bg_bit == 9) { EP_GO_F(Fft2048L, 4, 9); return; }
+    if (l == 4) { EP_GO_F(Fft2048L, 4, 0); return; }   // (other even lengths: not measured)
   }
   if (l == 2 && Bg_bit == 8 && !unbounded_2x8) EP_GO(2, 8);
   else if (l == 4 && Bg_bit == 9) EP_GO(4, 9);
@@ -467,6 +521,17 @@ static void launch_external_product(int l, int Bg_bit, hipStream_t s, const d2 *
 #undef EP_GO_F
 }
 
+// What the launcher decided for the multi-wavefront instantiations that take the pipelined unit loop by default, for tests and tools: entry i of those asked about so
+// far (an instantiation is asked about at its first launch).  Returns MOSFHET_HIP_EINVAL past the end.
+extern "C" int mosfhet_hip_ep_kernel_info(int i, const char **name, int *scratch_bytes, int *takes_pipelined) {
+  std::lock_guard<std::mutex> hold(g_ep_info_lock);
+  if (i < 0 || (size_t)i >= g_ep_info.size()) return MOSFHET_HIP_EINVAL;
+  if (name) *name = g_ep_info[i].name;
+  if (scratch_bytes) *scratch_bytes = g_ep_info[i].scratch_bytes;
+  if (takes_pipelined) *takes_pipelined = g_ep_info[i].takes_pipelined;
+  return MOSFHET_HIP_OK;
+}
+
 // ---- bootstrap launches ----
 // One launch per residency round when the key does not fit the L2s (N >= 2048).  All teams walk the key rows in the same order and
 // share each row through their XCD's L2 while they stay close together; in one big launch the teams of later rounds start as earlier
@@ -474,14 +539,12 @@ static void launch_external_product(int l, int Bg_bit, hipStream_t s, const d2 *
 // fabric reads; one round alone: 96 %, 7 GB).  Kernel boundaries re-align the teams: 79 -> 74 ms.  A round = CUs x resident teams
 // per CU (LDS-limited: 4 at N = 2048, 2 at N = 4096).  MOSFHET_HIP_ROUND_CHUNK overrides (0 = single launch).
 static int round_chunk(int threads) {
-  static int cus = 0, env = -2;
-  if (env == -2) { const char *e = getenv("MOSFHET_HIP_ROUND_CHUNK"); env = e ? atoi(e) : -1; }
-  if (env >= 0) return env;
-  if (!cus) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-  }
-  return threads == 128 ? 4 * cus : 0;   // N = 4096 (2 teams per CU) measured slower in rounds (tail idling): single launch
+  static std::atomic<int> env{-2};
+  int e = env.load(std::memory_order_relaxed);
+  if (e == -2) { const char *v = getenv("MOSFHET_HIP_ROUND_CHUNK"); e = v ? atoi(v) : -1; if (e < -1) e = -1; env.store(e, std::memory_order_relaxed); }
+  if (e >= 0) return e;
+  const int cus = device_cus();   // of the current device (several devices in one process: mosfhet_compat_multi.c)
+  return threads == 128 ? 4 * (cus > 0 ? cus : 256) : 0;   // N = 4096 (2 teams per CU) measured slower in rounds (tail idling): single launch
 }
 
 // Teams of one residency round re-align every K CMUX steps (pace_teams, bootstrap_kernels.h): kernel boundaries alone leave them drifting apart inside
@@ -540,7 +603,7 @@ static void launch_pbs(const PbsParams &p_in, int count, hipStream_t s) {
   p.pace_limit = pace_limit();
   if (chunk > 0 && count > chunk) {
     // row mode (TRGSW accumulators, per-level test vectors: block b takes input b / rows and test vector b % rows of ONE shared set): rounds of whole inputs
-    const int rows = p.rows > 1 ? p.rows : 1, step = chunk - chunk % rows;
+    const int rows = p.rows > 1 ? p.rows : 1, step = chunk < rows ? rows : chunk - chunk % rows;   // (a chunk below one input's rows: one input per launch)
     const size_t out_row = p.extract ? (size_t)F::N + 1 : (size_t)2 * F::N;
     for (int lo = 0; lo < count; lo += step) {
       PbsParams q = p;
@@ -624,17 +687,6 @@ static int wide_pairs_enabled() {
   int r = v.load(std::memory_order_relaxed);
   if (r < 0) { const char *e = getenv("MOSFHET_HIP_WIDE_PAIRS"); r = e ? (atoi(e) != 0) : 1; v.store(r, std::memory_order_relaxed); }
   return r;
-}
-static int device_cus() {   // CUs of the current device (cached per device id)
-  static std::atomic<int> cache[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-  int c = cache[dev].load(std::memory_order_relaxed);
-  if (c == 0) {
-    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) return 0;
-    cache[dev].store(c, std::memory_order_relaxed);
-  }
-  return c;
 }
 template <int LL, int BB>
 static int launch_wide_pair(const PbsParams &p, int count, hipStream_t s) {
@@ -1185,9 +1237,11 @@ static bool cb_levels_together(int count, int l) {
 }
 // circuit_bootstrap / FDFB KS21_2 (one bootstrap per level): the l bootstraps of an input side by side in row mode -- one launch, or residency rounds of whole inputs
 // (launch_pbs) -- instead of l launches of fewer than a round's worth of ciphertexts (capi_ext.inc)
-static bool cb_bootstraps_together(int count, int l) {
+// Row mode belongs to the folded bootstrap kernels: an unfolded key (bootstrap_unfolded) keeps one launch per level, as the reference's
+// functional_bootstrap dispatches on key->unfolding underneath circuit_bootstrap and the full-domain bootstraps (src/bootstrap.c:196-197,313-317,476-478).
+static bool cb_bootstraps_together(mosfhet_hip_bsk_t bsk, int count, int l) {
   const char *e = getenv("MOSFHET_HIP_CB_TOGETHER");
-  return l > 1 && count < 1024 && !(e && atoi(e) == 0);   // (from 1024 on, l launches of count ARE l count / 1024 residency rounds)
+  return bsk->unfolding == 1 && l > 1 && count < 1024 && !(e && atoi(e) == 0);   // (from 1024 on, l launches of count ARE l count / 1024 residency rounds)
 }
 
 // test vector of circuit_bootstrap_3 (src/bootstrap.c:350-355): 2l slots, slot l + i = 2^(64 - (i+1) Bg), slots < l zero

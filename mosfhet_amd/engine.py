@@ -716,6 +716,21 @@ def set_wide_team_max_batch(max_batch):
     _check(lib().mosfhet_hip_set_wide_team_max_batch(int(max_batch)))
 
 
+def set_ep_plain_loop(on):
+    """external products on two-wavefront teams (N = 2048, l = 4): the plain unit loop instead of the software-pipelined one (same bits)"""
+    _check(lib().mosfhet_hip_set_ep_plain_loop(int(bool(on))))
+
+
+def ep_kernel_info():
+    """[(name, scratch bytes per lane of the pipelined build, launcher takes it)] of the multi-wavefront external-product instantiations launched so far"""
+    out, i = [], 0
+    name, scratch, takes = C.c_char_p(), C.c_int(), C.c_int()
+    while lib().mosfhet_hip_ep_kernel_info(i, C.byref(name), C.byref(scratch), C.byref(takes)) == 0:
+        out.append((name.value.decode(), scratch.value, bool(takes.value)))
+        i += 1
+    return out
+
+
 def twiddles(N):
     out = np.empty(2 * (N // 2 - 1), dtype=np.float64)
     _check(lib().mosfhet_hip_twiddles(N, out.ctypes.data_as(C.c_void_p)))

@@ -133,6 +133,27 @@ def test_host_helpers_are_clean_under_sanitizers(native_lib, tmp_path):
     assert "exponent of TRGSW(X^5): 5" in r.stdout
 
 
+def test_kernel_table_of_the_build(native_lib):
+    """The built library's own kernel table (tools/kernel_table.py: code-object metadata, no GPU).  What the launcher ASSUMES of the build is held here, so that a
+    toolchain change shows up on the CPU box and not as a silent change of the kernels that run:
+      * the software-pipelined unit loop on two-wavefront teams (external_product_kernel<Fft2048L, 4, *, no CMUX>, FORM 0) is taken only while that build has no
+        scratch (capi.hip: ep_go falls back to the plain loop otherwise: correct, 11 % slower at lvl2) -- today it has none;
+      * its fall-back (FORM 1) exists for exactly those instantiations;
+      * no kernel has been built for more than 256 registers' worth of occupancy it does not get (AGPRs unused everywhere)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_table
+    rows = kernel_table.table()
+    by_name = {r["name"]: r for r in rows}
+    piped = [r for r in rows if r["name"].startswith("external_product_kernel<Fft2048T<false, true>, 4, ") and r["name"].endswith(", false, 0>")]
+    assert len(piped) == 2, [r["name"] for r in piped]
+    for r in piped:
+        assert r["scratch"] == 0, "%s now spills %d bytes: the launcher will run the plain loop (re-measure, re-soak: tools/soak.py)" % (r["name"], r["scratch"])
+        assert r["name"][:-2] + "1>" in by_name, "no plain-loop fall-back for " + r["name"]
+    assert all(r["agpr"] == 0 for r in rows)
+    assert len(rows) < 330, "%d kernel instantiations" % len(rows)
+
+
 def test_no_cpu_fallback(native_lib):
     import torch
     import mosfhet_amd as ma

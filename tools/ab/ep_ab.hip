@@ -10,6 +10,9 @@ using namespace mosfhet;
 #ifndef AB_BG
 #define AB_BG 8
 #endif
+#ifndef AB_FORM
+#define AB_FORM 0   // 1: plain unit loop, 2: software-pipelined unit loop on any ring (external_product_kernel: FORM)
+#endif
 #if AB_N == 1024
 using ABF = Fft1024;
 #elif AB_N == 2048
@@ -18,13 +21,14 @@ using ABF = Fft2048;
 using ABF = Fft4096;
 #endif
 extern "C" int ab_ep_bg_rt = 0;   // run-time gadget base of AB_BG = 0 builds
+extern "C" const uint64_t *ab_ep_in0 = nullptr;   // passed as `in0` (unused without CMUX): the debug buffer of tools/spill_hazard
 extern "C" int ab_ep(const double *d_row, const double *d_tw, const uint64_t *d_in, uint64_t *d_out, int count, int grid, int reps, float *ms_per_launch) {
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1;
   hipEventRecord(e0, nullptr);
   for (int r = 0; r < reps; r++)
-    hipLaunchKernelGGL((external_product_kernel<ABF, AB_L, AB_BG, false>), dim3((unsigned)grid), dim3(ABF::THREADS), 0, nullptr, (const d2 *)d_row, (const d2 *)d_tw, d_in, d_out,
-                       AB_BG ? AB_BG : ab_ep_bg_rt, count, (size_t)0, (size_t)(2 * ABF::N), (const uint64_t *)nullptr, (d2 *)nullptr);
+    hipLaunchKernelGGL((external_product_kernel<ABF, AB_L, AB_BG, false, AB_FORM>), dim3((unsigned)grid), dim3(ABF::THREADS), 0, nullptr, (const d2 *)d_row, (const d2 *)d_tw, d_in, d_out,
+                       AB_BG ? AB_BG : ab_ep_bg_rt, count, (size_t)0, (size_t)(2 * ABF::N), ab_ep_in0, (d2 *)nullptr);
   hipEventRecord(e1, nullptr);
   if (hipEventSynchronize(e1) != hipSuccess) return -2;
   float ms = 0.f;

@@ -131,9 +131,37 @@ def run_ep(B, rounds, grids, pset="set1", names=None):
                 for grid in gr:
                     ms = C.c_float()
                     out.zero_()
+                    dbg = None
+                    if "verify" in name:   # tools/spill_hazard verify_keys: 64 bytes per thread {used quad, true quad, quad + 1, unit counter}
+                        dbg = torch.zeros(8 + grid * 1024, dtype=torch.int64, device=eng.device)
+                        C.c_void_p.in_dll(lib, "ab_ep_in0").value = dbg.data_ptr()
+                    if "mirror" in name:   # tools/spill_hazard: mismatch counter + samples come back through the (otherwise unused) in0 argument
+                        dbg = torch.zeros(8 + grid * 512, dtype=torch.int64, device=eng.device)
+                        C.c_void_p.in_dll(lib, "ab_ep_in0").value = dbg.data_ptr()
                     rc = getattr(lib, fn)(C.c_void_p(d_row), C.c_void_p(d_tw.data_ptr()), C.c_void_p(d_in.data_ptr()), C.c_void_p(out.data_ptr()), B, grid, reps, C.byref(ms))
                     assert rc == 0, (name, fn, rc)
                     ok = bool((out == want).all())
+                    if dbg is not None and "verify" in name:
+                        d32 = ma.to_numpy(dbg).view(np.uint32)
+                        rec = d32[16:].reshape(grid * 128, 16)
+                        hit = np.nonzero(rec[:, 8] != 0)[0]
+                        print("   %s grid %d round %d: lanes whose key quad differed at its use from the drained re-read (over %d launches): %d; threads with a sample %d; bit-exact %s" % (name, grid, r, reps, int(d32[0]), len(hit), ok))
+                        for i in hit[:10]:
+                            print("      block %d thread %d quad %d unit+grid %d: used %s  true %s" % (i // 128, i % 128, rec[i, 8] - 1, rec[i, 9], " ".join("%08x" % x for x in rec[i, 0:4]), " ".join("%08x" % x for x in rec[i, 4:8])))
+                        if len(hit):
+                            blocks = np.unique(hit // 128)
+                            print("      blocks: %d distinct, below 256: %d; quads %s; lanes per hit block (first 8) %s" % (len(blocks), int((blocks < 256).sum()), np.bincount(rec[hit, 8] - 1, minlength=6).tolist(), [int((hit // 128 == b).sum()) for b in blocks[:8]]))
+                        dbg = None
+                    if dbg is not None:
+                        d = ma.to_numpy(dbg).view(np.uint64)
+                        rec = d[8:].reshape(grid * 128, 4)
+                        hit = np.nonzero((rec[:, 0] != rec[:, 1]) | (rec[:, 2] != rec[:, 3]))[0]
+                        print("   %s grid %d round %d: lanes whose scratch reload differed from the LDS mirror (over %d launches): %d; threads with a sample %d; bit-exact %s" % (name, grid, r, reps, int(d[0]), len(hit), ok))
+                        for i in hit[:6]:
+                            print("      block %d thread %d: scratch {%016x %016x}  LDS mirror {%016x %016x}" % (i // 128, i % 128, rec[i, 0], rec[i, 2], rec[i, 1], rec[i, 3]))
+                        if len(hit):
+                            blocks = np.unique(hit // 128)
+                            print("      blocks: %d distinct, below 256: %d, by block %% 8 %s; lanes per hit block (first 8) %s" % (len(blocks), int((blocks < 256).sum()), np.bincount(blocks % 8, minlength=8).tolist(), [int((hit // 128 == b).sum()) for b in blocks[:8]]))
                     if not ok:
                         o = ma.to_numpy(out)
                         bad = np.nonzero((o != w).any(axis=(1, 2)))[0]
@@ -144,6 +172,19 @@ def run_ep(B, rounds, grids, pset="set1", names=None):
                             dd = (o[b0] - w[b0]).astype(np.int64)
                             print("   %s grid %d: unit %d: %d of %d words differ, per component %s, max |diff| 2^%.1f, first positions %s" % (
                                 name, grid, b0, dw.sum(), dw.size, dw.sum(axis=1).tolist(), np.log2(np.abs(dd.astype(np.float64)).max() + 1), np.nonzero(dw.reshape(-1))[0][:8].tolist()))
+                        if r == 0 and os.environ.get("AB_DIAGNOSE"):
+                            # which inputs reproduce a wrong unit?  components a / b taken from this unit, the team's previous one or its next one
+                            for b0 in bad[:int(os.environ["AB_DIAGNOSE"])]:
+                                found = []
+                                for da in (0, -grid, grid):
+                                    for db in (0, -grid, grid):
+                                        if (da or db) and 0 <= b0 + da < B and 0 <= b0 + db < B:
+                                            x = np.stack([h_in[b0 + da][0], h_in[b0 + db][1]])
+                                            if (O.external_product(x, bkd[1], P["l"], P["Bg_bit"]) == o[b0]).all():
+                                                found.append((da // grid, db // grid))
+                                zero = bool((o[b0] == 0).all())
+                                print("   %s grid %d: wrong unit %d (block %d, iteration %d) equals the product of components (a, b) of the team's units at offsets %s%s" % (
+                                    name, grid, b0, b0 % grid, b0 // grid, found, "; output all zero" if zero else ""))
                         ok = "False: %d units differ from production (first %s); vs oracle on the sample: %s" % (len(bad), bad[:6].tolist(), {b: bool((o[b] == truth[b]).all()) for b in sample})
                     res.setdefault((name + ":" + fn, grid), []).append((ms.value, ok))
     for (name, grid), v in res.items():
