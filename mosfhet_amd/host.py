@@ -149,6 +149,21 @@ def gen_automorphism_keyset(rlwe_key, t, base_bit):
     return out
 
 
+def automorphism_key_sources(s):
+    """The N source polynomials of trlwe_new_automorphism_KS_keyset (src/keyswitch.c:500-511, skip_even): entry j is the key polynomial s under
+    X -> X^(2j+1) (polynomial_permute, src/polynomial.c:442-450) -- what Engine.generate_trlwe_ks_keys encrypts into the key set on the device."""
+    s = np.asarray(s, dtype=np.uint64)
+    N = s.size
+    i = np.arange(N, dtype=np.uint64)
+    out = np.zeros((N, N), dtype=np.uint64)
+    for j in range(N):
+        idx = i * np.uint64(2 * j + 1)
+        neg = (idx & np.uint64(N)) != 0
+        with np.errstate(over="ignore"):
+            out[j, (idx & np.uint64(N - 1)).astype(np.int64)] = np.where(neg, np.uint64(0) - s, s)
+    return out
+
+
 def gen_priv_ks_key(out_key, in_key, t, base_bit):
     """trlwe_new_priv_KS_key (src/keyswitch.c:39-50) as u64[2][t][2][N]: entry 0 from -s_out*s_in, entry 1 from -s_out."""
     L = _lib()

@@ -138,8 +138,7 @@ def test_kernel_table_of_the_build(native_lib):
     toolchain change shows up on the CPU box and not as a silent change of the kernels that run:
       * the software-pipelined unit loop on two-wavefront teams (external_product_kernel<Fft2048L, 4, *, no CMUX>, FORM 0) is taken only while that build has no
         scratch (capi.hip: ep_go falls back to the plain loop otherwise: correct, 11 % slower at lvl2) -- today it has none;
-      * its fall-back (FORM 1) exists for exactly those instantiations;
-      * no kernel has been built for more than 256 registers' worth of occupancy it does not get (AGPRs unused everywhere)."""
+      * its fall-back (FORM 1) exists for exactly those instantiations."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import kernel_table
@@ -150,7 +149,6 @@ def test_kernel_table_of_the_build(native_lib):
     for r in piped:
         assert r["scratch"] == 0, "%s now spills %d bytes: the launcher will run the plain loop (re-measure, re-soak: tools/soak.py)" % (r["name"], r["scratch"])
         assert r["name"][:-2] + "1>" in by_name, "no plain-loop fall-back for " + r["name"]
-    assert all(r["agpr"] == 0 for r in rows)
     assert len(rows) < 330, "%d kernel instantiations" % len(rows)
 
 
