@@ -1512,15 +1512,23 @@ __global__ __launch_bounds__(F::THREADS, EP_MIN_WAVES) void external_product_ker
     for (int m = 0; m < 8; m++) D::pack(w_lo[m], w_hi[m], ext[m], raw_lo[m] + off, raw_hi[m] + off);
   };
   if constexpr (!kPipe) {
-    // Rings of two or four wavefronts per team keep the plain structure -- component loop rolled, each component requested where it is used.  The
-    // pipelined form below is (a) not faster there (lvl2: 0.509 vs 0.488 ms per 16,384 units, SET_2: 0.249-0.292 vs 0.237-0.243 ms: these teams are
-    // issue-bound, and the first key-row wait of a unit waits for the older ciphertext loads too) and (b) gave intermittently wrong units on every such
-    // ring at l = 1 (1-2 % of the units, whole units, never from the first workgroup of a CU).  Round-3 diagnosis (experiments/README.md): only builds
-    // whose register spills went to scratch fail (the spilled values are the in-flight ciphertext words); the same source with one wavefront per SIMD
-    // (no spills), with the next unit's request moved behind the rows (no spills) or with every wait forced to zero passes; the compiler's vmcnt
-    // counts are consistent with in-order completion (tools/ab/wcheck.py) and neither scratch integrity nor load order fail in isolation
-    // (tools/ubench/scratch_check.hip, vmcnt_order.hip).  Not root-caused further; the form stays confined to the one-wavefront ring, whose
-    // instantiations are checked unit by unit against the oracle at batch sizes beyond the grid (tests/test_gpu_parity.py).
+    // PLAIN loop: component loop rolled, each component requested where it is used.  What every ring of two or four wavefronts per team takes, with one
+    // exception (ep_pipelined_by_default).  The pipelined form below is (a) not faster on these rings in general (SET_2: 0.249-0.292 vs 0.237-0.243 ms: the teams
+    // are issue-bound, and the first key-row wait of a unit waits for the older ciphertext loads too) and (b) has a failure mode on them that is NOT understood to
+    // the end: at l = 1 on N = 2048 / 4096, 1-2 % of the units of a launch come out wrong (whole units, a different set every launch).
+    // What round 5's assembly-level bisection of ONE failing build established (tools/spill_hazard, experiments/README.md "Round 5", profiles/r05_spill_hazard_*.txt):
+    //   * it is NOT the register spills round 3 blamed: the same listing with the two spilled words kept in LDS instead of scratch fails alike, and a copy of every
+    //     spilled word kept in LDS always equals what scratch returns;
+    //   * no wait is too weak: every partial s_waitcnt vmcnt(N) of the loop replaced by vmcnt(0) still fails, as does lgkmcnt(0) behind every DS instruction, a
+    //     workgroup barrier (with or without a full drain) at the top of the loop, vmcnt(0) in front of every barrier; the key-row words are what memory holds when
+    //     they are used (checked in place against a drained re-read);
+    //   * it IS a matter of time and of neighbours: one workgroup per CU never fails, two rarely, three and four at 0.4 % and 1.5 % of the units; the first workgroup
+    //     of a CU never fails, wherever its LDS sits; s_nop 3 / 15 / 4 x 15 / s_sleep 8 behind each key-row load cut the failures to 135 / 26 / 3 / 0 units of
+    //     5 x 16,384, and vmcnt(0) behind each key-row load (issue serialised) removes them.
+    // A wrong unit is not the product of any whole component of a neighbouring unit.  No instruction sequence in the listing violates a documented hazard or the
+    // in-order completion model (tools/ab/wcheck.py over all three paths through the loop).  Consequence: the pipelined loop runs on multi-wavefront teams only
+    // where it has been SOAKED -- lvl2's <Fft2048L, 4, *> without the CMUX operand: 1.3 x 10^9 units in 80,000 launches without one differing bit
+    // (tools/soak.py, profiles/r05_soak_*.txt) -- and the launcher drops back to this loop when that instantiation's build changes (capi.hip: ep_go).
     for (size_t u = blockIdx.x; u < (size_t)count; u += gridDim.x) {
       const d2 *__restrict__ bkrow = bkrow0 + u * key_stride;
       double o_re[2][8], o_im[2][8];
