@@ -474,13 +474,16 @@ def main():
     replicas = None
     if world > 1 or force_dist:
         import zlib
-        mine = torch.tensor([zlib.crc32(bk.tobytes()), zlib.crc32(cts.tobytes()), int(np.log2(err + 1) * 1000)], dtype=torch.int64,
+        mine = torch.tensor([zlib.crc32(bk.tobytes()), zlib.crc32(cts.tobytes()), int(np.log2(err + 1) * 1000), int(kernel_ms * 1e6), int(period * 1e6)], dtype=torch.int64,
                             device=eng.device if backend == "nccl" else "cpu")
         every = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         every = torch.stack(every).cpu().numpy()
         replicas = {"keys_identical": bool((every[:, 0] == every[0, 0]).all()), "inputs_distinct": len(set(every[:, 1].tolist())) == world,
-                    "max_phase_error_log2_per_rank": (every[:, 2] / 1000.0).tolist()}
+                    "max_phase_error_log2_per_rank": (every[:, 2] / 1000.0).tolist(),
+                    "kernel_ms_per_rank": (every[:, 3] / 1e6).tolist(), "period_ms_in_stream_regime_per_rank": (every[:, 4] / 1e6).tolist(),
+                    "route": "one process per GPU: every rank builds the key from the same seed and uploads its own replica (host -> its device); nothing crosses between GPUs",
+                    "key_bytes_per_gpu": int(bk.nbytes), "devices": [torch.cuda.get_device_name(dev_index)] if world == 1 else None}
         if rank == 0 and not (replicas["keys_identical"] and replicas["inputs_distinct"]):
             sys.exit("bench.py: the ranks are not replicas of one job: %s" % replicas)
 

@@ -343,6 +343,21 @@ int mosfhet_hip_set_wide_team_max_batch(int max_batch);
 int mosfhet_hip_set_ep_plain_loop(int on);
 int mosfhet_hip_ep_kernel_info(int i, const char **name, int *scratch_bytes, int *takes_pipelined);
 
+/* Digit-parallel forms of the radix-integer callers of applications/multi-ciphertext-arith for M INDEPENDENT integers: the gate sequences of
+ * ufhe_sl_add_integer / ufhe_sub_integer (src/integer.c:79-107,136-156), ufhe_relu_integer (src/ml.c:4-20) and ufhe_encrypted_tlwe_lut (src/lut.c:6-20), one
+ * key-switch / packing-switch / bootstrap LAUNCH per carry step or tree level instead of one gate per digit and integer.  Integers are digit-major on the device:
+ * [d][M][N+1] torus words, digit / (2 torus_base) per sample under the extracted TRLWE key (ufhe_encrypt_integer).  The handle borrows the keys (bootstrap key
+ * n -> N, LWE key switch N -> n, LUT-packing key of torus_base slots N -> TRLWE(N); pksk may be NULL for add / sub only) and is read-only after creation.
+ *   addsub: c = a + b (subtract = 0) or a - b (1) over all d digits, the carry out of the top digit dropped (equal-width operands); c must not alias a, b
+ *   relu: out = in > 0 ? in : 0 for signed integers; out may alias in
+ *   encrypted_lut: table[0][m] = table[selector_m][m]; d_table [size][M][N+1] is consumed, d_sel [log_B size][M][N+1] = selector digits, least significant first */
+typedef struct mosfhet_hip_vec *mosfhet_hip_vec_t;
+int mosfhet_hip_vec_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_vec_t *out, mosfhet_hip_bsk_t bsk, mosfhet_hip_ksk_t ksk, mosfhet_hip_ksk_t pksk, int torus_base);
+int mosfhet_hip_vec_destroy(mosfhet_hip_vec_t vec);
+int mosfhet_hip_vec_addsub(mosfhet_hip_vec_t vec, uint64_t *d_c, const uint64_t *d_a, const uint64_t *d_b, int M, int d, int subtract, void *stream);
+int mosfhet_hip_vec_relu(mosfhet_hip_vec_t vec, uint64_t *d_out, const uint64_t *d_in, int M, int d, void *stream);
+int mosfhet_hip_vec_encrypted_lut(mosfhet_hip_vec_t vec, uint64_t *d_table, const uint64_t *d_sel, int size, int M, void *stream);
+
 /* The canonical caller pattern in one call (applications/multi-ciphertext-arith/src/integer.c:94-95): tlwe_keyswitch kN -> n, then
  * functional_bootstrap (extract = 1: d_out [count][kN+1]) or functional_bootstrap_wo_extract (extract = 0: d_out [count][k+1][N]);
  * same stream, no host synchronisation in between. */

@@ -215,22 +215,15 @@ __device__ __forceinline__ void cmux_digits(typename Digits<L, BG>::word_t (&w_l
 
 // The L rows of component p: digits -> forward transform -> MAC against key rows p*L .. p*L+L-1.
 // The key row's component 0 is loaded under the last transform pass, component 1 under the MAC of component 0.
-// ONE_K: one register buffer for the key row (component 1 is loaded when component 0 has been consumed) -- for callers that need the 32 registers
-// FIRST: this call holds the first row of the product (component 0, level 0): its products INITIALISE the accumulators (x * y where the chain would
-// compute fma(x, y, 0.0): the same number), so the accumulator registers are free until then
 // KEY_LDS: the key rows are in LDS (external_product_ldskey_kernel): no early fetch into registers, each component's slots are read where they are used
-template <class F, int L, int BG, bool ONE_K = false, bool FIRST = false, bool KEY_LDS = false>
+template <class F, int L, int BG, bool KEY_LDS = false>
 __device__ __forceinline__ void cmux_rows(const typename Digits<L, BG>::word_t (&w_lo)[8], const typename Digits<L, BG>::word_t (&w_hi)[8],
                                           const uint32_t (&ext)[8], int p, double (&o_re)[2][8], double (&o_im)[2][8], d2 *xch,
                                           const F &fft, const d2 *__restrict__ bkrow, int Bg_bit, int t) {
   constexpr int M = F::M, T = F::THREADS;
   using D = Digits<L, BG>;
   // two levels are unrolled (the next row's digit conversion and first pass overlap the MAC tail; no scratch at l = 2), more stay rolled
-#ifdef MOSFHET_ROWS_ROLLED
-  constexpr int kUnroll = 1;
-#else
   constexpr int kUnroll = (L <= 2 && !KEY_LDS) ? L : 1;   // KEY_LDS: rolled -- unrolled, the LDS reads of both rows are hoisted and spill
-#endif
 #pragma unroll kUnroll
   for (int lv = 0; lv < L; lv++) {
     const d2 *__restrict__ row = bkrow + (size_t)(p * L + lv) * (2 * M);
@@ -260,36 +253,6 @@ __device__ __forceinline__ void cmux_rows(const typename Digits<L, BG>::word_t (
 #pragma unroll
     for (int m = 0; m < 8; m++) k0[m] = row[m * T + t];
     fft.forward_tail(re, im);
-    if (FIRST && lv == 0) {
-#pragma unroll
-      for (int m = 0; m < 8; m++) {
-        k1[m] = row[M + m * T + t];
-        o_re[0][m] = __builtin_fma(-im[m], k0[m].y, re[m] * k0[m].x);
-        o_im[0][m] = __builtin_fma(im[m], k0[m].x, re[m] * k0[m].y);
-      }
-#pragma unroll
-      for (int m = 0; m < 8; m++) {
-        o_re[1][m] = __builtin_fma(-im[m], k1[m].y, re[m] * k1[m].x);
-        o_im[1][m] = __builtin_fma(im[m], k1[m].x, re[m] * k1[m].y);
-      }
-      continue;
-    }
-    if constexpr (ONE_K) {
-#pragma unroll
-      for (int m = 0; m < 8; m++) {
-        o_re[0][m] = __builtin_fma(-im[m], k0[m].y, __builtin_fma(re[m], k0[m].x, o_re[0][m]));
-        o_im[0][m] = __builtin_fma(im[m], k0[m].x, __builtin_fma(re[m], k0[m].y, o_im[0][m]));
-      }
-      asm volatile("" ::: "memory");   // keep the second load behind the first product: it reuses the registers
-#pragma unroll
-      for (int m = 0; m < 8; m++) k0[m] = row[M + m * T + t];
-#pragma unroll
-      for (int m = 0; m < 8; m++) {
-        o_re[1][m] = __builtin_fma(-im[m], k0[m].y, __builtin_fma(re[m], k0[m].x, o_re[1][m]));
-        o_im[1][m] = __builtin_fma(im[m], k0[m].x, __builtin_fma(re[m], k0[m].y, o_im[1][m]));
-      }
-      continue;
-    }
 #pragma unroll
     for (int m = 0; m < 8; m++) {
       k1[m] = row[M + m * T + t];
@@ -378,9 +341,6 @@ __device__ __forceinline__ void cmux_rows2(const typename Digits<L, BG>::word_t 
 // the transpose buffer that is 17 KiB of LDS per wavefront and <= 256 VGPRs, i.e. two wavefronts per SIMD /
 // eight per CU.  (Both components in LDS: 25 KiB -> 6 per CU, measured 22 % slower; both in registers spills.)
 // F = Fft1024: one wavefront per ciphertext; F = Fft2048: two wavefronts (128 threads) per ciphertext.
-#ifndef MOSFHET_PBS_PAIRS
-#define MOSFHET_PBS_PAIRS 1
-#endif
 template <class F, int L, int BG>
 __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
   constexpr int N = F::N, M = F::M, T = F::THREADS, LOG2N2 = F::LOGM + 2;
@@ -435,11 +395,7 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
     if (T > 64 && p.pace && i > 0 && i % p.pace_every == 0) pace_teams(p.pace, (unsigned)(i / p.pace_every), t, p.pace_limit);   // (before the skip: every team counts every step)
     const int abar = (int)modswitch<LOG2N2>(pbs_pre(ct[i], p, LOG2N2));
     if (abar == 0) continue;  // src/bootstrap.c:114
-#ifdef MOSFHET_AB_KEYWRAP   // A/B only (tools/ab): walk the first MOSFHET_AB_KEYWRAP entries over and over -- every key request an L2 hit (results are wrong; timing only)
-    const d2 *__restrict__ bkrow = p.bk + (size_t)(i % MOSFHET_AB_KEYWRAP) * row_sz;
-#else
     const d2 *__restrict__ bkrow = p.bk + (size_t)i * row_sz;
-#endif
     const int a_lo = abar & (N - 1);
     const bool flip = (abar & N) != 0;
     double o_re[2][8], o_im[2][8];
@@ -454,9 +410,9 @@ __global__ __launch_bounds__(F::THREADS, 2) void pbs_kernel(PbsParams p) {
         typename Digits<L, BG>::word_t w_lo[8], w_hi[8];
         uint32_t ext[8];
         cmux_digits<F, L, BG>(w_lo, w_hi, ext, al, ah, q ? acc1 : nullptr, xch, a_lo, flip, off, t);
-        // rows two at a time where the transform keeps its pass twiddles in LDS: an A/B switch only (tools/ab/pbs_ab.hip with -DAB_LTW) -- at two wavefronts
-        // per SIMD the pairs gain nothing here (experiments/README.md round 4), production instantiates pbs_kernel on the register-twiddle transforms
-        if constexpr (F::kLtw && F::kForward2 && L % 2 == 0 && MOSFHET_PBS_PAIRS) cmux_rows2<F, L, BG>(w_lo, w_hi, ext, q, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
+        // rows two at a time where the transform keeps its pass twiddles in LDS (tools/ab/pbs_ab.hip -DAB_LTW instantiates that) -- at two wavefronts per SIMD
+        // the pairs gain nothing here (experiments/README.md round 4): production instantiates pbs_kernel on the register-twiddle transforms
+        if constexpr (F::kLtw && F::kForward2 && L % 2 == 0) cmux_rows2<F, L, BG>(w_lo, w_hi, ext, q, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
         else cmux_rows<F, L, BG>(w_lo, w_hi, ext, q, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
       }
     }
@@ -1440,19 +1396,8 @@ __global__ __launch_bounds__(F::THREADS) void dft_to_torus_kernel(const d2 *__re
 // in0 != nullptr: CMUX (applications/leveled_lut/vertical_packing.c:24-33): out[b] = in0[b] + TRGSW (.) (in[b] - in0[b])  (out may alias in0)
 // out_dft != nullptr: trgsw_mul_trlwe_DFT as the reference declares it (include/mosfhet.h:344): the result stays in the DFT domain,
 // out_dft[b][c][slot] in slot order; trlwe_from_DFT (dft_to_torus_kernel) finishes it with the same inverse transform and rounding.
-#ifndef EP_ONE_K
-#define EP_ONE_K false
-#endif
-#ifdef MOSFHET_EP_NO_NT
-#define EP_NT_LOAD(p) (*(p))
-#define EP_NT_STORE(v, p) (*(p) = (v))
-#else
 #define EP_NT_LOAD(p) __builtin_nontemporal_load(p)
 #define EP_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
-#endif
-#ifndef EP_MIN_WAVES
-#define EP_MIN_WAVES 2
-#endif
 // The unit loop comes in two forms: PLAIN (each component requested where it is used) and PIPELINED (the next component always in flight under the rows of the
 // current one).  FORM = 0 takes the form ep_pipelined_by_default() names, 1 forces the plain loop (the launcher's fall-back, capi.hip: ep_form), 2 forces the
 // pipelined one (experiments only: tools/ab/ep_ab.hip, tools/spill_hazard).
@@ -1463,7 +1408,7 @@ constexpr bool ep_pipelined_by_default() {
   return F::THREADS == 64 || (F::kForward2 && F::kLtw && L % 2 == 0 && !CMUX && L == 4);
 }
 template <class F, int L, int BG, bool CMUX, int FORM = 0>
-__global__ __launch_bounds__(F::THREADS, EP_MIN_WAVES) void external_product_kernel(const d2 *__restrict__ bkrow0, const d2 *__restrict__ tw,
+__global__ __launch_bounds__(F::THREADS, 2) void external_product_kernel(const d2 *__restrict__ bkrow0, const d2 *__restrict__ tw,
                                                                        const uint64_t *__restrict__ in, uint64_t *out, int Bg_bit_rt, int count,
                                                                        size_t key_stride = 0, size_t in_stride = 2 * F::N,
                                                                        const uint64_t *in0 = nullptr, d2 *__restrict__ out_dft = nullptr) {   // out may alias in0 (CMUX in place): neither is __restrict__
@@ -1569,27 +1514,21 @@ __global__ __launch_bounds__(F::THREADS, EP_MIN_WAVES) void external_product_ker
   for (size_t u = blockIdx.x; u < (size_t)count; u += gridDim.x) {
     const d2 *__restrict__ bkrow = bkrow0 + u * key_stride;
     double o_re[2][8], o_im[2][8];
-#ifndef MOSFHET_EP_FIRST
 #pragma unroll
     for (int c = 0; c < 2; c++)
 #pragma unroll
       for (int m = 0; m < 8; m++) { o_re[c][m] = 0.0; o_im[c][m] = 0.0; }
-#endif
     pack();              // component a (requested during the previous unit)
     request(u, 1);       // component b: in flight under the rows of component a
     if constexpr (kPairs) {
       cmux_rows2<F, L, BG>(w_lo, w_hi, ext, 0, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
     } else {
-#ifdef MOSFHET_EP_FIRST
-      cmux_rows<F, L, BG, EP_ONE_K, true>(w_lo, w_hi, ext, 0, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
-#else
-      cmux_rows<F, L, BG, EP_ONE_K>(w_lo, w_hi, ext, 0, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
-#endif
+      cmux_rows<F, L, BG>(w_lo, w_hi, ext, 0, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
     }
     pack();
     if (u + gridDim.x < (size_t)count) request(u + gridDim.x, 0);   // the next unit's component a: under the rows of b, the inverse pair and the stores
     if constexpr (kPairs) cmux_rows2<F, L, BG>(w_lo, w_hi, ext, 1, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
-    else cmux_rows<F, L, BG, EP_ONE_K>(w_lo, w_hi, ext, 1, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
+    else cmux_rows<F, L, BG>(w_lo, w_hi, ext, 1, o_re, o_im, xch, fft, bkrow, Bg_bit, t);
     if (out_dft) {
       d2 *dd = out_dft + u * 2 * M;
 #pragma unroll
@@ -1670,10 +1609,10 @@ __global__ __launch_bounds__(512, 2) void external_product_ldskey_kernel(const d
       for (int m = 0; m < 8; m++) { o_re[c][m] = 0.0; o_im[c][m] = 0.0; }
     pack();
     request(u, 1);
-    cmux_rows<F, L, BG, false, false, true>(w_lo, w_hi, ext, 0, o_re, o_im, xch, fft, key, Bg_bit, t);
+    cmux_rows<F, L, BG, true>(w_lo, w_hi, ext, 0, o_re, o_im, xch, fft, key, Bg_bit, t);
     pack();
     if (u + stride < (size_t)count) request(u + stride, 0);
-    cmux_rows<F, L, BG, false, false, true>(w_lo, w_hi, ext, 1, o_re, o_im, xch, fft, key, Bg_bit, t);
+    cmux_rows<F, L, BG, true>(w_lo, w_hi, ext, 1, o_re, o_im, xch, fft, key, Bg_bit, t);
     if (out_dft) {
       d2 *dd = out_dft + u * 2 * M;
 #pragma unroll

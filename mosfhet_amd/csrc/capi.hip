@@ -75,7 +75,7 @@ struct DevBuf {
 // handle: handles are read-only after creation, so any number of host threads may share them, as the reference's callers share its keys
 // (re-entrant through thread-local scratch, src/polynomial.c:269-352).  A thread's launches are ordered by the stream it passes; buffers are
 // released at thread exit (hipFree waits for work in flight).
-enum { POOL_BSK = 0, POOL_EXT0 = 1, POOL_EXT1 = 2, POOL_CTX0 = 3, POOL_UNFOLD = 6, POOL_PACK = 7, POOL_SLOTS = 8 };
+enum { POOL_BSK = 0, POOL_EXT0 = 1, POOL_EXT1 = 2, POOL_CTX0 = 3, POOL_UNFOLD = 6, POOL_PACK = 7, POOL_VEC = 8, POOL_SLOTS = 9 };
 struct ThreadPool {
   struct Dev {
     int device = -1;
@@ -1110,10 +1110,8 @@ static int launch_ga_f(int l, int Bg_bit, const GaParams &g, int count, hipStrea
   }
   if constexpr (std::is_same<F, Fft2048>::value) {
     // lvl2: the pass twiddles in LDS (Fft2048L) take the kernel out of scratch (68 bytes -> 0, 250 registers; same speed: experiments/README.md round 4).
-    // The run-time-gadget instantiations spill with either transform and stay where they were.  MOSFHET_HIP_GA_LTW=0: the register-twiddle kernel.
-    static int ltw = -1;
-    if (ltw < 0) { const char *e = getenv("MOSFHET_HIP_GA_LTW"); ltw = (e && e[0] == '0') ? 0 : 1; }
-    if (ltw && l == 4 && Bg_bit == 9) { launch_ga<Fft2048L, 4, 9>(g, count, s); HIP_TRY(hipGetLastError()); return MOSFHET_HIP_OK; }
+    // The run-time-gadget instantiations spill with either transform and stay where they were.
+    if (l == 4 && Bg_bit == 9) { launch_ga<Fft2048L, 4, 9>(g, count, s); HIP_TRY(hipGetLastError()); return MOSFHET_HIP_OK; }
   }
   if (l == 2 && Bg_bit == 8) launch_ga<F, 2, 8>(g, count, s);
   else if (l == 4 && Bg_bit == 9) launch_ga<F, 4, 9>(g, count, s);
@@ -1337,3 +1335,4 @@ extern "C" int mosfhet_hip_time_programmable_bootstrap(mosfhet_hip_ctx_t ctx, mo
 
 #include "capi_ext.inc"
 #include "capi_dft.inc"
+#include "capi_vec.inc"

@@ -1567,15 +1567,8 @@ static LevelEvents level_events_new(int l, int count) {
     if (hipEventCreateWithFlags(&e.piece[i], HIP_EVENT_DISABLE_TIMING)) mc_die("circuit bootstrap (event)");
   return e;
 }
-static double timeline_ms(void) {
-  struct timespec t;
-  clock_gettime(CLOCK_MONOTONIC, &t);
-  return (double)t.tv_sec * 1e3 + (double)t.tv_nsec * 1e-6;
-}
 static void trgsw_levels_download(TRGSW *out, Torus *h_flat, const Torus *d_flat, int count, int l, size_t row, LevelEvents *e) {
   const int rows = 2 * l;
-  const int timeline = getenv("MOSFHET_COMPAT_TIMELINE") != NULL;   /* debugging aid: when each piece landed and was unpacked, on stderr */
-  const double t0 = timeline ? timeline_ms() : 0.0;
   const size_t item = (size_t)rows * row, pitch = sizeof(Torus) * item, width = sizeof(Torus) * row;
   void *cs = mc_copy_stream();
   for (int i = 0; i < l; i++) {
@@ -1593,10 +1586,8 @@ static void trgsw_levels_download(TRGSW *out, Torus *h_flat, const Torus *d_flat
     for (int p = 0; p < e->n_pieces; p++) {
       const int lo = p * LEVEL_PIECE, cnt = count - lo < LEVEL_PIECE ? count - lo : LEVEL_PIECE;
       if (hipEventSynchronize(e->piece[i * e->n_pieces + p])) mc_die("circuit bootstrap (copy out)");
-      const double t1 = timeline ? timeline_ms() : 0.0;
       TrgswRows a = {out + lo, h_flat + (size_t)lo * item, rows, i, l + i, row};
       mc_parallel_for(trgsw_rows_from_flat_range, &a, cnt, 1);
-      if (timeline) fprintf(stderr, "[timeline] level %d piece %d: landed at %.2f ms, unpacked at %.2f ms after the launches were queued\n", i, p, t1 - t0, timeline_ms() - t0);
     }
   for (int i = 0; i < l; i++) hipEventDestroy(e->level[i]);
   for (int i = 0; i < l * e->n_pieces; i++) hipEventDestroy(e->piece[i]);

@@ -243,8 +243,8 @@ inline hipError_t launch_tlwe_keyswitch_nw(const uint64_t *ksk, uint64_t *out, s
   const int slices = (row + W - 1) / W, ct_blocks = (int)(Bp / TILE);
   // ~4 x the resident capacity (6 workgroups per CU): the workgroups are not equally long (tile padding, split remainders) and the
   // kernel is latency-bound (LDS ~42 %, VALU ~50 %, HBM ~34 % busy, profiles/r01d_ks_summary.txt), so a finer grid balances better:
-  // packing switch 7.4 -> 6.3 ms, lvl2 LWE switch 6.1 -> 5.1 ms per batch.  MOSFHET_KS_TARGET_WGS overrides (tuning).
-  static const int target_wgs = getenv("MOSFHET_KS_TARGET_WGS") ? atoi(getenv("MOSFHET_KS_TARGET_WGS")) : 6144;
+  // packing switch 7.4 -> 6.3 ms, lvl2 LWE switch 6.1 -> 5.1 ms per batch.
+  constexpr int target_wgs = 6144;
   int split = (target_wgs + slices * ct_blocks - 1) / (slices * ct_blocks);
   if (split > 16) split = 16;
   if (split > n_in / 8) split = n_in / 8;
@@ -273,11 +273,9 @@ inline hipError_t launch_tlwe_keyswitch_nw(const uint64_t *ksk, uint64_t *out, s
   // one stage; base_bit 3 and 4 take TWO positions per stage (same-box sweep with the 512-ciphertext tile: packing switch 5.00 -> 4.40 ms per 1024
   // and 18.9 -> 16.9 ms per 4096, lvl2 LWE switch 4.06 -> 3.54 ms; three positions are slower again); wider digit sets one.  A table whose
   // every word is regenerated (seed-compressed LWE key) keeps one position: its stage is generator-bound, 4.02 vs 4.11 ms.
-  // MOSFHET_KS_LDS_BYTES overrides (tuning).
-  static const int lds_env = getenv("MOSFHET_KS_LDS_BYTES") ? atoi(getenv("MOSFHET_KS_LDS_BYTES")) : 0;
   const int two_positions = 2 * (cands + 1) * (W + 2) * 8;
   const bool all_generated = compressed && mask_words == row - 1;
-  const int lds_budget = lds_env ? lds_env : (cands < 7 ? KS_LDS_BYTES : ((cands <= 15 && !all_generated) ? two_positions : 4352));
+  const int lds_budget = (cands < 7 ? KS_LDS_BYTES : ((cands <= 15 && !all_generated) ? two_positions : 4352));
   int JB = lds_budget / ((cands + 1) * (W + 2) * 8);          // per LDS buffer
   // rows a stage can prefetch through registers: 8 per thread, 16 for the widest digit sets (base_bit 8 with a 256-ciphertext tile, where
   // one digit position alone has more candidate rows than 8 per thread cover)
@@ -443,10 +441,9 @@ inline hipError_t launch_tlwe_keyswitch(const uint64_t *ksk, uint64_t *out, size
   static const int small_max = getenv("MOSFHET_KS_SMALL_MAX") ? atoi(getenv("MOSFHET_KS_SMALL_MAX")) : 16;
   if (count <= small_max)
     return launch_tlwe_keyswitch_small(ksk, out, out_stride, in, in_stride, count, n_in, row, b_word, t, base_bit, ws, s, compressed, seed, mask_words);
-  static const int tile_env = getenv("MOSFHET_KS_TILE") ? atoi(getenv("MOSFHET_KS_TILE")) : 0;   // tuning: 256 or 512 ciphertexts per workgroup
   // (up to 256 ciphertexts one 256-wide tile holds them all: the 512-wide tile's extra wavefronts would only stage rows -- +15 % on circuit bootstraps of
   // 64 - 256 ciphertexts, the shape of a batch of 1024 split over 8 GPUs)
-  if (tile_env == 512 || (tile_env != 256 && base_bit >= 3 && (count > 256 || base_bit > 4)))   // (wider digits need the 512-thread tile's staging width)
+  if (base_bit >= 3 && (count > 256 || base_bit > 4))   // (wider digits need the 512-thread tile's staging width)
     return launch_tlwe_keyswitch_nw<8>(ksk, out, out_stride, in, in_stride, count, n_in, row, b_word, t, base_bit, ws, s, compressed, seed, mask_words);
   return launch_tlwe_keyswitch_nw<KS_NW>(ksk, out, out_stride, in, in_stride, count, n_in, row, b_word, t, base_bit, ws, s, compressed, seed, mask_words);
 }

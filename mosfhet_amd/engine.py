@@ -572,6 +572,12 @@ class Engine:
         _check(lib().mosfhet_hip_external_product_batch(self.h, bsk.h, key_index, _ptr(out), _ptr(ct), count, self._stream()))
         return out
 
+    # ---- digit-parallel radix-integer callers (capi_vec.inc): integers are digit-major [d][M][N+1] ----
+    def vector_ops(self, bsk, ksk, pksk, torus_base):
+        h = C.c_void_p()
+        _check(lib().mosfhet_hip_vec_create(self.h, C.byref(h), bsk.h, ksk.h, pksk.h if pksk is not None else None, int(torus_base)))
+        return VectorOps(self, h, bsk, torus_base)
+
     # ---- DFT-level objects of the legacy API (include/mosfhet.h of the reference: TRGSW_DFT, TRLWE_DFT stay on the device in slot order) ----
     def trgsw_to_dft(self, trgsw):
         """trgsw_to_DFT (src/trgsw.c:359-366) for a batch: [count][(k+1)l][k+1][N] torus words -> the same shape in doubles (N/2 complex per polynomial)"""
@@ -714,6 +720,37 @@ def set_team_max_batch(max_batch):
 def set_wide_team_max_batch(max_batch):
     """Batches up to this size use the latency-oriented bootstrap kernel at N = 2048 (0 disables it)."""
     _check(lib().mosfhet_hip_set_wide_team_max_batch(int(max_batch)))
+
+
+class VectorOps:
+    """Handle of the digit-parallel integer callers (mosfhet_hip_vec_*): add / sub / ReLU / encrypted LUT over M independent radix-B integers"""
+    def __init__(self, eng, h, bsk, torus_base):
+        self.eng, self.h, self.bsk, self.torus_base = eng, h, bsk, torus_base
+
+    def addsub(self, a, b, subtract=False, out=None):
+        d, M, row = a.shape
+        if out is None:
+            out = self.eng.empty(d, M, row)
+        _check(lib().mosfhet_hip_vec_addsub(self.h, _ptr(out), _ptr(a), _ptr(b), M, d, int(bool(subtract)), self.eng._stream()))
+        return out
+
+    def relu(self, a, out=None):
+        d, M, row = a.shape
+        if out is None:
+            out = self.eng.empty(d, M, row)
+        _check(lib().mosfhet_hip_vec_relu(self.h, _ptr(out), _ptr(a), M, d, self.eng._stream()))
+        return out
+
+    def encrypted_lut(self, table, sel):
+        """table [size][M][N+1] is consumed; returns table[0] = the selected entries"""
+        size, M, row = table.shape
+        _check(lib().mosfhet_hip_vec_encrypted_lut(self.h, _ptr(table), _ptr(sel), size, M, self.eng._stream()))
+        return table[0]
+
+    def free(self):
+        if self.h:
+            lib().mosfhet_hip_vec_destroy(self.h)
+            self.h = None
 
 
 def set_ep_plain_loop(on):

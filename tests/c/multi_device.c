@@ -128,10 +128,17 @@ static void wider_callers(TLWE_Key lwe_key, int n_dev) {
 
 int main(int argc, char **argv) {
   enum { n = 64, N = 1024, k = 1, l = 2, Bg_bit = 8, COUNT = 301, BIG = 2 * 4096 + 11 };
-  const int devs[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* up to eight contexts on GPU 0: the slice arithmetic, worker threads and replicas of an 8-GPU node */
+  int devs[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* up to eight contexts on GPU 0: the slice arithmetic, worker threads and replicas of an 8-GPU node */
   const int n_dev = argc > 1 ? atoi(argv[1]) : 2;
-  if (n_dev < 1 || n_dev > 8) { printf("usage: multi_device [1 .. 8]\n"); return 255; }
+  /* "distinct": context i on board i (the box must have n_dev of them) -- the first run on more than one physical GPU takes this form; the key replicas must then
+   * travel peer to peer (or, with MOSFHET_HIP_NO_PEER set, by the route that forces) and every sharded batch must still equal the primary board's single calls */
+  const int distinct = argc > 2 && !strcmp(argv[2], "distinct");
+  if (n_dev < 1 || n_dev > 8) { printf("usage: multi_device [1 .. 8] [distinct]\n"); return 255; }
   setvbuf(stdout, NULL, _IOLBF, 0);
+  if (distinct) {
+    for (int i = 0; i < n_dev; i++) devs[i] = i;
+    printf("multi_device: %d contexts on %d distinct boards\n", n_dev, n_dev);
+  }
   mosfhet_set_devices(n_dev, devs);
   mosfhet_seed(0x4D4F5346);
   CHECK(mosfhet_device_count() == n_dev, "device count");
@@ -226,6 +233,10 @@ int main(int argc, char **argv) {
       if (keys[r])
         printf("key replication, %s: %d keys, %.1f MB in %.1f ms (%.1f GB/s)\n", route[r], keys[r], bytes[r] / 1e6, seconds[r] * 1e3, bytes[r] / 1e9 / (seconds[r] > 0 ? seconds[r] : 1));
     if (n_dev > 1) CHECK(keys[0] + keys[1] + keys[2] + keys[3] >= 8, "fewer replicated keys than the sharded calls use (%d)", keys[0] + keys[1] + keys[2] + keys[3]);
+    if (distinct && n_dev > 1) {
+      CHECK(keys[0] == 0, "%d key replicas took the same-device route between distinct boards", keys[0]);
+      if (!getenv("MOSFHET_HIP_NO_PEER")) CHECK(keys[1] > 0 && keys[2] + keys[3] == 0, "replicas between distinct boards did not all travel peer to peer (%d / %d / %d)", keys[1], keys[2], keys[3]);
+    }
   }
   printf("multi_device (%d contexts): %s\n", n_dev, failures ? "FAILED" : "ok");
   free_tlwe(one); free_tlwe(one_n); free_tlwe_array(in, BIG); free_tlwe_array(out, BIG); free_tlwe_array(back, COUNT); free_trlwe(tv);

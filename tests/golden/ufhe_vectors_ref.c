@@ -1,0 +1,43 @@
+/* Generator of tests/golden/ufhe_vectors.npz (run by tests/golden/make_ufhe_golden.py in the build container, where /root/reference exists): drives the
+ * REFERENCE's radix-integer application (applications/multi-ciphertext-arith, compiled unchanged from where it lies) on the REFERENCE's own library for a fixed
+ * list of inputs and prints what it decrypts -- add, sub, ReLU and the encrypted 16-entry LUT of signed 8-bit integers.  Own code; the printed numbers are the
+ * fixture the digit-parallel forms of this repository (mosfhet_hip_vec_*) are held to on the GPU. */
+#include "ufhe.h"
+
+ufhe_priv_keyset _priv_key;   /* integer.c declares them extern */
+ufhe_context _ctx;
+
+int main(int argc, char **argv) {
+  const int count = argc > 1 ? atoi(argv[1]) : 24;
+  _priv_key = ufhe_new_priv_keyset(SET0);
+  _ctx = ufhe_setup_context(ufhe_new_public_keyset(_priv_key, SET0));
+  ufhe_integer a = ufhe_new_integer(8, true, _ctx), b = ufhe_new_integer(8, true, _ctx), c = ufhe_new_integer(8, true, _ctx), sel = ufhe_new_integer(4, true, _ctx);
+  ufhe_integer vec[16];
+  for (int j = 0; j < 16; j++) vec[j] = ufhe_new_integer(8, true, _ctx);
+  printf("{\"torus_base\": %d, \"rows\": [\n", _ctx->torus_base);
+  for (int i = 0; i < count; i++) {
+    const int8_t va = (int8_t)((37 * i + 11) & 0xff), vb = (int8_t)((91 * i + 5) & 0xff);
+    const int vs = (5 * i + 2) & 0xf;
+    ufhe_encrypt_integer(a, (uint64_t)(uint8_t)va, _priv_key, _ctx);
+    ufhe_encrypt_integer(b, (uint64_t)(uint8_t)vb, _priv_key, _ctx);
+    ufhe_add_integer(c, a, b, _ctx);
+    const int r_add = (int)(int8_t)ufhe_decrypt_integer(c, _priv_key, _ctx);
+    ufhe_sub_integer(c, a, b, _ctx);
+    const int r_sub = (int)(int8_t)ufhe_decrypt_integer(c, _priv_key, _ctx);
+    ufhe_relu_integer(c, a, _ctx);
+    const int r_relu = (int)(int8_t)ufhe_decrypt_integer(c, _priv_key, _ctx);
+    ufhe_encrypt_integer(sel, (uint64_t)vs, _priv_key, _ctx);
+    printf("  {\"a\": %d, \"b\": %d, \"sel\": %d, \"table\": [", (int)va, (int)vb, vs);
+    for (int j = 0; j < 16; j++) {
+      const int8_t t = (int8_t)((13 * i + 7 * j * j + 3) & 0xff);
+      ufhe_encrypt_integer(vec[j], (uint64_t)(uint8_t)t, _priv_key, _ctx);
+      printf("%d%s", (int)t, j == 15 ? "" : ", ");
+    }
+    ufhe_mux_integer_array(c, sel, _ctx, 16, vec);
+    const int r_lut = (int)(int8_t)ufhe_decrypt_integer(c, _priv_key, _ctx);
+    printf("], \"add\": %d, \"sub\": %d, \"relu\": %d, \"lut\": %d}%s\n", r_add, r_sub, r_relu, r_lut, i == count - 1 ? "" : ",");
+    fflush(stdout);
+  }
+  printf("]}\n");
+  return 0;
+}

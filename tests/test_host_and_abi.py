@@ -152,6 +152,20 @@ def test_kernel_table_of_the_build(native_lib):
     assert len(rows) < 330, "%d kernel instantiations" % len(rows)
 
 
+def test_switch_table_matches_the_source():
+    """docs/SWITCHES.md (generated by tools/switch_table.py) names every getenv("MOSFHET_...") of the product source and nothing else, and every test it cites exists."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import switch_table
+    assert switch_table.in_source() == set(switch_table.SWITCHES), (switch_table.in_source() ^ set(switch_table.SWITCHES))
+    assert open(os.path.join(ROOT, "docs", "SWITCHES.md")).read() == switch_table.markdown(), "docs/SWITCHES.md is stale: python tools/switch_table.py --write"
+    tests = open(os.path.join(ROOT, "tests", "test_gpu_parity.py")).read()
+    for name, row in switch_table.SWITCHES.items():
+        for t in re.findall(r"`(test_\w+)`", row[3]):
+            assert "def %s(" % t in tests, (name, t)
+    assert len(switch_table.SWITCHES) <= 24
+
+
 def test_no_cpu_fallback(native_lib):
     import torch
     import mosfhet_amd as ma
