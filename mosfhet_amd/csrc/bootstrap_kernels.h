@@ -60,7 +60,7 @@ struct PbsParams {
 // first team that times out raises the give-up flag and nobody waits again in this launch.  Memory order: relaxed device-scope atomics, nothing is
 // communicated but time.  Layout of `pace`: 8 counters at 32-word spacing, then the flag at word 256.
 __device__ __forceinline__ void pace_teams(unsigned int *pace, unsigned int round, int t, int limit) {
-  __syncthreads();
+  workgroup_sync();
   if (t == 0 && __hip_atomic_load(pace + 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
     unsigned int xcd;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcd));
@@ -77,7 +77,7 @@ __device__ __forceinline__ void pace_teams(unsigned int *pace, unsigned int roun
       __builtin_amdgcn_s_sleep(32);
     }
   }
-  __syncthreads();
+  workgroup_sync();
 }
 
 // src/misc.c:18-22 with log_scale = log2(2N)
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(64 * 2 * L) void pbs_team_kernel(PbsParams p) {
     const bool flip = (rot & N) != 0;
     for (int x = tid; x < 2 * N; x += TEAM) acc[x >> 10][x & (N - 1)] = rot_coeff<N>(tv + (x >> 10) * N, x & (N - 1), a_lo, flip);
   }
-  __syncthreads();
+  workgroup_sync();
   uint64_t off = 1ull << (63 - L * Bg_bit);
 #pragma unroll
   for (int i = 0; i < L; i++) off += 1ull << (63 - i * Bg_bit);
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(64 * 2 * L) void pbs_team_kernel(PbsParams p) {
     fft.forward(re, im, xch[w], t);
 #pragma unroll
     for (int m = 0; m < 8; m++) xch[w][m * T + t] = d2{re[m], im[m]};
-    __syncthreads();
+    workgroup_sync();
     if (w < 2) {   // output component c = w: fma chain over the rows in order, inverse, round, accumulate
       double o_re[8], o_im[8];
 #pragma unroll
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(64 * 2 * L) void pbs_team_kernel(PbsParams p) {
         acc[w][M + m * T + t] = add_rounded<kReduce>(acc[w][M + m * T + t], o_im[m], scale);
       }
     }
-    __syncthreads();
+    workgroup_sync();
   }
   if (p.extract) {
     // src/trlwe.c:540-552 at idx = 0
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(F::THREADS * WideTeams<L>::value) void pbs_wide_tea
     const bool flip = (rot & N) != 0;
     for (int x = tid; x < 2 * N; x += WG) acc[x] = rot_coeff<N>(tv + (x / N) * N, x & (N - 1), a_lo, flip);
   }
-  __syncthreads();
+  workgroup_sync();
   uint64_t off = 1ull << (63 - L * Bg_bit);
 #pragma unroll
   for (int i = 0; i < L; i++) off += 1ull << (63 - i * Bg_bit);
@@ -633,8 +633,8 @@ __global__ __launch_bounds__(F::THREADS * WideTeams<L>::value) void pbs_wide_tea
       double re[8], im[8];
       if (row >= R) {   // ragged last phase: no row for this team -- keep the barrier sequence, leave the FP64 pipe to the others
         F::transform_barriers_only();
-        __syncthreads();
-        __syncthreads();
+        workgroup_sync();
+        workgroup_sync();
         continue;
       }
       {
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(F::THREADS * WideTeams<L>::value) void pbs_wide_tea
       fft.forward(re, im, xch, t);
 #pragma unroll
       for (int m = 0; m < 8; m++) xch[m * T + t] = d2{re[m], im[m]};
-      __syncthreads();
+      workgroup_sync();
       if (mac) {   // fma chain over the phase's rows in order
 #pragma unroll
         for (int r = 0; r < TEAMS; r++) {
@@ -668,7 +668,7 @@ __global__ __launch_bounds__(F::THREADS * WideTeams<L>::value) void pbs_wide_tea
           }
         }
       }
-      __syncthreads();   // the transformed digits are consumed: the buffers are free for the next phase's exchanges / the inverse
+      workgroup_sync();   // the transformed digits are consumed: the buffers are free for the next phase's exchanges / the inverse
     }
     if (mac) {   // (workgroup barriers inside: the other teams walk the same barriers)
       fft.inverse(o_re, o_im, xch, t);
@@ -681,7 +681,7 @@ __global__ __launch_bounds__(F::THREADS * WideTeams<L>::value) void pbs_wide_tea
     } else {
       F::transform_barriers_only();
     }
-    __syncthreads();
+    workgroup_sync();
   }
   if (p.extract) {
     // src/trlwe.c:540-552 at idx = 0
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(2 * F::THREADS) void pbs_wide_pair_kernel(PbsParams
     const bool flip = (rot & N) != 0;
     for (int x = tid; x < 2 * N; x += WG) acc[x] = rot_coeff<N>(tv + (x / N) * N, x & (N - 1), a_lo, flip);
   }
-  __syncthreads();
+  workgroup_sync();
   uint64_t off = 1ull << (63 - L * Bg_bit);
 #pragma unroll
   for (int i = 0; i < L; i++) off += 1ull << (63 - i * Bg_bit);
@@ -793,7 +793,7 @@ __global__ __launch_bounds__(2 * F::THREADS) void pbs_wide_pair_kernel(PbsParams
           o_im[m] = __builtin_fma(d.y, k.x, __builtin_fma(d.x, k.y, o_im[m]));
         }
       }
-      __syncthreads();
+      workgroup_sync();
 #pragma unroll
       for (int r = 2; r < 4; r++) {
         const d2 *__restrict__ dr = hand + (size_t)r * M;
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(2 * F::THREADS) void pbs_wide_pair_kernel(PbsParams
           o_im[m] = __builtin_fma(d.y, k.x, __builtin_fma(d.x, k.y, o_im[m]));
         }
       }
-      __syncthreads();   // the hand-over buffers are consumed
+      workgroup_sync();   // the hand-over buffers are consumed
     }
     fft.inverse(o_re, o_im, xch, t);
     uint64_t *accw = acc + (size_t)team * N;
@@ -813,7 +813,7 @@ __global__ __launch_bounds__(2 * F::THREADS) void pbs_wide_pair_kernel(PbsParams
       accw[m * T + t] = add_rounded<kReduce>(accw[m * T + t], o_re[m], scale);
       accw[M + m * T + t] = add_rounded<kReduce>(accw[M + m * T + t], o_im[m], scale);
     }
-    __syncthreads();
+    workgroup_sync();
   }
   if (p.extract) {
     uint64_t *dst = p.out + b * (size_t)(N + 1);
@@ -1096,7 +1096,7 @@ struct GaWide {
       } else {
         F::transform_barriers_only();
       }
-      __syncthreads();
+      workgroup_sync();
 #pragma unroll
       for (int r = 0; r < 2; r++) {
         if (r >= in_phase) continue;
@@ -1108,7 +1108,7 @@ struct GaWide {
           o_im[m] = __builtin_fma(d.y, k.x, __builtin_fma(d.x, k.y, o_im[m]));
         }
       }
-      __syncthreads();
+      workgroup_sync();
     }
     fft.inverse(o_re, o_im, xch, t);
   }
@@ -1123,7 +1123,7 @@ struct GaWide {
       accw[m * T + t] = round_mod_2_64(o_re[m], scale);
       accw[M + m * T + t] = round_mod_2_64(o_im[m], scale);
     }
-    __syncthreads();
+    workgroup_sync();
   }
 
   // acc <- Auto_gen(acc): permute both components in place (out[(i gen) mod N] = +-in[i]), then key switch component a with `entry`:
@@ -1133,13 +1133,13 @@ struct GaWide {
     uint64_t v[PER];
 #pragma unroll
     for (int j = 0; j < PER; j++) v[j] = acc[j * WG + tid];
-    __syncthreads();
+    workgroup_sync();
 #pragma unroll
     for (int j = 0; j < PER; j++) {
       const int x = j * WG + tid, c = x / N, i = x & (N - 1), ig = i * gen;
       acc[c * N + (ig & (N - 1))] = (ig & N) ? (0 - v[j]) : v[j];
     }
-    __syncthreads();
+    workgroup_sync();
     double o_re[8], o_im[8];
     product(o_re, o_im, entry, l);
     uint64_t *accw = acc + (size_t)team * N;
@@ -1156,7 +1156,7 @@ struct GaWide {
         accw[M + m * T + t] -= round_mod_2_64(o_im[m], scale);
       }
     }
-    __syncthreads();
+    workgroup_sync();
   }
 };
 
@@ -1188,7 +1188,7 @@ __global__ __launch_bounds__(2 * F::THREADS) void pbs_ga_wide_kernel(GaParams g,
     const bool flip = (rot & N) != 0;
     for (int x = tid; x < 2 * N; x += WG) acc[x] = rot_coeff<N>(tv + (x / N) * N, x & (N - 1), a_lo, flip);
   }
-  __syncthreads();
+  workgroup_sync();
   const GaWide<F> w{fft, xch_all, xch_all + (size_t)team * F::XCH_SLOTS, acc, team, t, tid, l, Bg_bit, off, (1u << Bg_bit) - 1, 1 << (Bg_bit - 1)};
   const uint32_t mask = 2 * N - 1;
   uint32_t a_cur = modswitch<LOG2N2>(ct[0]) | 1u;
@@ -1404,7 +1404,7 @@ __global__ __launch_bounds__(F::THREADS) void dft_to_torus_kernel(const d2 *__re
 template <class F, int L, bool CMUX>
 constexpr bool ep_pipelined_by_default() {
   // one-wavefront teams always; two-wavefront teams with the rows taken in pairs (pass twiddles in LDS) at l = 4 without the CMUX operand -- the one multi-wavefront
-  // instantiation that is faster pipelined AND has been soaked (tools/soak.py); see the note in the kernel body
+  // instantiation that is FASTER pipelined (-11 % at lvl2); the others are slower that way (see the note in the kernel body)
   return F::THREADS == 64 || (F::kForward2 && F::kLtw && L % 2 == 0 && !CMUX && L == 4);
 }
 template <class F, int L, int BG, bool CMUX, int FORM = 0>
@@ -1458,22 +1458,17 @@ __global__ __launch_bounds__(F::THREADS, 2) void external_product_kernel(const d
   };
   if constexpr (!kPipe) {
     // PLAIN loop: component loop rolled, each component requested where it is used.  What every ring of two or four wavefronts per team takes, with one
-    // exception (ep_pipelined_by_default).  The pipelined form below is (a) not faster on these rings in general (SET_2: 0.249-0.292 vs 0.237-0.243 ms: the teams
-    // are issue-bound, and the first key-row wait of a unit waits for the older ciphertext loads too) and (b) has a failure mode on them that is NOT understood to
-    // the end: at l = 1 on N = 2048 / 4096, 1-2 % of the units of a launch come out wrong (whole units, a different set every launch).
-    // What round 5's assembly-level bisection of ONE failing build established (tools/spill_hazard, experiments/README.md "Round 5", profiles/r05_spill_hazard_*.txt):
-    //   * it is NOT the register spills round 3 blamed: the same listing with the two spilled words kept in LDS instead of scratch fails alike, and a copy of every
-    //     spilled word kept in LDS always equals what scratch returns;
-    //   * no wait is too weak: every partial s_waitcnt vmcnt(N) of the loop replaced by vmcnt(0) still fails, as does lgkmcnt(0) behind every DS instruction, a
-    //     workgroup barrier (with or without a full drain) at the top of the loop, vmcnt(0) in front of every barrier; the key-row words are what memory holds when
-    //     they are used (checked in place against a drained re-read);
-    //   * it IS a matter of time and of neighbours: one workgroup per CU never fails, two rarely, three and four at 0.4 % and 1.5 % of the units; the first workgroup
-    //     of a CU never fails, wherever its LDS sits; s_nop 3 / 15 / 4 x 15 / s_sleep 8 behind each key-row load cut the failures to 135 / 26 / 3 / 0 units of
-    //     5 x 16,384, and vmcnt(0) behind each key-row load (issue serialised) removes them.
-    // A wrong unit is not the product of any whole component of a neighbouring unit.  No instruction sequence in the listing violates a documented hazard or the
-    // in-order completion model (tools/ab/wcheck.py over all three paths through the loop).  Consequence: the pipelined loop runs on multi-wavefront teams only
-    // where it has been SOAKED -- lvl2's <Fft2048L, 4, *> without the CMUX operand: 1.3 x 10^9 units in 80,000 launches without one differing bit
-    // (tools/soak.py, profiles/r05_soak_*.txt) -- and the launcher drops back to this loop when that instantiation's build changes (capi.hip: ep_go).
+    // exception (ep_pipelined_by_default): the pipelined form below is not faster on these rings in general (SET_2: 0.249-0.292 vs 0.237-0.243 ms: the teams are
+    // issue-bound, and the first key-row wait of a unit waits for the older ciphertext loads too).
+    // History of a bug that lived here (rounds 3 - 5; experiments/README.md "Round 5"): with the pipelined loop, the l = 1 builds of N = 2048 / 4096 gave 1 - 2 % wrong
+    // units per launch.  Cause, found in round 5 by patching one failing listing at assembly level and then reading the DFT-domain results slot by slot: the
+    // COMPILER had sunk the last LDS reads of forward_head (layout D) and the pass behind them from in front of forward_tail's workgroup barrier into the block
+    // behind the `if (next unit) request(...)` branch that follows it -- LLVM's machine sinking does not count S_BARRIER or the fences around it as a store -- so the
+    // other wavefront of the team, released by the barrier, could write the next transform's first exchange over data this one had not read yet.  It showed only
+    // where a conditional branch follows a barrier closely (this loop form), only on teams with a real barrier (two or four wavefronts), only when the two wavefronts
+    // drift apart by more than a row's products (memory contention: several workgroups per CU) -- and never had anything to do with the register spills round 3
+    // blamed.  Fixed at the root: every workgroup barrier of this library goes through workgroup_sync() (negacyclic_fft.h), which pins memory accesses to their
+    // side of the barrier; tests/test_host_and_abi.py checks the generated code for the pattern, tests/test_gpu_parity.py runs the once-failing builds.
     for (size_t u = blockIdx.x; u < (size_t)count; u += gridDim.x) {
       const d2 *__restrict__ bkrow = bkrow0 + u * key_stride;
       double o_re[2][8], o_im[2][8];
@@ -1574,7 +1569,7 @@ __global__ __launch_bounds__(512, 2) void external_product_ldskey_kernel(const d
 #pragma unroll
   for (int i = 0; i < L; i++) off += 1ull << (63 - i * Bg_bit);
   const RoundCtx scale(0x1p-64 / (double)M);
-  __syncthreads();
+  workgroup_sync();
   const size_t first = (size_t)blockIdx.x * TEAMS + w, stride = (size_t)gridDim.x * TEAMS;
 
   uint64_t raw_lo[8], raw_hi[8];

@@ -425,11 +425,12 @@ static int kernel_scratch_bytes(K kernel) {
   return (int)a.localSizeBytes;
 }
 
-// Which unit loop a multi-wavefront external-product instantiation takes (external_product_kernel: FORM).  The software-pipelined loop on rings of two or four
-// wavefronts has a failure mode that is not understood to the end (1 - 2 % of the units of a launch wrong on the l = 1 builds of N = 2048 / 4096 when several
-// workgroups share a CU; bootstrap_kernels.h, experiments/README.md "Round 5"): the launcher takes it only for the instantiation that has been soaked clean
-// (tools/soak.py) AND only while that instantiation is what was soaked -- a build without scratch.  A compiler that starts spilling there changes the schedule into one
-// nobody has measured: the plain loop then (always bit-exact, 11 % slower at lvl2).  MOSFHET_HIP_EP_PAIRS=0 forces the plain loop as well.
+// Which unit loop a multi-wavefront external-product instantiation takes (external_product_kernel: FORM).  The software-pipelined loop is taken where it is faster
+// (ep_pipelined_by_default: lvl2's <Fft2048L, 4, *> without the CMUX operand).  Its wrong-unit failure of rounds 3 - 5 was a compiler reordering of LDS reads
+// across a workgroup barrier, fixed at the root in round 5 (negacyclic_fft.h: workgroup_sync; bootstrap_kernels.h has the story).  The launcher still asks the
+// runtime for that instantiation's scratch size at its first launch and takes the plain loop (same bits) when it is not zero: not for correctness any more, but
+// because the pipelined form was measured (+11 %) and soaked (tools/soak.py) as a scratch-free build only -- a build that spills in-flight ciphertext words is a
+// different kernel and most likely the slower one.  MOSFHET_HIP_EP_PAIRS=0 / mosfhet_hip_set_ep_plain_loop force the plain loop.
 struct EpKernelInfo { const char *name; int pipelined_by_default, scratch_bytes, takes_pipelined; };
 static std::mutex g_ep_info_lock;
 static std::vector<EpKernelInfo> g_ep_info;   // every instantiation that has been asked about (mosfhet_hip_ep_kernel_info)

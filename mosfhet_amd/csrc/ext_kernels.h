@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void mv_phase2_kernel(const uint64_t *__restri
       }
       tmp[pos] = v;
     }
-    __syncthreads();
+    workgroup_sync();
     const int amount = 1 << j;
     // subtracted extractions: idx = N - 1 - (i - amount/2), i in [amount/2, amount); added: idx = i < amount/2
     for (int e = 0; e < amount; e++) {
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void mv_phase2_kernel(const uint64_t *__restri
       }
       if (tid == 0) acc_b += add ? tmp[N + idx] : (uint64_t)0 - tmp[N + idx];
     }
-    __syncthreads();
+    workgroup_sync();
   }
   uint64_t *o = out + (size_t)blockIdx.x * (N + 1);
 #pragma unroll
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(2 * F::THREADS) void ubr_phase2_wide_kernel(const d
     const bool flip = (rot & N) != 0;
     for (int x = tid; x < 2 * N; x += WG) acc[x] = rot_coeff<N>(tv + (x / N) * N, x & (N - 1), a_lo, flip);
   }
-  __syncthreads();
+  workgroup_sync();
   uint64_t off = 1ull << (63 - l * Bg_bit);
   for (int i = 0; i < l; i++) off += 1ull << (63 - i * Bg_bit);
   const uint32_t mask = (1u << Bg_bit) - 1;
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(2 * F::THREADS) void ubr_phase2_wide_kernel(const d
       fft.forward(re, im, xch, t);
 #pragma unroll
       for (int m = 0; m < 8; m++) xch[m * T + t] = d2{re[m], im[m]};
-      __syncthreads();
+      workgroup_sync();
 #pragma unroll
       for (int r = 0; r < 2; r++) {
         const d2 *__restrict__ dr = xch_all + (size_t)r * F::XCH_SLOTS;
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(2 * F::THREADS) void ubr_phase2_wide_kernel(const d
           o_im[m] = __builtin_fma(d.y, k.x, __builtin_fma(d.x, k.y, o_im[m]));
         }
       }
-      __syncthreads();
+      workgroup_sync();
     }
     fft.inverse(o_re, o_im, xch, t);
     uint64_t *accw = acc + (size_t)team * N;
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(2 * F::THREADS) void ubr_phase2_wide_kernel(const d
       accw[m * T + t] = round_mod_2_64(o_re[m], scale);
       accw[M + m * T + t] = round_mod_2_64(o_im[m], scale);
     }
-    __syncthreads();
+    workgroup_sync();
   }
   uint64_t *o = out + (size_t)blockIdx.x * (2 * N);
   for (int x = tid; x < 2 * N; x += WG) o[x] = acc[x];

@@ -33,7 +33,7 @@ __device__ __forceinline__ void general_forward(d2 *z, const d2 *__restrict__ tw
       *lo = d2{ar, ai};
       *hi = d2{br, bi};
     }
-    __syncthreads();
+    workgroup_sync();
   }
 }
 
@@ -52,7 +52,7 @@ __device__ __forceinline__ void general_inverse(d2 *z, const d2 *__restrict__ tw
       *lo = d2{ur, ui};
       *hi = d2{vr, vi};
     }
-    __syncthreads();
+    workgroup_sync();
   }
 }
 
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(GEN_THREADS) void pbs_general_kernel(GeneralParams 
       acc[x] = rot_coeff_rt(tv + (size_t)c * N, i, a_lo, flip, N);
     }
   }
-  __syncthreads();
+  workgroup_sync();
   uint64_t off = 1ull << (63 - l * Bg);
   for (int i = 0; i < l; i++) off += 1ull << (63 - i * Bg);
   const RoundCtx scale(p.logM);
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(GEN_THREADS) void pbs_general_kernel(GeneralParams 
           const uint64_t lo = rot_coeff_rt(src, x, a_lo, flip, N) - src[x] + off, hi = rot_coeff_rt(src, x + M, a_lo, flip, N) - src[x + M] + off;
           z[x] = d2{digit_rt(lo, j, Bg), digit_rt(hi, j, Bg)};
         }
-        __syncthreads();
+        workgroup_sync();
         general_forward(z, p.tw, p.logM);
         const d2 *__restrict__ row = bkrow + (size_t)(q * l + j) * (k + 1) * M;
         const bool first = (q == 0 && j == 0);
@@ -140,12 +140,12 @@ __global__ __launch_bounds__(GEN_THREADS) void pbs_general_kernel(GeneralParams 
             o.y = __builtin_fma(d.y, kk.x, __builtin_fma(d.x, kk.y, o.y));
             prod[(size_t)c * M + x] = o;     // same thread reads and writes slot x of every row: no cross-thread hazard in global memory
           }
-        __syncthreads();
+        workgroup_sync();
       }
     }
     for (int c = 0; c <= k; c++) {
       for (int x = threadIdx.x; x < M; x += GEN_THREADS) z[x] = prod[(size_t)c * M + x];
-      __syncthreads();
+      workgroup_sync();
       general_inverse(z, p.tw, p.logM);
       uint64_t *dst = acc + (size_t)c * N;
       for (int x = threadIdx.x; x < M; x += GEN_THREADS) {
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(GEN_THREADS) void pbs_general_kernel(GeneralParams 
         dst[x] += round_mod_2_64(v.x, scale);           // src/trlwe.c:629-634 + :437-439
         dst[x + M] += round_mod_2_64(v.y, scale);
       }
-      __syncthreads();
+      workgroup_sync();
     }
   }
   if (p.extract) {
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(GEN_THREADS) void external_product_general_kernel(c
         const uint64_t lo = sub ? src[x] - sub[x] : src[x], hi = sub ? src[x + M] - sub[x + M] : src[x + M];
         z[x] = d2{digit_rt(lo + off, j, Bg), digit_rt(hi + off, j, Bg)};
       }
-      __syncthreads();
+      workgroup_sync();
       general_forward(z, tw, logM);
       const d2 *__restrict__ row = g + (size_t)(q * l + j) * (k + 1) * M;
       const bool first = (q == 0 && j == 0);
@@ -204,12 +204,12 @@ __global__ __launch_bounds__(GEN_THREADS) void external_product_general_kernel(c
           o.y = __builtin_fma(d.y, kk.x, __builtin_fma(d.x, kk.y, o.y));
           prod[(size_t)c * M + x] = o;
         }
-      __syncthreads();
+      workgroup_sync();
     }
   }
   for (int c = 0; c <= k; c++) {
     for (int x = threadIdx.x; x < M; x += GEN_THREADS) z[x] = prod[(size_t)c * M + x];
-    __syncthreads();
+    workgroup_sync();
     general_inverse(z, tw, logM);
     uint64_t *dst = out + (b * (size_t)(k + 1) + c) * N;
     const uint64_t *add = base_all ? base_all + (size_t)c * N : nullptr;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(GEN_THREADS) void external_product_general_kernel(c
       dst[x] = add ? add[x] + r0 : r0;
       dst[x + M] = add ? add[x + M] + r1 : r1;
     }
-    __syncthreads();
+    workgroup_sync();
   }
 }
 
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(GEN_THREADS) void torus_to_dft_general_kernel(const
   const int M = N / 2;
   const uint64_t *src = in + (size_t)blockIdx.x * N;
   for (int x = threadIdx.x; x < M; x += GEN_THREADS) z[x] = d2{torus_to_double(src[x]), torus_to_double(src[x + M])};
-  __syncthreads();
+  workgroup_sync();
   general_forward(z, tw, logM);
   d2 *dst = out + (size_t)blockIdx.x * M;
   for (int x = threadIdx.x; x < M; x += GEN_THREADS) dst[x] = z[x];
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(GEN_THREADS) void dft_to_torus_general_kernel(const
   const int M = N / 2;
   const d2 *src = in + (size_t)blockIdx.x * M;
   for (int x = threadIdx.x; x < M; x += GEN_THREADS) z[x] = src[x];
-  __syncthreads();
+  workgroup_sync();
   general_inverse(z, tw, logM);
   const RoundCtx scale(logM);
   uint64_t *dst = out + (size_t)blockIdx.x * N;

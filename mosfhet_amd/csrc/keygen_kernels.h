@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "negacyclic_fft.h"   // workgroup_sync()
+
 namespace mosfhet {
 
 __device__ __forceinline__ uint64_t keygen_mix(uint64_t seed, uint64_t row, uint64_t idx, uint64_t stream) {
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256) void trlwe_table_keygen_kernel(uint64_t *__res
     a[x] = ax;
     if (!compressed) dst[x] = ax;
   }
-  __syncthreads();
+  workgroup_sync();
   const int slot = kind == 2 ? i % slots : 0, span = N / slots;
   const uint64_t s_i = kind == 2 ? s_in[i / slots] : (i < n ? s_in[i] : ~0ull);
   const uint64_t dec = s_i * (uint64_t)v * (1ull << (64 - (j + 1) * base_bit));
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void trgsw_bk_keygen_kernel(uint64_t *__restri
     key_is_binary = binary;
   }
   for (int x = tid; x < N; x += 256) a[x] = keygen_mix(seed, r, x, 0);
-  __syncthreads();
+  workgroup_sync();
   const uint64_t h = 1ull << (64 - (j + 1) * Bg_bit);
   // ga: TRGSW(X^{s_i}) for ANY integer key coefficient (bounded keys, src/bootstrap_ga.c:17-20 with tlwe_new_bounded_key): exponent mod 2N, X^N = -1
   const int e_full = ga ? (int)(s_in[i] & (uint64_t)(2 * N - 1)) : 0;
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(256) void trgsw_bk_keygen_k_kernel(uint64_t *__rest
   uint64_t *dst = rows + r * (size_t)(k + 1) * N, *dst_b = dst + (size_t)k * N;
   const uint64_t val = s_in[i] * (1ull << (64 - (j + 1) * Bg_bit));
   for (int m = 0; m < k; m++) {
-    __syncthreads();   // the previous mask's LDS image is consumed
+    workgroup_sync();   // the previous mask's LDS image is consumed
     const uint64_t *s_m = s_out + (size_t)m * N;
     if (tid == 0) {
       int cnt = 0;
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(256) void trgsw_bk_keygen_k_kernel(uint64_t *__rest
       n_ones = cnt;
     }
     for (int x = tid; x < N; x += 256) a[x] = keygen_mix(seed, r, x, (uint64_t)m);
-    __syncthreads();
+    workgroup_sync();
     const int cnt = n_ones;
     for (int x = tid; x < N; x += 256) {   // (a thread owns the same words x in every pass: the read-modify-write of dst_b needs no barrier)
       uint64_t acc = m ? dst_b[x] : 0;
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256) void trlwe_poly_keygen_kernel(uint64_t *__rest
     a[x] = ax;
     dst[x] = ax;
   }
-  __syncthreads();
+  workgroup_sync();
   const int shift = 64 - (j + 1) * base_bit, cnt = n_ones;
   for (int x = tid; x < N; x += 256) {
     uint64_t acc = 0;

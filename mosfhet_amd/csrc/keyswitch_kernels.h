@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void transpose_u64_kernel(const uint64_t *__re
       for (int s = 0; s < parts; s++) v += in[(size_t)s * part_stride + (size_t)r * ldin + c];
     tile[k][threadIdx.x] = v;
   }
-  __syncthreads();
+  workgroup_sync();
   for (int k = threadIdx.y; k < 32; k += 8) {
     const int c = c0 + k, r = r0 + threadIdx.x;
     if (c < C && r < R) out[(size_t)c * ldout + r] = tile[threadIdx.x][k];
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64 * NW) void tlwe_keyswitch_kernel(const uint64_t 
 #pragma unroll
       for (int k = 0; k < PF; k++)
         if (in_row && sv0 + k * SV_STEP < jb * cands) buf[slot[k]] = 0 - pf[k];   // rows are staged NEGATED: the inner op is a 64-bit add
-      __syncthreads();  // stage data visible; the other buffer is free (its readers passed the previous barrier)
+      workgroup_sync();  // stage data visible; the other buffer is free (its readers passed the previous barrier)
       // next stage: (i, j0 + JB) or (i + 1, 0)
       {
         int ni = i, nj = j0 + JB;

@@ -259,7 +259,18 @@ struct Fft1024 {
 // Only the A<->B exchange crosses the two wavefronts (workgroup barriers); B<->C and C<->D are wave-local (wave-level ordering).
 // Slot order of the DFT domain = layout D: device index m * 128 + thread.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void team_sync() { __syncthreads(); }
+// Workgroup barrier of this library.  NEVER call __syncthreads() directly: LLVM's machine-level sinking (ROCm 7.2.0, clang 22) moves LDS loads that stand IN
+// FRONT of a barrier into a successor block BEHIND it when their only uses are there -- neither S_BARRIER nor the fences around it count as a store for that pass --
+// so another wavefront, released by the barrier, can overwrite what this one has not read yet.  That is the root cause of the "wrong units" of the pipelined
+// external-product loop on two-wavefront teams (rounds 3 - 5; experiments/README.md "Round 5": the D-layout reads of forward_head sunk behind forward_tail's barrier
+// into the block behind the conditional next-unit request).  An empty asm with a memory clobber on both sides reads and writes memory as far as every pass is
+// concerned, which pins loads and stores to their side of the barrier; it emits nothing.
+__device__ __forceinline__ void workgroup_sync() {
+  asm volatile("" ::: "memory");
+  __syncthreads();
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void team_sync() { workgroup_sync(); }
 
 // TAIL3 = false: levels grouped 3 + 3 + 3 + 1 over the four layouts (pass C = levels 6-8, pass D = level 9).
 // TAIL3 = true:  3 + 3 + 1 + 3 (pass C = level 6, the top register bit of layout C; pass D = levels 7-9): the pass the caller overlaps with its key-row
@@ -578,7 +589,7 @@ __device__ __forceinline__ void fft_setup(F &fft, const d2 *__restrict__ tw, int
   if constexpr (F::kLtw) {
     __shared__ __attribute__((aligned(16))) d2 ltw_tab[F::LTW_SLOTS];
     fft.init_ltw(tw, t, ltw_tab);
-    __syncthreads();
+    workgroup_sync();
   }
 }
 

@@ -152,6 +152,27 @@ def test_kernel_table_of_the_build(native_lib):
     assert len(rows) < 330, "%d kernel instantiations" % len(rows)
 
 
+def test_no_lds_reads_emitted_behind_a_workgroup_barrier():
+    """The root cause of the "wrong units" of rounds 3 - 5 (experiments/README.md, Round 5) was the COMPILER moving LDS reads that the source places in front of a
+    workgroup barrier behind it (machine sinking into the block after a conditional branch; S_BARRIER is no store to that pass).  Every barrier of the library now goes
+    through workgroup_sync() (negacyclic_fft.h).  This holds the generated code to it: the external-product kernel in the loop forms and rings that used to fail, and
+    lvl2's production form, are compiled to device listings (seconds, no GPU) and checked by tools/check_lds_barriers.py; the checker itself is held to a listing
+    fragment with the old symptom."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_lds_barriers as chk
+    bad_listing = "\n".join(["_Z1kv:", "\tds_write_b128 v1, v[2:5]", "\t; wave barrier", "\ts_waitcnt lgkmcnt(0)", "\ts_barrier", "\ts_cbranch_vccnz .LBB0_2", ".LBB0_2:",
+                             "\tds_read_b128 v[2:5], v6", "\ts_endpgm"])
+    good_listing = bad_listing.replace("\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n", "").replace("\tds_read_b128 v[2:5], v6\n", "\tds_read_b128 v[2:5], v6\n\ts_barrier\n")
+    assert len(chk.check(bad_listing)) == 1 and chk.check(good_listing) == []
+    assert chk.build_and_check() == []
+    # and no kernel source calls the raw barrier: only workgroup_sync() itself does
+    for name in os.listdir(os.path.join(ROOT, "mosfhet_amd", "csrc")):
+        if name.endswith((".h", ".inc", ".hip")):
+            text = re.sub(r"//.*", "", open(os.path.join(ROOT, "mosfhet_amd", "csrc", name)).read())
+            assert text.count("__syncthreads()") == (1 if name == "negacyclic_fft.h" else 0), name
+
+
 def test_switch_table_matches_the_source():
     """docs/SWITCHES.md (generated by tools/switch_table.py) names every getenv("MOSFHET_...") of the product source and nothing else, and every test it cites exists."""
     import sys

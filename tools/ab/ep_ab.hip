@@ -16,11 +16,16 @@ using namespace mosfhet;
 #if AB_N == 1024
 using ABF = Fft1024;
 #elif AB_N == 2048
+#ifdef AB_LTW
+using ABF = Fft2048L;   // pass twiddles in LDS, rows two at a time: lvl2's production transform
+#else
 using ABF = Fft2048;
+#endif
 #else
 using ABF = Fft4096;
 #endif
 extern "C" int ab_ep_bg_rt = 0;   // run-time gadget base of AB_BG = 0 builds
+extern "C" double *ab_ep_out_dft = nullptr;      // != nullptr: the result stays in the DFT domain (no inverse transforms, no rounding): which half of a unit goes wrong?
 extern "C" const uint64_t *ab_ep_in0 = nullptr;   // passed as `in0` (unused without CMUX): the debug buffer of tools/spill_hazard
 extern "C" int ab_ep(const double *d_row, const double *d_tw, const uint64_t *d_in, uint64_t *d_out, int count, int grid, int reps, float *ms_per_launch) {
   hipEvent_t e0, e1;
@@ -28,7 +33,7 @@ extern "C" int ab_ep(const double *d_row, const double *d_tw, const uint64_t *d_
   hipEventRecord(e0, nullptr);
   for (int r = 0; r < reps; r++)
     hipLaunchKernelGGL((external_product_kernel<ABF, AB_L, AB_BG, false, AB_FORM>), dim3((unsigned)grid), dim3(ABF::THREADS), 0, nullptr, (const d2 *)d_row, (const d2 *)d_tw, d_in, d_out,
-                       AB_BG ? AB_BG : ab_ep_bg_rt, count, (size_t)0, (size_t)(2 * ABF::N), ab_ep_in0, (d2 *)nullptr);
+                       AB_BG ? AB_BG : ab_ep_bg_rt, count, (size_t)0, (size_t)(2 * ABF::N), ab_ep_in0, (d2 *)ab_ep_out_dft);
   hipEventRecord(e1, nullptr);
   if (hipEventSynchronize(e1) != hipSuccess) return -2;
   float ms = 0.f;

@@ -122,6 +122,46 @@ def run_ep(B, rounds, grids, pset="set1", names=None):
     for lib in libs.values():
         C.c_int.in_dll(lib, "ab_ep_bg_rt").value = P["Bg_bit"]
     out = eng.empty(B, 2, P["N"])
+    if os.environ.get("AB_OUT_DFT"):
+        # DFT-domain results (trgsw_mul_trlwe_DFT before trlwe_from_DFT) of every variant against the FIRST one named: is a wrong unit already wrong in front of the
+        # inverse transforms?
+        ref = None
+        dft = torch.zeros(B, 2, P["N"], dtype=torch.float64, device=eng.device)
+        for name, lib in sorted(libs.items(), key=lambda kv: (kv[0] != os.environ.get("AB_OUT_DFT_REF", "sh_plain"), kv[0])):
+            C.c_void_p.in_dll(lib, "ab_ep_out_dft").value = dft.data_ptr()
+            for rep in range(int(os.environ["AB_OUT_DFT"])):
+                dft.zero_()
+                ms = C.c_float()
+                rc = lib.ab_ep(C.c_void_p(d_row), C.c_void_p(d_tw.data_ptr()), C.c_void_p(d_in.data_ptr()), C.c_void_p(out.data_ptr()), B, grids[0], 1, C.byref(ms))
+                assert rc == 0
+                torch.cuda.synchronize()
+                if ref is None:
+                    ref = dft.clone()
+                    print("DFT-domain reference: %s" % name)
+                    break
+                bad = (dft.view(torch.int64) != ref.view(torch.int64)).reshape(B, -1).any(dim=1).nonzero().flatten().cpu().numpy()
+                print("   %s launch %d: %d of %d DFT-domain results differ from the reference's (first %s; blocks below 256: %d)" % (name, rep, len(bad), B, bad[:6].tolist(), int((bad % grids[0] < 256).sum())))
+                if rep == 0 and len(bad):
+                    # WHERE in a wrong unit: slot = register m (8) x thread t (T), per output component; the products are lane-local, so the pattern names the operand
+                    T = P["N"] // 16
+                    g = dft[torch.from_numpy(bad[:400]).to(dft.device)].view(torch.int64).cpu().numpy().reshape(-1, 2, 8, T, 2)
+                    w = ref[torch.from_numpy(bad[:400]).to(dft.device)].view(torch.int64).cpu().numpy().reshape(-1, 2, 8, T, 2)
+                    diff = (g != w).any(axis=4)                       # [units][component][m][t]
+                    kinds = {}
+                    for u in range(diff.shape[0]):
+                        c0, c1 = diff[u, 0], diff[u, 1]
+                        regs = tuple(int(x) for x in np.nonzero((c0 | c1).any(axis=1))[0])
+                        waves = tuple(int(x) for x in np.nonzero([(c0 | c1)[:, :64].any(), (c0 | c1)[:, 64:].any()])[0])
+                        key = ("both components" if c0.any() and c1.any() else ("component 0 only" if c0.any() else "component 1 only"),
+                               "same slots in both" if (c0 == c1).all() else "different slots", "registers %s" % (regs,), "waves %s" % (waves,), "%d slots" % int((c0 | c1).sum()))
+                        kinds[key] = kinds.get(key, 0) + 1
+                    for key, cnt in sorted(kinds.items(), key=lambda kv: -kv[1])[:12]:
+                        print("      %4d units: %s" % (cnt, ", ".join(key)))
+                    u = 0
+                    ts = np.nonzero((diff[u, 0] | diff[u, 1]).any(axis=0))[0]
+                    print("      unit %d: wrong threads %s%s" % (bad[0], ts[:24].tolist(), " ..." if len(ts) > 24 else ""))
+            C.c_void_p.in_dll(lib, "ab_ep_out_dft").value = None
+        return
     unit_bytes = 2 * 2 * P["N"] * 8
     res = {}
     reps = int(os.environ.get("AB_REPS", "5"))
