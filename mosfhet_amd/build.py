@@ -15,7 +15,7 @@ LIB = os.path.join(HERE, "libmosfhet_hip.so")
 HIP_SOURCES = ["capi.hip"]
 HOST_C_SOURCES = ["host/mosfhet_compat.c", "host/mosfhet_compat_dft.c", "host/mosfhet_compat_multi.c", "host/mosfhet_compat_legacy.c", "host/mosfhet_compat_extra.c", "host/csprng.c"]
 DEPS = ["negacyclic_fft.h", "bootstrap_kernels.h", "general_kernels.h", "keyswitch_kernels.h", "ext_kernels.h", "unfold_kernels.h", "keygen_kernels.h", "capi_ext.inc", "capi_dft.inc", "capi_vec.inc", "../../include/mosfhet_hip.h",
-        "../../include/mosfhet_compat.h", "../../include/mosfhet.h", "host/compat_internal.h", "../build.py"]
+        "../../include/mosfhet_compat.h", "../../include/mosfhet.h", "host/compat_internal.h", "../build.py", "../../tools/check_lds_barriers.py"]
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value",
                "-Wno-comment"]
@@ -67,6 +67,28 @@ def build(force=False, verbose=False):
         lock.close()
 
 
+def _check_listing(objdir, src):
+    """the device listing -save-temps left behind: no LDS read behind the barrier its exchange stands in front of; then the temporaries go (tens of MB)"""
+    import glob
+    sys.path.insert(0, os.path.join(HERE, "..", "tools"))
+    import check_lds_barriers
+    stem = os.path.join(objdir, os.path.splitext(src)[0])
+    listing = stem + "-hip-amdgcn-amd-amdhsa-gfx950.s"
+    with open(listing) as fh:
+        text = fh.read()
+    bad = check_lds_barriers.check(text)
+    with open(os.path.join(objdir, "lds_barrier_check.txt"), "w") as fh:
+        fh.write("%s: %d kernels, %d wave-level exchanges, %d workgroup barriers, %d violations\n" % (src, text.count(".amdhsa_kernel "), text.count("; wave barrier"),
+                                                                                                   text.count("\ts_barrier"), len(bad)))
+        for v in bad:
+            fh.write("%s line %d: %s\n" % v)
+    for tmp in glob.glob(stem + "-hip-*") + glob.glob(stem + "-host-*") + glob.glob(stem + ".hip-hip-*"):
+        os.remove(tmp)
+    if bad:
+        raise RuntimeError("the compiler emitted LDS reads behind a workgroup barrier (%d places, first: %s line %d): see %s" % (
+            len(bad), bad[0][0], bad[0][1], os.path.join(objdir, "lds_barrier_check.txt")))
+
+
 def _build_locked(verbose):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
@@ -83,10 +105,13 @@ def _build_locked(verbose):
         objs.append(obj)
     for src in HIP_SOURCES:
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        cmd = [_hipcc()] + HIPCC_FLAGS + os.environ.get("MOSFHET_HIPCC_EXTRA", "").split() + ["-c", os.path.join(CSRC, src), "-o", obj]
+        # -save-temps=obj leaves the DEVICE LISTING of the very code that is linked next to the object: it is checked for LDS reads emitted behind a workgroup
+        # barrier (tools/check_lds_barriers.py: the compiler reordering behind the wrong units of rounds 3 - 5) before the library is allowed to exist
+        cmd = [_hipcc()] + HIPCC_FLAGS + os.environ.get("MOSFHET_HIPCC_EXTRA", "").split() + ["-save-temps=obj", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        _check_listing(objdir, os.path.basename(src))
         objs.append(obj)
     tmp = LIB + ".tmp.%d" % os.getpid()
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs + ["-lm"]
