@@ -166,6 +166,19 @@ def test_no_lds_reads_emitted_behind_a_workgroup_barrier():
     good_listing = bad_listing.replace("\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n", "").replace("\tds_read_b128 v[2:5], v6\n", "\tds_read_b128 v[2:5], v6\n\ts_barrier\n")
     assert len(chk.check(bad_listing)) == 1 and chk.check(good_listing) == []
     assert chk.build_and_check() == []
+    # the minimal reproducer (tools/spill_hazard/minimal_sink_past_barrier.hip): the form with workgroup_sync()'s clobbers must be clean; whether the raw form still shows
+    # the reordering is a property of the toolchain and is only reported (today, ROCm 7.2.0: it does)
+    import subprocess
+    import tempfile
+    import warnings
+    with tempfile.TemporaryDirectory() as tmp:
+        lst = os.path.join(tmp, "min.s")
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-S", "--cuda-device-only", "-o", lst, os.path.join(ROOT, "tools", "spill_hazard", "minimal_sink_past_barrier.hip")],
+                              stderr=subprocess.DEVNULL)
+        found = chk.check(open(lst).read())
+    assert all(v[0] == "k_raw" for v in found), found
+    if not found:
+        warnings.warn("this toolchain no longer sinks LDS loads behind s_barrier in the minimal reproducer (k_raw is clean)")
     # and no kernel source calls the raw barrier: only workgroup_sync() itself does
     for name in os.listdir(os.path.join(ROOT, "mosfhet_amd", "csrc")):
         if name.endswith((".h", ".inc", ".hip")):

@@ -23,7 +23,7 @@ def check(text):
     out, kernel, pending, wrote = [], None, None, False
     for no, raw in enumerate(text.split("\n"), 1):
         line = raw.strip()
-        m = re.match(r"^(_Z\w+):", line)
+        m = re.match(r"^(_Z\w+|k_raw|k_fixed):", line)
         if m:
             kernel, pending, wrote = m.group(1), None, False
             continue
