@@ -15,7 +15,7 @@ using namespace mosfhet;
 using ABF = Fft1024;
 #elif AB_N == 2048
 #ifdef AB_LTW
-using ABF = Fft2048L;          // pass twiddles in LDS; rows two at a time unless -DMOSFHET_PBS_PAIRS=0
+using ABF = Fft2048L;          // pass twiddles in LDS; rows two at a time (cmux_rows2)
 #else
 using ABF = Fft2048T<AB_WIDE>;
 #endif
