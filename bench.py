@@ -540,7 +540,7 @@ def main():
         ep = external_product_leg(eng, ma, host, P, args.ep_batch, measured_traffic, "latest_traffic_ep.json",
                                   "mosfhet::external_product_ldskey_kernel<2, 8, false>", torch)
         ep2 = external_product_leg(eng, ma, host, dict(ma.PARAMS_LVL2), max(64, args.ep_batch // 4), measured_traffic, "latest_traffic_ep_lvl2.json",
-                                   "mosfhet::external_product_kernel<mosfhet::Fft2048T<false, true>, 4, 9, false>", torch)
+                                   "mosfhet::external_product_kernel<mosfhet::Fft2048T<false, true>, 4, 9, false, 0>", torch)
 
     lvl2 = configs34 = None
     if rank == 0 and not args.no_lvl2:
