@@ -1266,7 +1266,10 @@ void mosfhet_gen_tlwe_ks_key_flat(Torus *out, TLWE_Key out_key, TLWE_Key in_key,
 }
 
 /* host view with the reference's shape s[i][j][v] (mosfhet.h:62-65): TLWE headers aliasing the flat table, which the key owns; + device copy */
-static TLWE_KS_Key tlwe_ks_wrap(Torus *flat, int n_in, int n_out, int t, int base_bit, const char *who) {
+static TLWE_KS_Key tlwe_ks_wrap_dev(Torus *flat, int n_in, int n_out, int t, int base_bit, const char *who, mosfhet_hip_ksk_t have);
+static TLWE_KS_Key tlwe_ks_wrap(Torus *flat, int n_in, int n_out, int t, int base_bit, const char *who) { return tlwe_ks_wrap_dev(flat, n_in, n_out, t, base_bit, who, NULL); }
+/* have != NULL: the device table already exists (made there: tlwe_new_KS_key) and `flat` is its exported image; otherwise `flat` is uploaded */
+static TLWE_KS_Key tlwe_ks_wrap_dev(Torus *flat, int n_in, int n_out, int t, int base_bit, const char *who, mosfhet_hip_ksk_t have) {
   const int base = 1 << base_bit;
   const size_t row = (size_t)n_out + 1;
   TLWE_KS_Key res = (TLWE_KS_Key)mc_xmalloc(sizeof(*res));
@@ -1288,15 +1291,24 @@ static TLWE_KS_Key tlwe_ks_wrap(Torus *flat, int n_in, int n_out, int t, int bas
       }
     }
   }
-  mosfhet_hip_ksk_t dev = NULL;
-  if (mosfhet_hip_ksk_create((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, flat, n_in, n_out, t, base_bit)) mc_die(who);
+  mosfhet_hip_ksk_t dev = have;
+  if (!dev && mosfhet_hip_ksk_create((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, flat, n_in, n_out, t, base_bit)) mc_die(who);
   res->device = dev;
   return res;
 }
 
+/* tlwe_new_KS_key (src/tlwe.c:193-212).  The table is encrypted ON THE DEVICE (mosfhet_hip_tlwe_ksk_generate: exact a * s, Gaussian noise of the output key's sigma,
+ * masks from a seed drawn from the host generator; lvl2's 1.2 GB in milliseconds instead of seconds of host encryption) and read back once, because its samples
+ * key->s[i][j][v] are caller-visible in the reference's struct; the device copy that made them is the one the key switches use.  Parameters the device generator
+ * does not take are encrypted on the host and uploaded, as before. */
 TLWE_KS_Key tlwe_new_KS_key(TLWE_Key out_key, TLWE_Key in_key, int t, int base_bit) {
-  const size_t words = (size_t)in_key->n * t * ((1 << base_bit) - 1) * ((size_t)out_key->n + 1);
+  const size_t rows = (size_t)in_key->n * t * ((1 << base_bit) - 1), words = rows * ((size_t)out_key->n + 1);
   Torus *flat = (Torus *)mc_xmalloc(sizeof(Torus) * words);
+  mosfhet_hip_ksk_t dev = NULL;
+  if (mosfhet_hip_tlwe_ksk_generate((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, out_key->s, out_key->n, in_key->s, in_key->n, t, base_bit, out_key->sigma, mc_rnd64(), 0) == 0) {
+    if (mosfhet_hip_ksk_export_rows(dev, 0, rows, flat)) mc_die("tlwe_new_KS_key (read back)");
+    return tlwe_ks_wrap_dev(flat, in_key->n, out_key->n, t, base_bit, "tlwe_new_KS_key", dev);
+  }
   mosfhet_gen_tlwe_ks_key_flat(flat, out_key, in_key, t, base_bit);
   return tlwe_ks_wrap(flat, in_key->n, out_key->n, t, base_bit, "tlwe_new_KS_key");
 }
