@@ -10,6 +10,9 @@ using namespace mosfhet;
 #ifndef AB_BG
 #define AB_BG 8
 #endif
+#ifndef AB_CMUX
+#define AB_CMUX false   // true: the CMUX form (out = in0 + TRGSW (.) (in - in0)); ab_ep_in0 must then point at a batch of the same shape
+#endif
 #ifndef AB_FORM
 #define AB_FORM 0   // 1: plain unit loop, 2: software-pipelined unit loop on any ring (external_product_kernel: FORM)
 #endif
@@ -32,7 +35,7 @@ extern "C" int ab_ep(const double *d_row, const double *d_tw, const uint64_t *d_
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1;
   hipEventRecord(e0, nullptr);
   for (int r = 0; r < reps; r++)
-    hipLaunchKernelGGL((external_product_kernel<ABF, AB_L, AB_BG, false, AB_FORM>), dim3((unsigned)grid), dim3(ABF::THREADS), 0, nullptr, (const d2 *)d_row, (const d2 *)d_tw, d_in, d_out,
+    hipLaunchKernelGGL((external_product_kernel<ABF, AB_L, AB_BG, AB_CMUX, AB_FORM>), dim3((unsigned)grid), dim3(ABF::THREADS), 0, nullptr, (const d2 *)d_row, (const d2 *)d_tw, d_in, d_out,
                        AB_BG ? AB_BG : ab_ep_bg_rt, count, (size_t)0, (size_t)(2 * ABF::N), ab_ep_in0, (d2 *)ab_ep_out_dft);
   hipEventRecord(e1, nullptr);
   if (hipEventSynchronize(e1) != hipSuccess) return -2;

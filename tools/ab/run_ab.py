@@ -102,7 +102,10 @@ def run_ep(B, rounds, grids, pset="set1", names=None):
     bsk = eng.load_bootstrap_key(host_bk, 1, P["l"], P["Bg_bit"])
     g = torch.Generator(device="cpu").manual_seed(1)
     d_in = torch.randint(-2 ** 63, 2 ** 63 - 1, (B, 2, P["N"]), dtype=torch.int64, generator=g).to(eng.device)
-    want = eng.external_product(bsk, 1, d_in)
+    d_in0 = None
+    if os.environ.get("AB_CMUX"):   # the CMUX form: every variant gets the same in0 batch (its .so must be built with -DAB_CMUX=true)
+        d_in0 = torch.randint(-2 ** 63, 2 ** 63 - 1, (B, 2, P["N"]), dtype=torch.int64, generator=g).to(eng.device)
+    want = eng.external_product(bsk, 1, d_in) if d_in0 is None else eng.cmux(bsk, 1, d_in0, d_in)
     # the truth for a sample of units: the oracle (production is itself under test when a variant disagrees with it)
     from oracle import oracle as O
     O.build()
@@ -121,6 +124,8 @@ def run_ep(B, rounds, grids, pset="set1", names=None):
     libs = {os.path.basename(p)[3:-3]: C.CDLL(p) for p in sorted(glob.glob(os.path.join(OUT, "ep_*.so"))) if not names or os.path.basename(p)[3:-3] in names}
     for lib in libs.values():
         C.c_int.in_dll(lib, "ab_ep_bg_rt").value = P["Bg_bit"]
+        if d_in0 is not None:
+            C.c_void_p.in_dll(lib, "ab_ep_in0").value = d_in0.data_ptr()
     out = eng.empty(B, 2, P["N"])
     if os.environ.get("AB_OUT_DFT"):
         # DFT-domain results (trgsw_mul_trlwe_DFT before trlwe_from_DFT) of every variant against the FIRST one named: is a wrong unit already wrong in front of the
