@@ -4,6 +4,7 @@ fault of the kind the round-3 / round-5 experiments chase (tools/spill_hazard, 1
 at rates far below what a parity test of a few thousand units can see.
 
     python tools/soak.py [launches] [what,...]      what: ep_lvl2 ep_lvl2_cmux ep_set1 ep_set1_cmux ep_set1_global ep_set2 ep_set3 pbs_set1 pbs_lvl2
+                                                           pbs_set1_small pbs_lvl2_small (latency kernels: 256 / 128 per launch) pbs_set2 ks_lvl2 cb3_lvl2 ga_lvl2
 
 Prints one line per case: launches, units per launch, launches whose output differed, units that differed in total.
 """
@@ -63,9 +64,35 @@ def main():
                 else:
                     want = O.external_product(h_in[b], bkd[1], P["l"], P["Bg_bit"])
                 assert (h_first[b] == want).all(), (case, b)
+        elif kind in ("ks", "cb3", "ga"):
+            # compositions and the table key switch at lvl2: random inputs, repeatability only (their parity is tests/test_gpu_parity.py's business)
+            P, lk, rk, hb, bsk = key("lvl2", 40)
+            N, l, Bg = P["N"], P["l"], P["Bg_bit"]
+            s_, ex = rk.s[0], rk.extracted_lwe_key().s
+            rngk = np.random.default_rng(11)
+            if kind == "ks":
+                ksk = eng.generate_keyswitch_key(lk.s, ex, P["t"], P["base_bit"], P["lwe_sigma"], seed=5)
+                B = 4096
+                d_x = ma.to_device(rngk.integers(0, 2 ** 64, size=(B, N + 1), dtype=np.uint64), eng.device)
+                run = lambda out: eng.tlwe_keyswitch(ksk, d_x, out=out)
+            elif kind == "cb3":
+                kska = eng.load_trlwe_ks_keys(host.gen_priv_ks_key(rk, rk, 20, 2), 2)
+                pk = eng.generate_table_key(0, s_, s_, 6, 4, P["rlwe_sigma"], seed=9, compressed=True)
+                B = 128
+                d_x = ma.to_device(rngk.integers(0, 2 ** 64, size=(B, 41), dtype=np.uint64), eng.device)
+                run = lambda out: eng.circuit_bootstrap_3(bsk, kska, pk, d_x, out=out)
+            else:
+                bk_ga = eng.generate_bootstrap_key(s_, lk.s, l, Bg, P["rlwe_sigma"], seed=3, ga=True)
+                gak = eng.generate_trlwe_ks_keys(s_, host.automorphism_key_sources(s_), l, Bg, P["rlwe_sigma"], seed=4)
+                B = 1024
+                d_x = ma.to_device(rngk.integers(0, 2 ** 64, size=(B, 41), dtype=np.uint64), eng.device)
+                d_tv = ma.to_device(rngk.integers(0, 2 ** 64, size=(1, 2, N), dtype=np.uint64), eng.device)
+                run = lambda out: eng.functional_bootstrap_ga(bk_ga, gak, d_tv, d_x, 4, out=out)
+            first = run(None)
+            torch.cuda.synchronize()
         else:
             P, lk, rk, hb, bsk = key(pset, sets[pset]["n"])
-            B = 4096 if pset == "set1" else 1024
+            B = {"small": 256 if pset == "set1" else 128}.get(mode, 4096 if pset == "set1" else 1024)
             lut = np.array([1 << 60, 5 << 60, 9 << 60, 13 << 60], dtype=np.uint64)
             tv = ma.to_device(host.torus_packing(lut, 1, P["N"])[None], eng.device)
             cts = ma.to_device(host.tlwe_samples([host.double2torus((b % 4) / 8.0) for b in range(B)], lk), eng.device)
@@ -74,7 +101,7 @@ def main():
             torch.cuda.synchronize()
             ph = host.tlwe_phase(ma.to_numpy(first), rk.extracted_lwe_key().s)
             assert O.torus_dist(ph, lut[np.arange(B) % 4]).max() < 2.0 ** 58, case
-        n_case = launches if kind == "ep" else max(1, launches // 20)
+        n_case = launches if kind == "ep" else max(1, launches // (4 if kind == "ks" else 20))
         out = torch.empty_like(first)
         bad_launches = bad_units = 0
         for i in range(n_case):
