@@ -18,7 +18,7 @@ Prints ONE JSON line (rank 0) with the contract fields plus
                  key entry, 32 KiB of ciphertext I/O per unit) against HBM bandwidth, timed live the same way; a sample of its outputs is checked
                  by phase (BK_i = TRGSW(s_i): phase(BK_i (.) c) = s_i phase(c), within the reference's 2^54);
   roofline_external_product_lvl2 : the same at N = 2048, l = 4 (64 KiB per unit, 256 KiB key entry);
-  configs_3_4  : BASELINE.json configs[3] and [4] on this GPU (N = 1): 1024 x circuit_bootstrap_3, full-domain functional bootstrap, multi-value bootstrap
+  configs_3_4  : BASELINE.json configs[3] and [4] (N = 1: on this GPU; N > 1: each batch of 1024 SPLIT over the ranks, strong scaling, max over ranks): 1024 x circuit_bootstrap_3, full-domain functional bootstrap, multi-value bootstrap
                  (8 LUTs) and Galois-automorphism bootstrap at N = 2048, each checked by phase, each with the FP64 share of its blind rotations, the circuit
                  bootstrap's packing switches against their LDS-gather floor, and ONE GPU's share of the batch when it is split over 8 (128 inputs);
   lvl2_bootstraps : BASELINE.json configs[2] for the record (4096 programmable bootstraps at N = 2048, l = 4 on this GPU: rate, FP64-model fraction,
@@ -111,13 +111,17 @@ def lvl2_bootstrap_leg(eng, ma, host, torch, keys, B2=4096):
 LDS_GATHER_PEAK_GBS = 256 * 256 * 2.0   # table key switches: 256 B / clock / CU of ds_read_b128 x 256 CUs x 2.0 GHz sustained = 131 TB/s
 
 
-def composition_legs(eng, ma, host, torch, keys, batch=1024, share=8):
+def composition_legs(eng, ma, host, torch, keys, batch=1024, share=8, rank=0, world=1, dist_device=None):
     """BASELINE.json configs[3] and [4] on this GPU, `batch` inputs each and -- beside it -- ONE GPU's share when the configs' batches are split over `share` GPUs:
       circuit_bootstrap_3 (src/bootstrap.c:346-366: one bootstrap, l extractions, packing + private key switch per level; packing key t = 6, bb = 4, private key t = 20,
       bb = 2), full_domain_functional_bootstrap (:519-538, precision 3), multivalue_bootstrap_CLOT21 (:222-230, torus_base 2, 8 LUTs) and functional_bootstrap_ga
       (src/bootstrap_ga.c:62-76).  All keys but the private key-switch pair are generated on the device.  Every leg is checked by PHASE (no oracle on the measured path);
       each carries the share of the chip's FP64 vector peak its blind rotations reach (SURVEY 8(d) FLOP model over the composition's whole time -- the key switches,
-      extractions and copies count as time, not as work) and, for the circuit bootstrap, its packing switches alone against the LDS-gather floor that bounds them."""
+      extractions and copies count as time, not as work) and, for the circuit bootstrap, its packing switches alone against the LDS-gather floor that bounds them.
+    world > 1 (every rank calls this): the configs' own shape -- the batch of 1024 SPLIT over the GPUs (strong scaling): rank r bootstraps the contiguous slice
+      shard_bounds(batch, r, world) against its own replica of the keys (same seeds), no collective on the data path; a leg's time is the max over ranks of a
+      barrier-bracketed region (mosfhet_amd/shard.py), its rate batch / that time; every rank phase-checks its own slice and the worst error is reported."""
+    from mosfhet_amd import shard
     P2, lk2, rk2, bsk = keys
     N, l, Bg, n = P2["N"], P2["l"], P2["Bg_bit"], P2["n"]
     s, out_s = rk2.s[0], rk2.extracted_lwe_key().s
@@ -127,10 +131,27 @@ def composition_legs(eng, ma, host, torch, keys, batch=1024, share=8):
     def phase_err(got, want):
         return float(np.abs((got - want).astype(np.int64).astype(np.float64)).max())
 
+    lo, hi = shard.shard_bounds(batch, rank, world)
+    mine = hi - lo                       # this rank's inputs (all of them at world = 1)
+
     def entry(name, workload, ref, units, run, check, rotations, small_run, extra=None):
         run()
         torch.cuda.synchronize()
         err = check()
+        if world > 1:
+            import torch.distributed as dist
+            reps = 3
+            ms = 1e3 * shard.timed_region(run, reps, sync=torch.cuda.synchronize, device=dist_device) / reps
+            e = torch.tensor([float(np.log2(err + 1))], dtype=torch.float64, device=dist_device)
+            dist.all_reduce(e, op=dist.ReduceOp.MAX)
+            tflops = rotations * flops_rot * units / (ms * 1e-3) / 1e12
+            res[name] = {"workload": workload + " -- split over %d GPUs, %d - %d inputs each" % (world, batch // world, -(-batch // world)), "reference": ref, "units": units,
+                         "n_gpus": world, "scaling": "strong", "ms_per_batch": ms, "units_per_s": units / (ms * 1e-3), "max_phase_error_log2": float(e.item()),
+                         "decrypts": bool(e.item() < 60.0),
+                         "roofline": {"bound": "fp64_valu", "achieved": tflops, "peak": world * FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": tflops / (world * FP64_VECTOR_PEAK_TFLOPS), "blind_rotations_per_unit": rotations,
+                                      "note": "blind-rotation FLOP (SURVEY 8(d)) of the whole batch over the max-over-ranks time, against the %d GPUs' peak" % world}}
+            return
         ms = timed_ms(torch, run)
         small_run()
         torch.cuda.synchronize()
@@ -145,36 +166,37 @@ def composition_legs(eng, ma, host, torch, keys, batch=1024, share=8):
         if extra:
             res[name].update(extra)
 
-    small = batch // share
+    small = max(1, mine // share)
     # ---- configs[3]: circuit_bootstrap_3 ----
     kska = eng.load_trlwe_ks_keys(host.gen_priv_ks_key(rk2, rk2, 20, 2), 2)
     pk = eng.generate_table_key(0, s, s, 6, 4, P2["rlwe_sigma"], seed=99, compressed=True)   # 6 GB of rows, 3 GB in HBM: masks regenerated in the kernel
-    d_cb_in = ma.to_device(host.tlwe_samples([host.double2torus(0.25 * (b & 1)) for b in range(batch)], lk2), eng.device)
-    d_cb_out = eng.empty(batch, 2 * l, 2, N)
-    pick = np.unique(np.concatenate([[0, 1, batch // 2, batch - 1], np.random.default_rng(3).integers(0, batch, 12)]))
+    d_cb_in = ma.to_device(host.tlwe_samples([host.double2torus(0.25 * (b & 1)) for b in range(lo, hi)], lk2), eng.device)
+    d_cb_out = eng.empty(mine, 2 * l, 2, N)
+    pick = np.unique(np.concatenate([[0, 1, mine // 2, mine - 1], np.random.default_rng(3).integers(0, mine, 12)]))
 
     def chk_cb():   # row l + i of TRGSW(bit): phase = bit 2^(64 - (i+1) Bg) on X^0 (test/tests.c:999-1003); a sample of the outputs, every coefficient of their b rows
         rows = ma.to_numpy(d_cb_out[pick][:, l:]).reshape(-1, 2, N)
         ph = trlwe_phase(rows, s).reshape(len(pick), l, N)
         want = np.zeros_like(ph)
         for i in range(l):
-            want[:, i, 0] = (pick & 1).astype(np.uint64) << np.uint64(64 - (i + 1) * Bg)
+            want[:, i, 0] = ((pick + lo) & 1).astype(np.uint64) << np.uint64(64 - (i + 1) * Bg)
         return phase_err(ph, want)
     # the packing switches of one batch alone (l switches of `batch` extracted samples), against the LDS-gather floor
-    d_ext = ma.to_device(np.random.default_rng(4).integers(0, 2 ** 64, size=(batch, N + 1), dtype=np.uint64), eng.device)
-    d_pk_out = eng.empty(batch, 2, N)
+    d_ext = ma.to_device(np.random.default_rng(4).integers(0, 2 ** 64, size=(mine, N + 1), dtype=np.uint64), eng.device)
+    d_pk_out = eng.empty(mine, 2, N)
     eng.trlwe_packing1_keyswitch(pk, d_ext, out=d_pk_out)
     pk_ms = timed_ms(torch, lambda: eng.trlwe_packing1_keyswitch(pk, d_ext, out=d_pk_out))
-    pk_bytes = batch * N * 6 * (2 * N) * 8
+    pk_bytes = mine * N * 6 * (2 * N) * 8
     entry("circuit_bootstrap_3", "%d x circuit_bootstrap_3 at N=2048 l=4 n=632, packing key t=6 bb=4 (6 GB of rows, seed-compressed to 3 GB), private key t=20 bb=2 "
           "(BASELINE.json configs[3])" % batch, "/root/reference/src/bootstrap.c:346-366", batch,
           lambda: eng.circuit_bootstrap_3(bsk, kska, pk, d_cb_in, out=d_cb_out), chk_cb, 1,
           lambda: eng.circuit_bootstrap_3(bsk, kska, pk, d_cb_in[:small], out=d_cb_out[:small]),
-          {"packing_switch": {"bound": "lds_gather", "kernel": "mosfhet::tlwe_keyswitch_kernel (TRLWE rows)", "kernel_ms": pk_ms, "switches_per_launch": batch,
+          {"packing_switch": {"bound": "lds_gather", "kernel": "mosfhet::tlwe_keyswitch_kernel (TRLWE rows)", "kernel_ms": pk_ms, "switches_per_launch": mine,
                               "launches_per_batch": l, "algorithmic_lds_bytes_per_launch": pk_bytes, "achieved": pk_bytes / (pk_ms * 1e-3) / 1e9,
                               "peak": LDS_GATHER_PEAK_GBS, "unit": "GB/s", "frac": pk_bytes / (pk_ms * 1e-3) / 1e9 / LDS_GATHER_PEAK_GBS,
                               "share_of_batch_time": None}})
-    res["circuit_bootstrap_3"]["packing_switch"]["share_of_batch_time"] = l * pk_ms / res["circuit_bootstrap_3"]["ms_per_batch"]
+    if world == 1:
+        res["circuit_bootstrap_3"]["packing_switch"]["share_of_batch_time"] = l * pk_ms / res["circuit_bootstrap_3"]["ms_per_batch"]
     pk.free()
     kska.free()
     del d_cb_out, d_pk_out
@@ -183,21 +205,21 @@ def composition_legs(eng, ma, host, torch, keys, batch=1024, share=8):
     ksk = eng.generate_keyswitch_key(lk2.s, out_s, P2["t"], P2["base_bit"], P2["lwe_sigma"], seed=7, compressed=True)
     lut8 = np.array([host.double2torus(((3 * i + 1) % 8) / 8.0) for i in range(8)], dtype=np.uint64)
     d_tv8 = ma.to_device(host.torus_packing_many_lut(lut8, 1, N, 4, 2)[None], eng.device)
-    d_in5 = ma.to_device(host.tlwe_samples([(b % 8) << 61 for b in range(batch)], lk2), eng.device)
-    d_o5 = eng.empty(batch, N + 1)
+    d_in5 = ma.to_device(host.tlwe_samples([(b % 8) << 61 for b in range(lo, hi)], lk2), eng.device)
+    d_o5 = eng.empty(mine, N + 1)
     entry("full_domain_functional_bootstrap", "%d x full_domain_functional_bootstrap, precision 3, N=2048 l=4 n=632, key switch t=%d bb=%d (BASELINE.json configs[4])" % (batch, P2["t"], P2["base_bit"]),
           "/root/reference/src/bootstrap.c:519-538", batch, lambda: eng.full_domain_functional_bootstrap(bsk, ksk, d_tv8, d_in5, 3, out=d_o5),
-          lambda: phase_err(host.tlwe_phase(ma.to_numpy(d_o5), out_s), lut8[np.arange(batch) % 8]), 2,
+          lambda: phase_err(host.tlwe_phase(ma.to_numpy(d_o5), out_s), lut8[np.arange(lo, hi) % 8]), 2,
           lambda: eng.full_domain_functional_bootstrap(bsk, ksk, d_tv8, d_in5[:small], 3, out=d_o5[:small]))
     ksk.free()
     lut16 = np.array([host.double2torus(((5 * i + 3) % 16) / 16.0) for i in range(16)], dtype=np.uint64)
     d_tvm = ma.to_device(host.torus_packing(lut16, 1, N)[None], eng.device)
-    d_inm = ma.to_device(host.tlwe_samples([host.double2torus((b % 2) / 4.0) for b in range(batch)], lk2), eng.device)
-    d_om = eng.empty(batch, 8, N + 1)
+    d_inm = ma.to_device(host.tlwe_samples([host.double2torus((b % 2) / 4.0) for b in range(lo, hi)], lk2), eng.device)
+    d_om = eng.empty(mine, 8, N + 1)
 
     def chk_mv():   # selector m / 4 (m = b % 2), torus_base 2, 8 LUTs: output i is slot 8 m + i of the packed vector (test/tests.c:931-963)
-        ph = host.tlwe_phase(ma.to_numpy(d_om).reshape(-1, N + 1), out_s).reshape(batch, 8)
-        want = lut16[(8 * (np.arange(batch) % 2))[:, None] + np.arange(8)[None, :]]
+        ph = host.tlwe_phase(ma.to_numpy(d_om).reshape(-1, N + 1), out_s).reshape(mine, 8)
+        want = lut16[(8 * (np.arange(lo, hi) % 2))[:, None] + np.arange(8)[None, :]]
         return phase_err(ph, want)
     entry("multivalue_bootstrap_CLOT21", "%d x multivalue_bootstrap_CLOT21, torus_base 2, 8 LUTs per blind rotation, N=2048 l=4 n=632 (BASELINE.json configs[4])" % batch,
           "/root/reference/src/bootstrap.c:222-230", batch, lambda: eng.multivalue_bootstrap_CLOT21(bsk, d_tvm, d_inm, 2, 8, out=d_om), chk_mv, 1,
@@ -208,12 +230,12 @@ def composition_legs(eng, ma, host, torch, keys, batch=1024, share=8):
     gak = eng.generate_trlwe_ks_keys(s, host.automorphism_key_sources(s), l, Bg, P2["rlwe_sigma"], seed=SEED + 10)
     lut4 = np.array([1 << 60, 5 << 60, 9 << 60, 13 << 60], dtype=np.uint64)
     d_tv4 = ma.to_device(host.torus_packing(lut4, 1, N)[None], eng.device)
-    d_inga = ma.to_device(host.tlwe_samples([host.double2torus((b % 4) / 8.0) for b in range(batch)], lk2), eng.device)
-    d_oga = eng.empty(batch, N + 1)
+    d_inga = ma.to_device(host.tlwe_samples([host.double2torus((b % 4) / 8.0) for b in range(lo, hi)], lk2), eng.device)
+    d_oga = eng.empty(mine, N + 1)
     entry("functional_bootstrap_ga", "%d x functional_bootstrap_ga (Galois-automorphism blind rotation), N=2048 l=4 n=632, 2048 automorphism keys (256 MiB) "
           "(BASELINE.json configs[4])" % batch, "/root/reference/src/bootstrap_ga.c:62-76", batch,
           lambda: eng.functional_bootstrap_ga(bk_ga, gak, d_tv4, d_inga, 4, out=d_oga),
-          lambda: phase_err(host.tlwe_phase(ma.to_numpy(d_oga), out_s), lut4[np.arange(batch) % 4]), 1,
+          lambda: phase_err(host.tlwe_phase(ma.to_numpy(d_oga), out_s), lut4[np.arange(lo, hi) % 4]), 1,
           lambda: eng.functional_bootstrap_ga(bk_ga, gak, d_tv4, d_inga[:small], 4, out=d_oga[:small]),
           {"note": "FLOP model of the plain blind rotation; the Galois form runs 1.6 x its transforms (an automorphism key switch per step)"})
     bk_ga.free()
@@ -361,7 +383,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lvl2", action="store_true", help="skip the configs[2] leg (4096 lvl2 bootstraps, ~2 s) and with it configs[3] / [4]")
-    ap.add_argument("--no-configs34", action="store_true", help="skip the configs[3] / [4] legs (circuit bootstrap, FDFB, multi-value, Galois bootstrap: ~10 s, N = 1 only)")
+    ap.add_argument("--no-configs34", action="store_true", help="skip the configs[3] / [4] legs (circuit bootstrap, FDFB, multi-value, Galois bootstrap: ~10 s; N > 1: the batches split over the ranks)")
     args = ap.parse_args()
 
     import torch
@@ -543,11 +565,13 @@ def main():
                                    "mosfhet::external_product_kernel<mosfhet::Fft2048T<false, true>, 4, 9, false, 0>", torch)
 
     lvl2 = configs34 = None
-    if rank == 0 and not args.no_lvl2:
-        keys2 = lvl2_keys(eng, ma, host)
-        lvl2 = lvl2_bootstrap_leg(eng, ma, host, torch, keys2)
-        if world == 1 and not args.no_configs34:
-            configs34 = composition_legs(eng, ma, host, torch, keys2)
+    if not args.no_lvl2 and (rank == 0 or (world > 1 and not args.no_configs34)):
+        keys2 = lvl2_keys(eng, ma, host)      # same seeds on every rank: replicas of one key set
+        if rank == 0:
+            lvl2 = lvl2_bootstrap_leg(eng, ma, host, torch, keys2)
+        if not args.no_configs34:
+            # N = 1: the whole batches on this GPU (+ one GPU's share of 8); N > 1: the batches split over the ranks, every rank takes part (barrier + max over ranks)
+            configs34 = composition_legs(eng, ma, host, torch, keys2, rank=rank, world=world, dist_device=(eng.device if backend == "nccl" else "cpu"))
         keys2[3].free()
 
     # one bootstrap alone (the latency kernel: one workgroup of 2l wavefronts for the ciphertext), same key, same timing method as roofline.kernel_ms
