@@ -350,13 +350,17 @@ int mosfhet_hip_ep_kernel_info(int i, const char **name, int *scratch_bytes, int
  * n -> N, LWE key switch N -> n, LUT-packing key of torus_base slots N -> TRLWE(N); pksk may be NULL for add / sub only) and is read-only after creation.
  *   addsub: c = a + b (subtract = 0) or a - b (1) over all d digits, the carry out of the top digit dropped (equal-width operands); c must not alias a, b
  *   relu: out = in > 0 ? in : 0 for signed integers; out may alias in
- *   encrypted_lut: table[0][m] = table[selector_m][m]; d_table [size][M][N+1] is consumed, d_sel [log_B size][M][N+1] = selector digits, least significant first */
+ *   encrypted_lut: table[0][m] = table[selector_m][m]; d_table [size][M][N+1] is consumed, d_sel [log_B size][M][N+1] = selector digits, least significant first
+ *   cmp: c[m] = 0 / 1 / 2 for a[m] < / = / > b[m] (ufhe_cmp_integer, src/integer.c:205-264); d_c [M][N+1] is the one result digit
+ *   lut_cleartext: out[m] = h_lut[selector_m] for a CLEARTEXT table (ufhe_lut_integer, src/lut.c:23-47): one multi-value rotation per selector, then the tree */
 typedef struct mosfhet_hip_vec *mosfhet_hip_vec_t;
 int mosfhet_hip_vec_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_vec_t *out, mosfhet_hip_bsk_t bsk, mosfhet_hip_ksk_t ksk, mosfhet_hip_ksk_t pksk, int torus_base);
 int mosfhet_hip_vec_destroy(mosfhet_hip_vec_t vec);
 int mosfhet_hip_vec_addsub(mosfhet_hip_vec_t vec, uint64_t *d_c, const uint64_t *d_a, const uint64_t *d_b, int M, int d, int subtract, void *stream);
 int mosfhet_hip_vec_relu(mosfhet_hip_vec_t vec, uint64_t *d_out, const uint64_t *d_in, int M, int d, void *stream);
 int mosfhet_hip_vec_encrypted_lut(mosfhet_hip_vec_t vec, uint64_t *d_table, const uint64_t *d_sel, int size, int M, void *stream);
+int mosfhet_hip_vec_cmp(mosfhet_hip_vec_t vec, uint64_t *d_c, const uint64_t *d_a, const uint64_t *d_b, int M, int d, int a_signed, int b_signed, void *stream);
+int mosfhet_hip_vec_lut_cleartext(mosfhet_hip_vec_t vec, uint64_t *d_out, const uint64_t *d_sel, const uint64_t *h_lut, int size, int d_out_digits, int M, void *stream);
 
 /* The canonical caller pattern in one call (applications/multi-ciphertext-arith/src/integer.c:94-95): tlwe_keyswitch kN -> n, then
  * functional_bootstrap (extract = 1: d_out [count][kN+1]) or functional_bootstrap_wo_extract (extract = 0: d_out [count][k+1][N]);

@@ -747,6 +747,21 @@ class VectorOps:
         _check(lib().mosfhet_hip_vec_encrypted_lut(self.h, _ptr(table), _ptr(sel), size, M, self.eng._stream()))
         return table[0]
 
+    def cmp(self, a, b, a_signed=True, b_signed=True):
+        """[M][N+1]: digit 0 / 1 / 2 (over 2 B) for a < / = / > b"""
+        d, M, row = a.shape
+        out = self.eng.empty(M, row)
+        _check(lib().mosfhet_hip_vec_cmp(self.h, _ptr(out), _ptr(a), _ptr(b), M, d, int(bool(a_signed)), int(bool(b_signed)), self.eng._stream()))
+        return out
+
+    def lut_cleartext(self, sel, lut, out_digits):
+        """out[m] = lut[selector_m] for a cleartext table (numpy uint64 [size]); sel [levels][M][N+1] -> [out_digits][M][N+1]"""
+        levels, M, row = sel.shape
+        lut = np.ascontiguousarray(lut, dtype=np.uint64)
+        out = self.eng.empty(out_digits, M, row)
+        _check(lib().mosfhet_hip_vec_lut_cleartext(self.h, _ptr(out), _ptr(sel), lut.ctypes.data_as(C.c_void_p), int(lut.size), int(out_digits), M, self.eng._stream()))
+        return out
+
     def free(self):
         if self.h:
             lib().mosfhet_hip_vec_destroy(self.h)

@@ -35,7 +35,19 @@ int main(int argc, char **argv) {
     }
     ufhe_mux_integer_array(c, sel, _ctx, 16, vec);
     const int r_lut = (int)(int8_t)ufhe_decrypt_integer(c, _priv_key, _ctx);
-    printf("], \"add\": %d, \"sub\": %d, \"relu\": %d, \"lut\": %d}%s\n", r_add, r_sub, r_relu, r_lut, i == count - 1 ? "" : ",");
+    /* comparison, signed and unsigned reading of the same bytes (test_int_cmp), and the cleartext-table look-up of test_lut_ct with the row's table as cleartext */
+    ufhe_cmp_integer(c, a, b, _ctx);
+    const int r_cmp_s = (int)ufhe_decrypt_integer(c, _priv_key, _ctx);
+    a->_signed = b->_signed = c->_signed = false;
+    ufhe_cmp_integer(c, a, b, _ctx);
+    const int r_cmp_u = (int)ufhe_decrypt_integer(c, _priv_key, _ctx);
+    a->_signed = b->_signed = c->_signed = true;
+    uint64_t ct_lut[16];
+    for (int j = 0; j < 16; j++) ct_lut[j] = (uint64_t)((13 * i + 7 * j * j + 3) & 0xff);
+    ufhe_lut_integer(c, sel, ct_lut, 16, _ctx);
+    const int r_lut_ct = (int)(int8_t)ufhe_decrypt_integer(c, _priv_key, _ctx);
+    printf("], \"add\": %d, \"sub\": %d, \"relu\": %d, \"lut\": %d, \"cmp_signed\": %d, \"cmp_unsigned\": %d, \"lut_cleartext\": %d}%s\n", r_add, r_sub, r_relu, r_lut, r_cmp_s,
+           r_cmp_u, r_lut_ct, i == count - 1 ? "" : ",");
     fflush(stdout);
   }
   printf("]}\n");
