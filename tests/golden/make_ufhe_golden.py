@@ -1,5 +1,5 @@
 """Makes tests/golden/ufhe_vectors.npz: what the REFERENCE's radix-integer application (applications/multi-ciphertext-arith) decrypts, on the reference's own
-AVX-512 library, for a fixed list of signed 8-bit inputs -- add, sub, ReLU, encrypted 16-entry LUT, comparison (signed and unsigned), cleartext 16-entry LUT.  Needs /root/reference (build container only); compiles
+AVX-512 library, for a fixed list of signed 8-bit inputs -- add, sub, ReLU, encrypted 16-entry LUT, comparison (signed and unsigned), cleartext 16-entry LUT, multiplication (signed into 32 bits, unsigned full product).  Needs /root/reference (build container only); compiles
 tests/golden/ufhe_vectors_ref.c (own driver) with the reference's sources where they lie (oracle/ref/Makefile: ufhe_vectors_ref), runs it (minutes: the LUT-packing
 key alone is 4.8 GB of CPU-encrypted rows) and stores inputs and decrypted outputs.  tests/test_gpu_parity.py::test_vector_integer_callers holds the
 digit-parallel GPU forms to these numbers."""
@@ -25,7 +25,8 @@ def main():
                         add=np.array([r["add"] for r in rows], dtype=np.int64), sub=np.array([r["sub"] for r in rows], dtype=np.int64),
                         relu=np.array([r["relu"] for r in rows], dtype=np.int64), lut=np.array([r["lut"] for r in rows], dtype=np.int64),
                         cmp_signed=np.array([r["cmp_signed"] for r in rows], dtype=np.int64), cmp_unsigned=np.array([r["cmp_unsigned"] for r in rows], dtype=np.int64),
-                        lut_cleartext=np.array([r["lut_cleartext"] for r in rows], dtype=np.int64))
+                        lut_cleartext=np.array([r["lut_cleartext"] for r in rows], dtype=np.int64),
+                        mul_signed=np.array([r["mul_signed"] for r in rows], dtype=np.int64), mul_unsigned=np.array([r["mul_unsigned"] for r in rows], dtype=np.int64))
     print("wrote tests/golden/ufhe_vectors.npz: %d rows" % len(rows))
 
 

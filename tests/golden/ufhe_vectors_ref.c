@@ -1,6 +1,6 @@
 /* Generator of tests/golden/ufhe_vectors.npz (run by tests/golden/make_ufhe_golden.py in the build container, where /root/reference exists): drives the
  * REFERENCE's radix-integer application (applications/multi-ciphertext-arith, compiled unchanged from where it lies) on the REFERENCE's own library for a fixed
- * list of inputs and prints what it decrypts -- add, sub, ReLU and the encrypted 16-entry LUT of signed 8-bit integers.  Own code; the printed numbers are the
+ * list of inputs and prints what it decrypts -- add, sub, ReLU, the encrypted 16-entry LUT, comparison, cleartext LUT and multiplication of signed 8-bit integers.  Own code; the printed numbers are the
  * fixture the digit-parallel forms of this repository (mosfhet_hip_vec_*) are held to on the GPU. */
 #include "ufhe.h"
 
@@ -12,6 +12,7 @@ int main(int argc, char **argv) {
   _priv_key = ufhe_new_priv_keyset(SET0);
   _ctx = ufhe_setup_context(ufhe_new_public_keyset(_priv_key, SET0));
   ufhe_integer a = ufhe_new_integer(8, true, _ctx), b = ufhe_new_integer(8, true, _ctx), c = ufhe_new_integer(8, true, _ctx), sel = ufhe_new_integer(4, true, _ctx);
+  ufhe_integer wide = ufhe_new_integer(32, true, _ctx);
   ufhe_integer vec[16];
   for (int j = 0; j < 16; j++) vec[j] = ufhe_new_integer(8, true, _ctx);
   printf("{\"torus_base\": %d, \"rows\": [\n", _ctx->torus_base);
@@ -46,8 +47,16 @@ int main(int argc, char **argv) {
     for (int j = 0; j < 16; j++) ct_lut[j] = (uint64_t)((13 * i + 7 * j * j + 3) & 0xff);
     ufhe_lut_integer(c, sel, ct_lut, 16, _ctx);
     const int r_lut_ct = (int)(int8_t)ufhe_decrypt_integer(c, _priv_key, _ctx);
-    printf("], \"add\": %d, \"sub\": %d, \"relu\": %d, \"lut\": %d, \"cmp_signed\": %d, \"cmp_unsigned\": %d, \"lut_cleartext\": %d}%s\n", r_add, r_sub, r_relu, r_lut, r_cmp_s,
-           r_cmp_u, r_lut_ct, i == count - 1 ? "" : ",");
+    /* multiplication as test_int_mul has it: signed 8-bit operands into a 32-bit result (the low byte of the product, sign-extended), then the same bytes read unsigned
+     * (the full product) */
+    ufhe_mul_integer(wide, a, b, _ctx);
+    const long long r_mul_s = (long long)(int32_t)ufhe_decrypt_integer(wide, _priv_key, _ctx);
+    a->_signed = b->_signed = wide->_signed = false;
+    ufhe_mul_integer(wide, a, b, _ctx);
+    const long long r_mul_u = (long long)(uint32_t)ufhe_decrypt_integer(wide, _priv_key, _ctx);
+    a->_signed = b->_signed = wide->_signed = true;
+    printf("], \"add\": %d, \"sub\": %d, \"relu\": %d, \"lut\": %d, \"cmp_signed\": %d, \"cmp_unsigned\": %d, \"lut_cleartext\": %d, \"mul_signed\": %lld, \"mul_unsigned\": %lld}%s\n",
+           r_add, r_sub, r_relu, r_lut, r_cmp_s, r_cmp_u, r_lut_ct, r_mul_s, r_mul_u, i == count - 1 ? "" : ",");
     fflush(stdout);
   }
   printf("]}\n");
