@@ -360,6 +360,9 @@ int mosfhet_hip_vec_addsub(mosfhet_hip_vec_t vec, uint64_t *d_c, const uint64_t 
 int mosfhet_hip_vec_relu(mosfhet_hip_vec_t vec, uint64_t *d_out, const uint64_t *d_in, int M, int d, void *stream);
 int mosfhet_hip_vec_encrypted_lut(mosfhet_hip_vec_t vec, uint64_t *d_table, const uint64_t *d_sel, int size, int M, void *stream);
 int mosfhet_hip_vec_cmp(mosfhet_hip_vec_t vec, uint64_t *d_c, const uint64_t *d_a, const uint64_t *d_b, int M, int d, int a_signed, int b_signed, void *stream);
+/*   mul: c = a * b (ufhe_mul_integer, src/integer.c:166-203): schoolbook over a's digits -- per digit one multi-value rotation, two packed product tables per integer,
+ *        two bootstrap launches over all digits of b, a shifted addition and a shifted accumulation; a [da][M][N+1], b [db][M][N+1], c [dc][M][N+1], no aliasing */
+int mosfhet_hip_vec_mul(mosfhet_hip_vec_t vec, uint64_t *d_c, int dc, const uint64_t *d_a, int da, const uint64_t *d_b, int db, int is_signed, int M, void *stream);
 int mosfhet_hip_vec_lut_cleartext(mosfhet_hip_vec_t vec, uint64_t *d_out, const uint64_t *d_sel, const uint64_t *h_lut, int size, int d_out_digits, int M, void *stream);
 
 /* The canonical caller pattern in one call (applications/multi-ciphertext-arith/src/integer.c:94-95): tlwe_keyswitch kN -> n, then

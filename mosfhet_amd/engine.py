@@ -754,6 +754,12 @@ class VectorOps:
         _check(lib().mosfhet_hip_vec_cmp(self.h, _ptr(out), _ptr(a), _ptr(b), M, d, int(bool(a_signed)), int(bool(b_signed)), self.eng._stream()))
         return out
 
+    def mul(self, a, b, out_digits, signed=True):
+        da, M, row = a.shape
+        out = self.eng.empty(out_digits, M, row)
+        _check(lib().mosfhet_hip_vec_mul(self.h, _ptr(out), int(out_digits), _ptr(a), da, _ptr(b), b.shape[0], int(bool(signed)), M, self.eng._stream()))
+        return out
+
     def lut_cleartext(self, sel, lut, out_digits):
         """out[m] = lut[selector_m] for a cleartext table (numpy uint64 [size]); sel [levels][M][N+1] -> [out_digits][M][N+1]"""
         levels, M, row = sel.shape
