@@ -342,6 +342,9 @@ int mosfhet_hip_set_wide_team_max_batch(int max_batch);
  * its name, the scratch bytes per lane of its pipelined build and whether the launcher takes that build; MOSFHET_HIP_EINVAL past the end. */
 int mosfhet_hip_set_ep_plain_loop(int on);
 int mosfhet_hip_ep_kernel_info(int i, const char **name, int *scratch_bytes, int *takes_pipelined);
+/* N >= 2048 bootstraps re-align their teams per XCD every few CMUX steps (a bounded wait: timing only).  A launch whose wait ran out (the chip was shared
+ * with another launch) makes the next MOSFHET_HIP_PACE_SKIP (16) paced launches of the device skip the rendezvous; this returns how many are still to skip. */
+int mosfhet_hip_pace_skip_credit(mosfhet_hip_ctx_t ctx, int *credit);
 
 /* Digit-parallel forms of the radix-integer callers of applications/multi-ciphertext-arith for M INDEPENDENT integers: the gate sequences of
  * ufhe_sl_add_integer / ufhe_sub_integer (src/integer.c:79-107,136-156), ufhe_relu_integer (src/ml.c:4-20) and ufhe_encrypted_tlwe_lut (src/lut.c:6-20), one
@@ -362,6 +365,9 @@ int mosfhet_hip_vec_encrypted_lut(mosfhet_hip_vec_t vec, uint64_t *d_table, cons
 int mosfhet_hip_vec_cmp(mosfhet_hip_vec_t vec, uint64_t *d_c, const uint64_t *d_a, const uint64_t *d_b, int M, int d, int a_signed, int b_signed, void *stream);
 /*   mul: c = a * b (ufhe_mul_integer, src/integer.c:166-203): schoolbook over a's digits -- per digit one multi-value rotation, two packed product tables per integer,
  *        two bootstrap launches over all digits of b, a shifted addition and a shifted accumulation; a [da][M][N+1], b [db][M][N+1], c [dc][M][N+1], no aliasing */
+int mosfhet_hip_vec_sl_add(mosfhet_hip_vec_t vec, uint64_t *d_c, int dc, const uint64_t *d_a, int da, int g, const uint64_t *d_b, int db, int h, int is_signed, int M,
+                           void *stream);   /* c = a B^g + b B^h (ufhe_sl_add_integer, src/integer.c:79-107) */
+int mosfhet_hip_vec_extend(mosfhet_hip_vec_t vec, uint64_t *d_c, int dc, int d_ini, int is_signed, int M, void *stream);   /* digits [d_ini, dc) <- zero or sign (ufhe_extend_integer, :62-77) */
 int mosfhet_hip_vec_mul(mosfhet_hip_vec_t vec, uint64_t *d_c, int dc, const uint64_t *d_a, int da, const uint64_t *d_b, int db, int is_signed, int M, void *stream);
 int mosfhet_hip_vec_lut_cleartext(mosfhet_hip_vec_t vec, uint64_t *d_out, const uint64_t *d_sel, const uint64_t *h_lut, int size, int d_out_digits, int M, void *stream);
 

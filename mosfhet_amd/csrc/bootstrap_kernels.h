@@ -57,8 +57,25 @@ struct PbsParams {
 // 128-byte line per XCD, so that the eight counters do not queue behind each other at the memory side) and waits until all the teams dealt to that XCD
 // have arrived at rendezvous number `round` -- but never longer than `limit` timer ticks: a launch whose teams are NOT all resident (another stream's
 // kernel holds some CUs), or one that is not dealt round-robin over the XCDs (`mine` assumes blocks b and b + 8 share one), must not hang on it.  The
-// first team that times out raises the give-up flag and nobody waits again in this launch.  Memory order: relaxed device-scope atomics, nothing is
-// communicated but time.  Layout of `pace`: 8 counters at 32-word spacing, then the flag at word 256.
+// first team that times out raises the give-up flag and nobody waits again in this launch -- and leaves a credit in `pace_skip_credit` (one word per
+// device): the launcher's pace_prepare_kernel starts that many following paced launches with the flag already raised, so a caller that keeps the chip shared
+// (several streams or processes with full-chip launches) pays the bounded wait once in PACE_SKIP + 1 launches instead of in every one.  Memory order:
+// relaxed device-scope atomics, nothing is communicated but time.  Layout of `pace`: 8 counters at 32-word spacing, then the flag at word 256.
+__device__ unsigned int pace_skip_credit = 0;
+__device__ unsigned int pace_skip_after_giveup = 16;   // (set by the launcher from MOSFHET_HIP_PACE_SKIP when the ring is made)
+
+// In front of every paced launch, on its stream: counters to zero; the flag raised while a credit is left.
+__global__ void pace_prepare_kernel(unsigned int *slot) {
+  const unsigned int t = threadIdx.x;
+  if (t < 256) slot[t] = 0u;
+  if (t == 256) {
+    const unsigned int credit = __hip_atomic_load(&pace_skip_credit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (credit > 0u) __hip_atomic_store(&pace_skip_credit, credit - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (racing launchers may count one credit twice: timing only)
+    slot[256] = credit > 0u ? 1u : 0u;
+  }
+  if (t > 256) slot[t] = 0u;
+}
+
 __device__ __forceinline__ void pace_teams(unsigned int *pace, unsigned int round, int t, int limit) {
   workgroup_sync();
   if (t == 0 && __hip_atomic_load(pace + 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
@@ -72,6 +89,7 @@ __device__ __forceinline__ void pace_teams(unsigned int *pace, unsigned int roun
     while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
       if (wall_clock64() - t0 > limit) {
         __hip_atomic_store(pace + 256, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&pace_skip_credit, pace_skip_after_giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
       __builtin_amdgcn_s_sleep(32);

@@ -75,7 +75,7 @@ struct DevBuf {
 // handle: handles are read-only after creation, so any number of host threads may share them, as the reference's callers share its keys
 // (re-entrant through thread-local scratch, src/polynomial.c:269-352).  A thread's launches are ordered by the stream it passes; buffers are
 // released at thread exit (hipFree waits for work in flight).
-enum { POOL_BSK = 0, POOL_EXT0 = 1, POOL_EXT1 = 2, POOL_CTX0 = 3, POOL_UNFOLD = 6, POOL_PACK = 7, POOL_VEC = 8, POOL_SLOTS = 9 };
+enum { POOL_BSK = 0, POOL_EXT0 = 1, POOL_EXT1 = 2, POOL_CTX0 = 3, POOL_UNFOLD = 6, POOL_PACK = 7, POOL_VEC = 8, POOL_VEC2 = 9, POOL_SLOTS = 10 };
 struct ThreadPool {
   struct Dev {
     int device = -1;
@@ -566,7 +566,7 @@ static int pace_limit() {
 }
 constexpr int PACE_WORDS = 288;   // 8 per-XCD counters on 128-byte lines of their own + the give-up flag (word 256)
 // a ring of 256 counter blocks per device (allocated when the first context on the device is made -- not lazily at a launch, which could sit inside a stream
-// capture -- and kept for the life of the process), handed out round-robin to all host threads and zeroed on the launch stream in front of the launch that uses it.
+// capture -- and kept for the life of the process), handed out round-robin to all host threads and prepared (pace_prepare_kernel) on the launch stream in front of the launch that uses it.
 // A block comes round again 256 paced launches later; should the earlier launch still be running then, the two share a block and the rendezvous misfires -- a
 // timing matter only (results never depend on it), ended by the bounded wait.
 constexpr int PACE_MAX_DEV = 64, PACE_SLOTS = 256;
@@ -581,6 +581,10 @@ static unsigned int *pace_ring(int dev, bool may_allocate) {
   mem = g_pace_ring[dev].load(std::memory_order_relaxed);
   if (!mem) {
     if (hipMalloc((void **)&mem, (size_t)PACE_SLOTS * PACE_WORDS * 4) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    // launches that skip the rendezvous after one gave up (pace_teams): MOSFHET_HIP_PACE_SKIP, default 16; 0 = every launch tries (rounds 4's behaviour)
+    const char *e = getenv("MOSFHET_HIP_PACE_SKIP");
+    const unsigned int skip = e && atoi(e) >= 0 ? (unsigned int)atoi(e) : 16u;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(pace_skip_after_giveup), &skip, sizeof(skip)) != hipSuccess) (void)hipGetLastError();
     g_pace_ring[dev].store(mem, std::memory_order_release);
   }
   return mem;
@@ -591,8 +595,20 @@ static unsigned int *pace_slot(hipStream_t s) {
   unsigned int *mem = pace_ring(dev, false);   // no ring (allocation failed at context creation): the launch runs unpaced
   if (!mem) return nullptr;
   unsigned int *slot = mem + (size_t)PACE_WORDS * (g_pace_next[dev].fetch_add(1u, std::memory_order_relaxed) % PACE_SLOTS);
-  if (hipMemsetAsync(slot, 0, PACE_WORDS * 4, s) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  hipLaunchKernelGGL(pace_prepare_kernel, dim3(1), dim3(PACE_WORDS), 0, s, slot);
+  if (hipGetLastError() != hipSuccess) return nullptr;
   return slot;
+}
+
+// Launches of `ctx`'s device that will still skip the rendezvous because an earlier one gave up (pace_teams); synchronises the device.  For tests and tools.
+extern "C" int mosfhet_hip_pace_skip_credit(mosfhet_hip_ctx_t ctx, int *credit) {
+  if (!ctx || !credit) return fail(MOSFHET_HIP_EINVAL, "pace_skip_credit: null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipDeviceSynchronize());
+  unsigned int v = 0;
+  HIP_TRY(hipMemcpyFromSymbol(&v, HIP_SYMBOL(pace_skip_credit), sizeof(v)));
+  *credit = (int)v;
+  return MOSFHET_HIP_OK;
 }
 
 template <class F, int L, int BG>

@@ -141,6 +141,12 @@ class Engine:
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
 
+    def pace_skip_credit(self):
+        """paced launches of this device that will still skip the team rendezvous because an earlier launch's wait ran out (synchronises the device)"""
+        v = C.c_int()
+        _check(lib().mosfhet_hip_pace_skip_credit(self.h, C.byref(v)))
+        return v.value
+
     def empty(self, *shape):
         return self.torch.empty(*shape, dtype=self.torch.int64, device=self.device)
 
@@ -753,6 +759,17 @@ class VectorOps:
         out = self.eng.empty(M, row)
         _check(lib().mosfhet_hip_vec_cmp(self.h, _ptr(out), _ptr(a), _ptr(b), M, d, int(bool(a_signed)), int(bool(b_signed)), self.eng._stream()))
         return out
+
+    def sl_add(self, a, g, b, h, out_digits, signed=True):
+        da, M, row = a.shape
+        out = self.eng.empty(out_digits, M, row)
+        _check(lib().mosfhet_hip_vec_sl_add(self.h, _ptr(out), int(out_digits), _ptr(a), da, int(g), _ptr(b), b.shape[0], int(h), int(bool(signed)), M, self.eng._stream()))
+        return out
+
+    def extend(self, c, d_ini, signed=True):
+        dc, M, _ = c.shape
+        _check(lib().mosfhet_hip_vec_extend(self.h, _ptr(c), dc, int(d_ini), int(bool(signed)), M, self.eng._stream()))
+        return c
 
     def mul(self, a, b, out_digits, signed=True):
         da, M, row = a.shape

@@ -26,7 +26,8 @@ def main():
                         relu=np.array([r["relu"] for r in rows], dtype=np.int64), lut=np.array([r["lut"] for r in rows], dtype=np.int64),
                         cmp_signed=np.array([r["cmp_signed"] for r in rows], dtype=np.int64), cmp_unsigned=np.array([r["cmp_unsigned"] for r in rows], dtype=np.int64),
                         lut_cleartext=np.array([r["lut_cleartext"] for r in rows], dtype=np.int64),
-                        mul_signed=np.array([r["mul_signed"] for r in rows], dtype=np.int64), mul_unsigned=np.array([r["mul_unsigned"] for r in rows], dtype=np.int64))
+                        mul_signed=np.array([r["mul_signed"] for r in rows], dtype=np.int64), mul_unsigned=np.array([r["mul_unsigned"] for r in rows], dtype=np.int64),
+                        **{k: np.array([r[k] for r in rows], dtype=np.int64) for k in ("sl_g", "sl_h", "sl_add_signed", "sl_add_unsigned")})
     print("wrote tests/golden/ufhe_vectors.npz: %d rows" % len(rows))
 
 

@@ -55,8 +55,17 @@ int main(int argc, char **argv) {
     ufhe_mul_integer(wide, a, b, _ctx);
     const long long r_mul_u = (long long)(uint32_t)ufhe_decrypt_integer(wide, _priv_key, _ctx);
     a->_signed = b->_signed = wide->_signed = true;
-    printf("], \"add\": %d, \"sub\": %d, \"relu\": %d, \"lut\": %d, \"cmp_signed\": %d, \"cmp_unsigned\": %d, \"lut_cleartext\": %d, \"mul_signed\": %lld, \"mul_unsigned\": %lld}%s\n",
-           r_add, r_sub, r_relu, r_lut, r_cmp_s, r_cmp_u, r_lut_ct, r_mul_s, r_mul_u, i == count - 1 ? "" : ",");
+    /* shifted addition (test_int_sl_add): c = a B^g + b B^h with the row's shifts, signed (a's four digits, then the sign extension) and unsigned */
+    const int sg = i & 3, sh = (i >> 2) & 3;
+    ufhe_sl_add_integer(wide, a, sg, b, sh, _ctx);
+    const long long r_sl_s = (long long)(int32_t)ufhe_decrypt_integer(wide, _priv_key, _ctx);
+    a->_signed = b->_signed = wide->_signed = false;
+    ufhe_sl_add_integer(wide, a, sg, b, sh, _ctx);
+    const long long r_sl_u = (long long)(uint32_t)ufhe_decrypt_integer(wide, _priv_key, _ctx);
+    a->_signed = b->_signed = wide->_signed = true;
+    printf("], \"add\": %d, \"sub\": %d, \"relu\": %d, \"lut\": %d, \"cmp_signed\": %d, \"cmp_unsigned\": %d, \"lut_cleartext\": %d, \"mul_signed\": %lld, \"mul_unsigned\": %lld, "
+           "\"sl_g\": %d, \"sl_h\": %d, \"sl_add_signed\": %lld, \"sl_add_unsigned\": %lld}%s\n",
+           r_add, r_sub, r_relu, r_lut, r_cmp_s, r_cmp_u, r_lut_ct, r_mul_s, r_mul_u, sg, sh, r_sl_s, r_sl_u, i == count - 1 ? "" : ",");
     fflush(stdout);
   }
   printf("]}\n");

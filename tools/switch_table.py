@@ -27,6 +27,8 @@ SWITCHES = {
                                 "-", "`tools/launch_chunk_sweep.py` (timing); results independent of it by construction (same kernel, same blocks)"),
     "MOSFHET_HIP_PACE": ("32", "N >= 2048: the teams of a residency round re-align per XCD every this many CMUX steps (`pace_teams`); 0 = off", "-",
                          "`test_team_pacing_changes_timing_only`"),
+    "MOSFHET_HIP_PACE_SKIP": ("16", "paced launches of a device that skip the rendezvous after one launch's wait ran out (the chip is being shared); 0 = every launch tries", "-",
+                              "`test_team_pacing_changes_timing_only`"),
     "MOSFHET_HIP_PACE_LIMIT": ("100000", "bound of one re-alignment wait in 10 ns ticks (1 ms), after which the launch stops waiting", "-", "`test_team_pacing_changes_timing_only`"),
     "MOSFHET_HIP_CB_TOGETHER": ("auto", "circuit bootstraps / KS21 on few inputs: all gadget levels through one table switch and one row-mode bootstrap launch (1), one per level (0); "
                                 "auto = when it saves table sweeps, folded keys only", "-", "`test_per_level_compositions_on_the_lvl2_ring_in_row_mode`, `tools/cb_together_ab.sh`"),
