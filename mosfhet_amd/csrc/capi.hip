@@ -510,12 +510,12 @@ static void launch_external_product(int l, int Bg_bit, hipStream_t s, const d2 *
     if (l == 4) { EP_GO_F(Fft2048L, 4, 0); return; }   // (other even lengths: not measured)
   }
   if (l == 2 && Bg_bit == 8 && !unbounded_2x8) EP_GO(2, 8);
-  else if (l == 4 && Bg_bit == 9) EP_GO(4, 9);
+  else if (l == 4 && Bg_bit == 9) { if constexpr (!std::is_same<F, Fft2048>::value) EP_GO(4, 9); }   // (N = 2048, l = 4 left above: no instantiation here)
   else if (l == 1 && Bg_bit == 23) EP_GO(1, 23);
   else if (l == 1) EP_GO(1, 0);
   else if (l == 2) EP_GO(2, 0);
   else if (l == 3) EP_GO(3, 0);
-  else if (l == 4) EP_GO(4, 0);
+  else if (l == 4) { if constexpr (!std::is_same<F, Fft2048>::value) EP_GO(4, 0); }
   else if (l == 5) EP_GO(5, 0);
   else EP_GO(6, 0);
 #undef EP_GO
