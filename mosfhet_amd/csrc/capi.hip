@@ -644,6 +644,9 @@ static int launch_pbs_f(int l, int Bg_bit, const PbsParams &p, int count, hipStr
   // TRGSW_DFT objects (blind_rotate(tv, a, TRGSW_DFT *s, size)) takes the reducing run-time-gadget kernel.
   if (l == 2 && Bg_bit == 8 && (bounded || F::N != 1024)) launch_pbs<F, 2, 8>(p, count, s);
   else if (l == 4 && Bg_bit == 9) launch_pbs<F, 4, 9>(p, count, s);
+  // 6 x 2^7 at N = 2048: the one parameter set of the reference's radix-integer application (applications/multi-ciphertext-arith/src/ufhe.c:18-20); the compile-time
+  // gadget is worth 20 - 35 % on this kernel (l = 4: 17.1 against 21.7 ms per 1024 with the gadget at run time)
+  else if (l == 6 && Bg_bit == 7 && F::N == 2048) { if constexpr (F::N == 2048) launch_pbs<F, 6, 7>(p, count, s); }
   // l = 1: the transform grouping with a full last pass (negacyclic_fft.h, Fft2048T: same results, same key layout; +2 % at SET_2, +6 % at SET_3)
   else if (l == 1 && Bg_bit == 23) launch_pbs<typename WideTail<F>::type, 1, 23>(p, count, s);
   else if (l == 1) launch_pbs<typename WideTail<F>::type, 1, 0>(p, count, s);
