@@ -4,7 +4,7 @@ fault of the kind the round-3 / round-5 experiments chase (tools/spill_hazard, 1
 at rates far below what a parity test of a few thousand units can see.
 
     python tools/soak.py [launches] [what,...]      what: ep_lvl2 ep_lvl2_cmux ep_set1 ep_set1_cmux ep_set1_global ep_set2 ep_set3 pbs_set1 pbs_lvl2
-                                                           pbs_set1_small pbs_lvl2_small (latency kernels: 256 / 128 per launch) pbs_set2 ks_lvl2 cb3_lvl2 ga_lvl2
+                                                           pbs_set1_small pbs_lvl2_small (latency kernels: 256 / 128 per launch) pbs_set2 ks_lvl2 cb3_lvl2 ga_lvl2 vec
 
 Prints one line per case: launches, units per launch, launches whose output differed, units that differed in total.
 """
@@ -40,6 +40,33 @@ def main():
         return keys[(pset, n)]
 
     for case in what:
+        if case == "vec":
+            # the digit-parallel radix-integer callers (capi_vec.inc): whole gate sequences over pooled temporaries -- every repetition must give the first one's bits
+            t0 = time.time()
+            n, N, l, Bg, t, bb, B, d, M = 630, 2048, 6, 7, 6, 2, 4, 4, 64
+            host.seed(0x0F50)
+            lk = host.LweKey(n, 3.0517578125e-05)
+            rk = host.RlweKey(N, 1, 5.684341886080802e-14)
+            ex = rk.extracted_lwe_key()
+            bsk = eng.generate_bootstrap_key(rk.s[0], lk.s, l, Bg, 5.684341886080802e-14, seed=31)
+            ksk = eng.generate_keyswitch_key(lk.s, ex.s, t, bb, 3.0517578125e-05, seed=32, compressed=True)
+            pksk = eng.generate_lut_packing_key(rk.s[0], ex.s, t, bb, B, 5.684341886080802e-14, seed=33)
+            vec = eng.vector_ops(bsk, ksk, pksk, B)
+            rngv = np.random.default_rng(3)
+            def enc(v):
+                msgs = [host.double2torus(float((int(x) >> (2 * i)) & 3) / (2 * B)) for i in range(d) for x in v]
+                return ma.to_device(host.tlwe_samples(msgs, ex).reshape(d, len(v), N + 1), eng.device)
+            a, b = enc(rngv.integers(0, 256, M)), enc(rngv.integers(0, 256, M))
+            ops = {"add": lambda: vec.addsub(a, b), "sub": lambda: vec.addsub(a, b, subtract=True), "relu": lambda: vec.relu(a), "cmp": lambda: vec.cmp(a, b, True, True),
+                   "sl_add": lambda: vec.sl_add(a, 1, b, 2, 16, signed=False), "mul_signed": lambda: vec.mul(a, b, 16, signed=True), "mul_unsigned": lambda: vec.mul(a, b, 16, signed=False),
+                   "lut_cleartext": lambda: vec.lut_cleartext(a[:2].contiguous(), np.arange(16, dtype=np.uint64) * 7 % 256, d)}
+            reps = max(2, launches // 100)
+            for name, fn in ops.items():
+                first = fn().clone()
+                bad = sum(0 if torch.equal(fn(), first) else 1 for _ in range(reps))
+                print("vec %-14s %4d calls x %3d integers: %d calls differed" % (name, reps, M, bad), flush=True)
+            print("vec: %.1f s" % (time.time() - t0), flush=True)
+            continue
         kind, _, rest = case.partition("_")
         pset, _, mode = rest.partition("_")
         t0 = time.time()
