@@ -196,6 +196,20 @@ struct Digits {
 // Digit words of one accumulator component for this thread's 8 coefficient pairs.  `home` != nullptr: the component
 // lives in LDS (al / ah unused); otherwise it lives in registers (al, ah) and is staged through the transpose
 // buffer for the rotation.  F = Fft1024 (one wavefront) or Fft2048 (two wavefronts, workgroup barriers).
+// x + off for the run-time-gadget builds of the fused bootstrap kernel (cmux_digits; the external-product and Galois kernels gain nothing from it): the (wave-uniform) offset word is read from its SGPR pair by ONE 64-bit add.  Written as `x + off` the compiler splits it into
+// add / add-with-carry, whose second half reads VCC and therefore needs the offset's high word in a VGPR; at 256 registers that copy tips the allocator into 78 - 130
+// spills per lane (N = 2048) with 64 scratch operations per CMUX step -- with this form 14 - 96 and 10 - 24 (experiments/README.md round 5).  Compile-time gadgets
+// keep the plain expression (their offset is an immediate).
+template <int BG>
+__device__ __forceinline__ uint64_t add_offset(uint64_t x, uint64_t off) {
+  if constexpr (BG == 0) {
+    uint64_t r;
+    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(off));
+    return r;
+  } else {
+    return x + off;
+  }
+}
 template <class F, int L, int BG>
 __device__ __forceinline__ void cmux_digits(typename Digits<L, BG>::word_t (&w_lo)[8], typename Digits<L, BG>::word_t (&w_hi)[8],
                                             uint32_t (&ext)[8], const uint64_t (&al)[8], const uint64_t (&ah)[8],
@@ -208,8 +222,8 @@ __device__ __forceinline__ void cmux_digits(typename Digits<L, BG>::word_t (&w_l
 #pragma unroll
     for (int m = 0; m < 8; m++) {
       const int j = m * T + t;
-      D::pack(w_lo[m], w_hi[m], ext[m], rot_coeff<N>(home, j, a_lo, flip) - home[j] + off,
-              rot_coeff<N>(home, j + M, a_lo, flip) - home[j + M] + off);
+      D::pack(w_lo[m], w_hi[m], ext[m], add_offset<BG>(rot_coeff<N>(home, j, a_lo, flip) - home[j], off),
+              add_offset<BG>(rot_coeff<N>(home, j + M, a_lo, flip) - home[j + M], off));
     }
   } else {
     // stage the component and read it back rotated by abar
@@ -223,8 +237,8 @@ __device__ __forceinline__ void cmux_digits(typename Digits<L, BG>::word_t (&w_l
 #pragma unroll
     for (int m = 0; m < 8; m++) {
       const int j = m * T + t;
-      D::pack(w_lo[m], w_hi[m], ext[m], rot_coeff<N>(st, j, a_lo, flip) - al[m] + off,
-              rot_coeff<N>(st, j + M, a_lo, flip) - ah[m] + off);
+      D::pack(w_lo[m], w_hi[m], ext[m], add_offset<BG>(rot_coeff<N>(st, j, a_lo, flip) - al[m], off),
+              add_offset<BG>(rot_coeff<N>(st, j + M, a_lo, flip) - ah[m], off));
     }
     F::sync();
   }
