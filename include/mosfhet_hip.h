@@ -365,6 +365,9 @@ int mosfhet_hip_vec_encrypted_lut(mosfhet_hip_vec_t vec, uint64_t *d_table, cons
 int mosfhet_hip_vec_cmp(mosfhet_hip_vec_t vec, uint64_t *d_c, const uint64_t *d_a, const uint64_t *d_b, int M, int d, int a_signed, int b_signed, void *stream);
 /*   mul: c = a * b (ufhe_mul_integer, src/integer.c:166-203): schoolbook over a's digits -- per digit one multi-value rotation, two packed product tables per integer,
  *        two bootstrap launches over all digits of b, a shifted addition and a shifted accumulation; a [da][M][N+1], b [db][M][N+1], c [dc][M][N+1], no aliasing */
+/*   mux_array: out[m] = vec[selector_m][m] over arrays of `size` integers of d digits (ufhe_mux_integer_array, src/lut.c:49-64): all d trees of all M instances as ONE
+ *        tree over d M instances; d_tables [size][d][M][N+1] is consumed, d_sel [log_B size][M][N+1], d_out [d][M][N+1] */
+int mosfhet_hip_vec_mux_array(mosfhet_hip_vec_t vec, uint64_t *d_out, uint64_t *d_tables, const uint64_t *d_sel, int size, int d, int M, void *stream);
 int mosfhet_hip_vec_sl_add(mosfhet_hip_vec_t vec, uint64_t *d_c, int dc, const uint64_t *d_a, int da, int g, const uint64_t *d_b, int db, int h, int is_signed, int M,
                            void *stream);   /* c = a B^g + b B^h (ufhe_sl_add_integer, src/integer.c:79-107) */
 int mosfhet_hip_vec_extend(mosfhet_hip_vec_t vec, uint64_t *d_c, int dc, int d_ini, int is_signed, int M, void *stream);   /* digits [d_ini, dc) <- zero or sign (ufhe_extend_integer, :62-77) */

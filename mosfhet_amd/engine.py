@@ -760,6 +760,13 @@ class VectorOps:
         _check(lib().mosfhet_hip_vec_cmp(self.h, _ptr(out), _ptr(a), _ptr(b), M, d, int(bool(a_signed)), int(bool(b_signed)), self.eng._stream()))
         return out
 
+    def mux_array(self, tables, sel):
+        """tables [size][d][M][N+1] (consumed), sel [log_B size][M][N+1] -> [d][M][N+1]"""
+        size, d, M, row = tables.shape
+        out = self.eng.empty(d, M, row)
+        _check(lib().mosfhet_hip_vec_mux_array(self.h, _ptr(out), _ptr(tables), _ptr(sel), size, d, M, self.eng._stream()))
+        return out
+
     def sl_add(self, a, g, b, h, out_digits, signed=True):
         da, M, row = a.shape
         out = self.eng.empty(out_digits, M, row)
