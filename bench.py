@@ -372,6 +372,22 @@ def usable_cores():
     return n
 
 
+def launch_ranks(n_gpus):
+    """One rank per GPU under torch.distributed.run on this node (127.0.0.1, a free port), started as a child process with this script's own arguments.
+    The child's stdout / stderr are inherited, so rank 0's JSON line is this command's JSON line; returns the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this pool's host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -386,13 +402,17 @@ def main():
     ap.add_argument("--no-configs34", action="store_true", help="skip the configs[3] / [4] legs (circuit bootstrap, FDFB, multi-value, Galois bootstrap: ~10 s; N > 1: the batches split over the ranks)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as a CHILD torch.distributed.run, before this process has imported torch or
+        # touched a GPU (never exec: see the GPU pool's rule); relay the ranks' output -- rank 0's one JSON line -- and leave with the child's code
+        sys.exit(launch_ranks(args.gpus))
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        sys.exit("bench.py --gpus %d inside a launcher with WORLD_SIZE=%d: the two must agree" % (args.gpus, world))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: mosfhet_amd has no CPU path")
     # Test hooks for the N > 1 path on a box with fewer GPUs than ranks (tests/test_gpu_parity.py::test_bench_two_ranks_on_one_gpu): every rank on
@@ -434,6 +454,15 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(P, bk, tv, cts[:64], args.cpu_seconds)
         cpu["ffnt_single_ms"] = ffnt_single_ms(P, bk, tv, cts[0])      # BASELINE.json configs[0]
+    elif world > 1 and not args.no_cpu_baseline:
+        # N > 1: the same sample, shorter, on rank 0 while the other ranks sleep in a socket wait (a gloo side group: an RCCL barrier would keep one host
+        # core per rank spinning under the CPU measurement) -- so that a SCALE line carries its own cpu_baseline
+        side = dist.new_group(backend="gloo") if backend == "nccl" else None
+        dist.barrier(group=side)
+        if rank == 0:
+            cpu = cpu_baseline(P, bk, tv, cts[:64], min(args.cpu_seconds, 8.0))
+            cpu["sample"] += " (rank 0 of %d, the other ranks idle)" % world
+        dist.barrier(group=side)
     d_tv = ma.to_device(tv[None], eng.device)
     d_ct = ma.to_device(cts, eng.device)
     d_out = eng.empty(B, P["k"] * P["N"] + 1)

@@ -65,3 +65,20 @@ def test_two_rank_sharded_batch_matches_single_process(count):
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, port, count, ret), nprocs=2, join=True)
     assert ret["ok"]
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE around it starts two ranks as a child torch.distributed.run.  No GPU here: each
+    rank must reach the loud no-GPU exit (there is no CPU path), and the command's exit code must be the child's."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: tests/test_gpu_parity.py::test_bench_launches_its_own_ranks runs the real thing")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=600, env=env, cwd=root)
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs a GPU") == 2, r.stderr[-2000:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
