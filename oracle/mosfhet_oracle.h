@@ -86,6 +86,8 @@ void orc_poly_mul_fft(const orc_fft_plan *p, Torus *out, const Torus *a, const T
 /* ---- TRGSW / bootstrap ---- */
 void orc_trgsw_to_dft(const orc_fft_plan *p, double *out /*[(k+1)l][k+1][N]*/,
                       const Torus *in, int k, int l);                                 /* trgsw.c:345-349 */
+void orc_set_product_order(int order);   /* 0: the reference's one chain over all rows; 1: per input component partial sums, added (oracle_tfhe.c) */
+int orc_get_product_order(void);
 void orc_trgsw_mul_trlwe_dft(const orc_fft_plan *p, double *out_dft /*[k+1][N]*/, const Torus *in /*[k+1][N]*/,
                              const double *trgsw_dft, int k, int l, int Bg_bit);       /* trgsw.c:385-423 */
 void orc_external_product(const orc_fft_plan *p, Torus *out, const Torus *in,

@@ -23,7 +23,7 @@ def build(force=False):
     """Compile liboracle.so with gcc (building the checker is not using it)."""
     if force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-        for f in ("oracle_int.c", "oracle_fft.c", "oracle_tfhe.c", "mosfhet_oracle.h")
+        for f in ("oracle_int.c", "oracle_fft.c", "oracle_tfhe.c", "oracle_ext.c", "mosfhet_oracle.h")
     ):
         subprocess.check_call(["make", "-s", "-C", _HERE, "-B"])
     return _LIB_PATH
@@ -236,6 +236,24 @@ def bk_to_dft(bk, k, l):
     for i in range(bk.shape[0]):
         out[i] = trgsw_to_dft(bk[i], k, l)
     return out
+
+
+class product_order:
+    """with product_order("by_component"): every external product of the oracle (and so every composition) sums per input component first -- the order of a
+    bootstrap split over one workgroup per accumulator component (oracle_tfhe.c: orc_set_product_order); "reference" = one chain over all rows (default)."""
+    ORDERS = {"reference": 0, "by_component": 1}
+
+    def __init__(self, order):
+        self.order = self.ORDERS[order]
+
+    def __enter__(self):
+        self.old = lib().orc_get_product_order()
+        lib().orc_set_product_order(self.order)
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_product_order(self.old)
+        return False
 
 
 def external_product(c, g_dft, l, Bg_bit):

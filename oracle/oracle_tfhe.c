@@ -22,11 +22,45 @@ void orc_trgsw_to_dft(const orc_fft_plan *p, double *out, const Torus *in, int k
 /* src/trgsw.c:385-423  trgsw_mul_trlwe_DFT.
  * out_DFT[c] = sum_{p<=k} sum_{j<l} DFT(digit_j(in[p])) (.) row[p*l+j][c], rows of a[0] first, b last,
  * levels in increasing j, accumulated in that order (first product, then mul-add). */
+static int g_product_order = 0;
+/* 0 (default): the reference's order -- one mul-add chain over all (k+1) l rows, as described above.
+ * 1: "per input component" -- the l rows of each input component q are chained from zero into a partial sum of their own and the partial sums are
+ *    added in component order ((P_0 + P_1) + ...).  The order of a bootstrap that is split over one workgroup per accumulator component
+ *    (mosfhet_amd/csrc/bootstrap_kernels.h: pbs_split_kernel), each of which can only see its own component's rows; the reference's result
+ *    differs from it by FFT-level rounding only (tests/test_oracle_vs_reference.py holds this order to the reference within the same tolerance).
+ * Every composition of this oracle (bootstraps, circuit bootstraps, ...) goes through orc_trgsw_mul_trlwe_dft and follows the switch. */
+void orc_set_product_order(int order) { g_product_order = order; }
+int orc_get_product_order(void) { return g_product_order; }
+
+static void trgsw_mul_trlwe_dft_by_component(const orc_fft_plan *p, double *out_dft, const Torus *in, const double *trgsw_dft, int k, int l,
+                                             int Bg_bit, int N) {
+  Torus *dec = (Torus *)malloc(sizeof(Torus) * (size_t)N);
+  double *dec_dft = (double *)malloc(sizeof(double) * (size_t)N);
+  double *part = (double *)malloc(sizeof(double) * (size_t)(k + 1) * N);
+  for (int q = 0; q <= k; q++) {
+    memset(part, 0, sizeof(double) * (size_t)(k + 1) * N);
+    for (int j = 0; j < l; j++) {
+      orc_poly_decompose_i(dec, in + (size_t)q * N, N, Bg_bit, l, j);
+      orc_int_to_dft(p, dec_dft, (const int64_t *)dec);
+      const double *row = trgsw_dft + (size_t)(q * l + j) * (k + 1) * N;
+      for (int c = 0; c <= k; c++) orc_dft_mul_addto(part + (size_t)c * N, dec_dft, row + (size_t)c * N, N);
+    }
+    for (size_t x = 0; x < (size_t)(k + 1) * N; x++) out_dft[x] = q == 0 ? part[x] : out_dft[x] + part[x];
+  }
+  free(dec);
+  free(dec_dft);
+  free(part);
+}
+
 void orc_trgsw_mul_trlwe_dft(const orc_fft_plan *p, double *out_dft, const Torus *in,
                              const double *trgsw_dft, int k, int l, int Bg_bit) {
   int cnt = 0;
   (void)orc_fft_twiddles(p, &cnt);
   const int N = 2 * (cnt + 1);
+  if (g_product_order == 1) {
+    trgsw_mul_trlwe_dft_by_component(p, out_dft, in, trgsw_dft, k, l, Bg_bit, N);
+    return;
+  }
   Torus *dec = (Torus *)malloc(sizeof(Torus) * (size_t)N);
   double *dec_dft = (double *)malloc(sizeof(double) * (size_t)N);
   memset(out_dft, 0, sizeof(double) * (size_t)(k + 1) * N);
