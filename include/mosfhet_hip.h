@@ -334,6 +334,18 @@ int mosfhet_hip_tlwe_ksk_generate(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t *out,
 int mosfhet_hip_set_team_max_batch(int max_batch);
 /* the same switch-over for N = 2048 and, at half the value, N = 4096 (one workgroup of two transform teams per ciphertext; default 512, MOSFHET_HIP_WIDE_TEAM_MAX; 0 disables) */
 int mosfhet_hip_set_wide_team_max_batch(int max_batch);
+/* N = 2048, l = 4 (the TFHEpp lvl2 set of BASELINE.json configs[2..4]): batches of at most `max_batch` bootstraps take TWO CUs each (pbs_split_kernel: one workgroup per
+ * accumulator component, one 16 KiB exchange per CMUX step) -- the share one GPU gets when a config's batch is sharded over eight leaves half its CUs idle otherwise.
+ * -1 = half the device's CUs (default, MOSFHET_HIP_SPLIT_MAX), 0 = never.  The ONE selection that changes bits: that kernel adds the external product's rows per
+ * accumulator component and then the two partial sums (src/trgsw.c:393-419 is one chain over all rows); the results differ from every other kernel's by FFT-level
+ * rounding -- the tolerance the reference's own tests accept between its two FFT back-ends -- and are bit-identical to the oracle's restatement of that order
+ * (oracle/oracle_tfhe.c: orc_set_product_order). */
+int mosfhet_hip_set_split_max_batch(int max_batch);
+/* how long (10 ns ticks; default 200000 = 2 ms, MOSFHET_HIP_SPLIT_LIMIT) the first workgroup of such a pair waits for its partner before it takes the whole bootstrap
+ * alone (same summation order, same bits); 0 = always alone (test switch) */
+int mosfhet_hip_set_split_wait_limit(int ticks);
+/* of the calling host thread's last split launch (synchronises its stream): bootstraps taken by a pair of workgroups / alone */
+int mosfhet_hip_split_last_launch(int *count, int *paired, int *alone);
 
 /* Unit-loop form of the external-product kernel on rings of two wavefronts per team (N = 2048, l = 4; trgsw_mul_trlwe_DFT, src/trgsw.c:385-423).  The
  * software-pipelined loop is taken only by the instantiation that has been soaked clean and only while its build has no scratch (capi.hip: ep_go); the plain

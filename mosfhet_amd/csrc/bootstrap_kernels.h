@@ -858,6 +858,265 @@ __global__ __launch_bounds__(2 * F::THREADS) void pbs_wide_pair_kernel(PbsParams
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// pbs_split_kernel: ONE bootstrap on TWO workgroups (two CUs), split by accumulator component -- for batches that leave half the chip idle (N = 2048, l = 4:
+// up to CUs / 2 ciphertexts, the share of configs[3] / [4] one GPU of eight gets).  Workgroup h of a pair keeps accumulator component h.  The rows h l ..
+// h l + l - 1 of a TRGSW sample are exactly the rows that decompose component h (src/trgsw.c:393-419), so per CMUX step workgroup h
+//   * rotates and decomposes ITS component (both teams read it), runs the l forward transforms (pbs_wide_pair_kernel's double phase: team w takes rows
+//     h l + w and h l + 2 + w, pipelined, handed over through LDS) and multiplies-accumulates them against the key rows' two components, team w the output
+//     component w: the partial sums S_h[0], S_h[1] -- half the transforms, half the products and half the key rows (128 KiB) of a step;
+//   * team 1 - h SENDS S_h[1 - h] (16 KiB) to the partner; team h RECEIVES S_(1-h)[h], adds it to S_h[h], runs the ONE inverse transform, rounds and adds
+//     to its component -- all it needs for its next decomposition.
+// Summation order: out[c] = (chain over rows 0 .. l-1 from zero) + (chain over rows l .. 2l-1 from zero) -- NOT the reference's one chain over all 2 l rows
+// (an fma chain cannot be cut without changing roundings).  The difference is FFT-level rounding; the oracle restates this order
+// (oracle_tfhe.c: orc_set_product_order(1), held to the reference within the tolerance of the plain order) and the kernel is bit-identical to THAT.
+// Exchange (tools/ubench/xchg.hip: 1.5 us per step against 3.75 us for data + flag): no flag.  Receive slots hold a sentinel -- a NaN pattern that fma
+// arithmetic on finite numbers never produces; the sender's lanes store their 16-byte items with device-scope stores, the receiver's lanes poll THEIR OWN
+// items with device-scope loads until both halves of every item differ from the sentinel, then put the sentinel back (complete before the workgroup's next send
+// can be observed: s_waitcnt + the step's barrier).  Two slot sets alternate by step, so a sender never meets a slot its partner has not reset.
+// Pairing: blocks B and B + 8 (the same XCD when workgroups are dealt round-robin; nothing depends on it) claim their ciphertext through one state word:
+// the first to arrive waits a bounded time for the second; if that runs out (the partner is not resident: the chip is shared) it takes the whole
+// bootstrap ALONE -- both components, the same summation order, the same bits -- and the late partner leaves.  Nothing can hang and no result depends on timing.
+// ------------------------------------------------------------------------------------------------------------
+constexpr uint64_t kSplitSentinel = 0xFFF7A5C3DEADBEEFull;
+struct SplitParams {
+  d2 *xbuf;              // [count][2 receivers][2 step parities][M] receive slots, all sentinel between launches
+  unsigned int *state;   // [count] 0 nobody, 1 one workgroup waiting, 2 paired, 3 taken alone; zero before the launch
+  int count;             // ciphertexts (x accumulator rows)
+  int limit;             // bound of the pairing wait in 10 ns ticks; <= 0: every bootstrap is taken alone by its first workgroup (test switch)
+};
+__global__ void split_prepare_kernel(uint64_t *xbuf_words, size_t n_words, unsigned int *state, int count) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_words) xbuf_words[i] = kSplitSentinel;
+  if (i < (size_t)count) state[i] = 0u;
+}
+// the lane's eight 16-byte items of a 16 KiB set (item m at [m * 128 + t]), device scope
+__device__ __forceinline__ void split_store8(d2 *p, const double (&re)[8], const double (&im)[8]) {
+#pragma unroll
+  for (int m = 0; m < 8; m++) {
+    const d2 v = d2{re[m], im[m]};
+    // (s_nop 1: a store of more than 8 bytes reads its data registers late -- the VALU instruction behind it must not overwrite them for two wait states, and the
+    // compiler's hazard recognizer does not look into inline assembly; tools/ubench/xchg.hip sent half-computed real parts from lanes 12 - 15 of every 16 without it)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p + m * 128), "v"(v) : "memory");
+  }
+}
+__device__ __forceinline__ void split_load8(d2 (&v)[8], const d2 *p) {
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off sc1\n\t"
+      "global_load_dwordx4 %1, %8, off offset:2048 sc1\n\t"
+      "global_load_dwordx4 %2, %9, off sc1\n\t"
+      "global_load_dwordx4 %3, %9, off offset:2048 sc1\n\t"
+      "global_load_dwordx4 %4, %10, off sc1\n\t"
+      "global_load_dwordx4 %5, %10, off offset:2048 sc1\n\t"
+      "global_load_dwordx4 %6, %11, off sc1\n\t"
+      "global_load_dwordx4 %7, %11, off offset:2048 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+      : "v"(p), "v"(p + 256), "v"(p + 512), "v"(p + 768)
+      : "memory");
+}
+
+template <class F, int L, int BG>
+__global__ __launch_bounds__(2 * F::THREADS) void pbs_split_kernel(PbsParams p, SplitParams sp) {
+  static_assert(F::kForward2 && F::kLtw && L == 4 && F::THREADS == 128, "one double phase of pbs_wide_pair_kernel = the l = 4 rows of one accumulator component");
+  constexpr int N = F::N, M = F::M, T = F::THREADS, LOG2N2 = F::LOGM + 2, WG = 2 * T;
+  constexpr bool kReduce = !(BG > 0 && kCeilLog2<2 * L>::value + (F::LOGM + 1) + BG - 1 + 63 < 83);   // see pbs_kernel
+  extern __shared__ __attribute__((aligned(16))) unsigned char wide_lds[];
+  d2 *xch_all = reinterpret_cast<d2 *>(wide_lds);                                   // [2][F::XCH_SLOTS]
+  d2 *hand = xch_all + (size_t)2 * F::XCH_SLOTS;                                    // [4][M]: row r of the double phase
+  uint64_t *acc = reinterpret_cast<uint64_t *>(hand + (size_t)4 * M);               // [2][N] (paired: only component h is kept up to date)
+  __shared__ int mode_s;
+  const int tid = threadIdx.x, team = __builtin_amdgcn_readfirstlane(tid / T), t = tid % T;
+  d2 *xch = xch_all + (size_t)team * F::XCH_SLOTS;
+  const int h = (int)((blockIdx.x >> 3) & 1u);
+  const size_t b = (size_t)(blockIdx.x >> 4) * 8 + (blockIdx.x & 7u);
+  if (b >= (size_t)sp.count) return;
+  // ---- pairing ----
+  if (tid == 0) {
+    unsigned int *st = sp.state + b;
+    int mode;   // 0 paired, 1 alone, 2 leave
+    if (sp.limit <= 0) {
+      mode = h == 0 ? 1 : 2;
+    } else {
+      unsigned int seen = 0u;
+      if (__hip_atomic_compare_exchange_strong(st, &seen, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        const long long t0 = wall_clock64();   // first here: wait for the partner, but not for ever
+        mode = -1;
+        while (mode < 0) {
+          if (__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2u) mode = 0;
+          else if (wall_clock64() - t0 > sp.limit) {
+            unsigned int one = 1u;
+            mode = __hip_atomic_compare_exchange_strong(st, &one, 3u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+          } else __builtin_amdgcn_s_sleep(8);
+        }
+      } else if (seen == 1u) {
+        unsigned int one = 1u;
+        mode = __hip_atomic_compare_exchange_strong(st, &one, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0 : 2;
+      } else {
+        mode = 2;
+      }
+    }
+    mode_s = mode;
+  }
+  workgroup_sync();
+  const int mode = mode_s;
+  if (mode == 2) return;
+  const bool alone = mode == 1;
+  const int dp_lo = alone ? 0 : h, dp_hi = alone ? 2 : h + 1;
+  d2 *recv = sp.xbuf + ((size_t)b * 2 + (size_t)h) * 2 * M, *send = sp.xbuf + ((size_t)b * 2 + (size_t)(1 - h)) * 2 * M;
+
+  const uint64_t *__restrict__ ct = p.in + (p.rows > 1 ? b / (size_t)p.rows : b) * (size_t)(p.n + 1);
+  const int Bg_bit = BG > 0 ? BG : p.Bg_bit;
+  F fft;
+  fft_setup(fft, p.tw, t);
+  if (p.skip_init) {
+    const uint64_t *src = p.out + b * (size_t)(2 * N);
+    for (int x = tid; x < 2 * N; x += WG) acc[x] = src[x];
+  } else {
+    const uint64_t *__restrict__ tv = p.rows > 1 ? p.tv + (b % (size_t)p.rows) * (size_t)(2 * N) : p.tv + b * (size_t)p.tv_stride;
+    const uint32_t bbar = modswitch<LOG2N2>(pbs_pre(ct[p.n], p, LOG2N2) + p.prec_offset);
+    const int rot = (2 * N - (int)bbar) & (2 * N - 1);
+    const int a_lo = rot & (N - 1);
+    const bool flip = (rot & N) != 0;
+    for (int x = tid; x < 2 * N; x += WG) acc[x] = rot_coeff<N>(tv + (x / N) * N, x & (N - 1), a_lo, flip);
+  }
+  workgroup_sync();
+  uint64_t off = 1ull << (63 - L * Bg_bit);
+#pragma unroll
+  for (int i = 0; i < L; i++) off += 1ull << (63 - i * Bg_bit);
+  const RoundCtx scale(0x1p-64 / (double)M);
+  const size_t row_sz = (size_t)2 * L * 2 * M;
+  const uint32_t mask = (1u << Bg_bit) - 1;
+  const int half = 1 << (Bg_bit - 1);
+  const int sx = 64 - (team + 1) * Bg_bit, sy = 64 - (team + 3) * Bg_bit;   // this team's levels: team (x) and team + 2 (y) of the component
+  int par = 0;
+  for (int i = 0; i < p.n; i++) {
+    const int abar = (int)modswitch<LOG2N2>(pbs_pre(ct[i], p, LOG2N2));
+    if (!abar) continue;   // src/bootstrap.c:114 (uniform over both workgroups of a pair)
+    const d2 *__restrict__ bkrow = p.bk + (size_t)i * row_sz;
+    const int a_lo = abar & (N - 1);
+    const bool flip = (abar & N) != 0;
+    double s_re[8], s_im[8];   // this team's output component: sum of the components' partial sums, component 0's first
+#pragma unroll 1
+    for (int dp = dp_lo; dp < dp_hi; dp++) {
+      d2 kk[4][8];   // this team's output component of the four key rows of input component dp
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int m = 0; m < 8; m++) kk[r][m] = bkrow[(size_t)(4 * dp + r) * (2 * M) + (size_t)team * M + m * T + t];
+      double o_re[8], o_im[8];
+#pragma unroll
+      for (int m = 0; m < 8; m++) { o_re[m] = 0.0; o_im[m] = 0.0; }
+      double xr[8], xi[8], yr[8], yi[8];
+      {
+        const uint64_t *accx = acc + (size_t)dp * N;
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          const int j = m * T + t;
+          const uint64_t d_lo = rot_coeff<N>(accx, j, a_lo, flip) - accx[j] + off;
+          const uint64_t d_hi = rot_coeff<N>(accx, j + M, a_lo, flip) - accx[j + M] + off;
+          xr[m] = (double)((int)((uint32_t)(d_lo >> sx) & mask) - half);
+          xi[m] = (double)((int)((uint32_t)(d_hi >> sx) & mask) - half);
+          yr[m] = (double)((int)((uint32_t)(d_lo >> sy) & mask) - half);
+          yi[m] = (double)((int)((uint32_t)(d_hi >> sy) & mask) - half);
+        }
+      }
+      fft.forward2_head(xr, xi, yr, yi, xch, t);
+      fft.pass_d_fwd(xr, xi);
+      d2 *hx = hand + (size_t)team * M, *hy = hand + (size_t)(2 + team) * M;   // hand-over buffer r holds row 4 dp + r
+#pragma unroll
+      for (int m = 0; m < 8; m++) hx[m * T + t] = d2{xr[m], xi[m]};
+      fft.forward2_fetch(yr, yi, xch, t);
+      fft.pass_d_fwd(yr, yi);
+      F::forward2_done();   // (a workgroup barrier: both teams' x rows are handed over)
+#pragma unroll
+      for (int m = 0; m < 8; m++) hy[m * T + t] = d2{yr[m], yi[m]};
+#pragma unroll
+      for (int r = 0; r < 2; r++) {   // fma chain over the component's rows in order: the x rows (levels 0, 1) while the y rows land
+        const d2 *__restrict__ dr = hand + (size_t)r * M;
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          const d2 d = dr[m * T + t], k = kk[r][m];
+          o_re[m] = __builtin_fma(-d.y, k.y, __builtin_fma(d.x, k.x, o_re[m]));
+          o_im[m] = __builtin_fma(d.y, k.x, __builtin_fma(d.x, k.y, o_im[m]));
+        }
+      }
+      workgroup_sync();
+#pragma unroll
+      for (int r = 2; r < 4; r++) {
+        const d2 *__restrict__ dr = hand + (size_t)r * M;
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          const d2 d = dr[m * T + t], k = kk[r][m];
+          o_re[m] = __builtin_fma(-d.y, k.y, __builtin_fma(d.x, k.x, o_re[m]));
+          o_im[m] = __builtin_fma(d.y, k.x, __builtin_fma(d.x, k.y, o_im[m]));
+        }
+      }
+      if (dp == dp_lo) {
+#pragma unroll
+        for (int m = 0; m < 8; m++) { s_re[m] = o_re[m]; s_im[m] = o_im[m]; }
+      } else {
+#pragma unroll
+        for (int m = 0; m < 8; m++) { s_re[m] = s_re[m] + o_re[m]; s_im[m] = s_im[m] + o_im[m]; }
+      }
+      workgroup_sync();   // the hand-over buffers are consumed
+    }
+    bool inv = true;
+    if (!alone) {
+      if (team != h) {   // S_h[1 - h] goes to the workgroup that keeps component 1 - h
+        split_store8(send + (size_t)par * M + t, s_re, s_im);
+        inv = false;
+      } else {
+        d2 *slot = recv + (size_t)par * M + t;
+        d2 v[8];
+        bool all;
+        do {
+          split_load8(v, slot);
+          all = true;
+#pragma unroll
+          for (int m = 0; m < 8; m++) {   // (element copies first: __builtin_bit_cast of a vector ELEMENT reads element 0 whichever is named -- clang 22)
+            const double vx = v[m].x, vy = v[m].y;
+            all = all && __builtin_bit_cast(uint64_t, vx) != kSplitSentinel && __builtin_bit_cast(uint64_t, vy) != kSplitSentinel;
+          }
+        } while (!all);
+        const double sent = __builtin_bit_cast(double, kSplitSentinel);
+#pragma unroll
+        for (int m = 0; m < 8; m++) {   // (IEEE addition commutes: own + partner's is S_0 + S_1 for both workgroups)
+          s_re[m] = s_re[m] + v[m].x;
+          s_im[m] = s_im[m] + v[m].y;
+          const d2 sv = d2{sent, sent};
+          asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(slot + m * 128), "v"(sv) : "memory");
+        }
+      }
+      par ^= 1;
+    }
+    if (inv) {   // (workgroup barriers inside: a team that sits it out walks the same barriers)
+      fft.inverse(s_re, s_im, xch, t);
+      uint64_t *accw = acc + (size_t)team * N;
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        accw[m * T + t] = add_rounded<kReduce>(accw[m * T + t], s_re[m], scale);
+        accw[M + m * T + t] = add_rounded<kReduce>(accw[M + m * T + t], s_im[m], scale);
+      }
+    } else {
+      F::transform_barriers_only();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the slots put back to the sentinel are at their coherence point before the barrier that precedes the next send
+    workgroup_sync();
+  }
+  const bool mine0 = alone || h == 0, mine1 = alone || h == 1;   // which components this workgroup holds
+  if (p.extract) {
+    // src/trlwe.c:540-552 at idx = 0: the mask comes from component 0, the body from component 1
+    uint64_t *dst = p.out + b * (size_t)(N + 1);
+    if (mine0) for (int j = tid; j < N; j += WG) dst[j] = (j == 0) ? acc[0] : (0 - acc[N - j]);
+    if (mine1 && tid == 0) dst[N] = acc[N];
+  } else {
+    uint64_t *dst = p.out + b * (size_t)(2 * N);
+    for (int x = tid; x < 2 * N; x += WG)
+      if (x < N ? mine0 : mine1) dst[x] = acc[x];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Galois-automorphism bootstrap [src/bootstrap_ga.c:39-76] and its building blocks:
 //   trlwe_keyswitch          [src/keyswitch.c:162-193]  out = (0, b) - IDFT(sum_j DFT(digit_j(a)) (.) KS[j])
 //   trlwe_eval_automorphism  [src/trlwe.c:775-781, src/polynomial.c:442-450]  X -> X^gen on both components, then

@@ -75,7 +75,7 @@ struct DevBuf {
 // handle: handles are read-only after creation, so any number of host threads may share them, as the reference's callers share its keys
 // (re-entrant through thread-local scratch, src/polynomial.c:269-352).  A thread's launches are ordered by the stream it passes; buffers are
 // released at thread exit (hipFree waits for work in flight).
-enum { POOL_BSK = 0, POOL_EXT0 = 1, POOL_EXT1 = 2, POOL_CTX0 = 3, POOL_UNFOLD = 6, POOL_PACK = 7, POOL_VEC = 8, POOL_VEC2 = 9, POOL_SLOTS = 10 };
+enum { POOL_BSK = 0, POOL_EXT0 = 1, POOL_EXT1 = 2, POOL_CTX0 = 3, POOL_UNFOLD = 6, POOL_PACK = 7, POOL_VEC = 8, POOL_VEC2 = 9, POOL_VEC3 = 10, POOL_VEC4 = 11, POOL_SLOTS = 12 };
 struct ThreadPool {
   struct Dev {
     int device = -1;
@@ -718,9 +718,125 @@ static int launch_wide_pair(const PbsParams &p, int count, hipStream_t s) {
   return MOSFHET_HIP_OK;
 }
 
+// ---- one bootstrap on two workgroups (pbs_split_kernel): N = 2048, l = 4, batches of at most half the CUs ----
+// MOSFHET_HIP_SPLIT_MAX: largest batch that takes it (-1 = CUs / 2, the default; 0 = never).  The ONE switch of this library that changes bits: the split kernel sums
+// the external product per accumulator component (see the kernel), within FFT rounding of every other kernel's order.
+static std::atomic<int> g_split_max{-2};
+static int split_max_batch() {
+  int v = g_split_max.load(std::memory_order_relaxed);
+  if (v == -2) {
+    const char *e = getenv("MOSFHET_HIP_SPLIT_MAX");
+    v = e ? atoi(e) : -1;
+    if (v < -1) v = -1;
+    g_split_max.store(v, std::memory_order_relaxed);
+  }
+  return v < 0 ? device_cus() / 2 : v;
+}
+extern "C" int mosfhet_hip_set_split_max_batch(int max_batch) {
+  g_split_max = max_batch < -1 ? -1 : max_batch;
+  return MOSFHET_HIP_OK;
+}
+// MOSFHET_HIP_SPLIT_LIMIT: how long the first workgroup of a pair waits for the second before it takes the bootstrap alone, in 10 ns ticks (default 2 ms);
+// 0 = every bootstrap alone (test switch: same bits)
+static std::atomic<int> g_split_limit{-1};
+static int split_wait_limit() {
+  int v = g_split_limit.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char *e = getenv("MOSFHET_HIP_SPLIT_LIMIT");
+    v = e ? atoi(e) : 200000;
+    if (v < 0) v = 0;
+    g_split_limit.store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+extern "C" int mosfhet_hip_set_split_wait_limit(int ticks) {
+  g_split_limit = ticks < 0 ? 0 : ticks;
+  return MOSFHET_HIP_OK;
+}
+// Exchange slots + pairing words of the split launches of this host thread: one set per (device, stream) -- launches on one stream are ordered, launches on
+// different streams may overlap and must not share slots.  At most SPLIT_SETS streams per thread and device; a further stream takes the one-CU kernel.
+constexpr int SPLIT_SETS = 8;
+struct SplitSet { int device = -1; hipStream_t stream = nullptr; d2 *xbuf = nullptr; unsigned int *state = nullptr; int cap = 0, last_count = 0; };
+struct SplitSets {
+  SplitSet set[SPLIT_SETS];
+  ~SplitSets() {
+    for (SplitSet &x : set)
+      if (x.xbuf && hipSetDevice(x.device) == hipSuccess) { (void)hipFree(x.xbuf); (void)hipFree(x.state); }
+  }
+};
+static thread_local SplitSets t_split;
+static thread_local SplitSet *t_split_last = nullptr;
+static SplitSet *split_set(hipStream_t s, int count) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  SplitSet *free_slot = nullptr;
+  for (SplitSet &x : t_split.set) {
+    if (x.xbuf && x.device == dev && x.stream == s && x.cap >= count) return &x;
+    if (!x.xbuf && !free_slot) free_slot = &x;
+  }
+  if (!free_slot) return nullptr;
+  const int cap = device_cus() / 2 > count ? device_cus() / 2 : count;
+  if (hipMalloc((void **)&free_slot->xbuf, (size_t)cap * 2 * 2 * 1024 * sizeof(d2)) != hipSuccess) { (void)hipGetLastError(); free_slot->xbuf = nullptr; return nullptr; }
+  if (hipMalloc((void **)&free_slot->state, (size_t)cap * sizeof(unsigned int)) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(free_slot->xbuf);
+    free_slot->xbuf = nullptr;
+    return nullptr;
+  }
+  free_slot->device = dev;
+  free_slot->stream = s;
+  free_slot->cap = cap;
+  return free_slot;
+}
+template <int LL, int BB>
+static int launch_split(const PbsParams &p, int count, hipStream_t s, bool *taken) {
+  using F = Fft2048L;
+  *taken = false;
+  SplitSet *set = split_set(s, count);
+  if (!set) return MOSFHET_HIP_OK;   // no slots for this stream: the caller goes on to the one-CU kernel
+  constexpr size_t lds = sizeof(d2) * ((size_t)2 * F::XCH_SLOTS + (size_t)4 * F::M) + sizeof(uint64_t) * 2 * F::N;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_split_kernel<F, LL, BB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const size_t words = (size_t)count * 2 * 2 * F::M * 2;
+  hipLaunchKernelGGL(split_prepare_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, reinterpret_cast<uint64_t *>(set->xbuf), words, set->state, count);
+  SplitParams sp;
+  sp.xbuf = set->xbuf;
+  sp.state = set->state;
+  sp.count = count;
+  sp.limit = split_wait_limit();
+  hipLaunchKernelGGL((pbs_split_kernel<F, LL, BB>), dim3((unsigned)(16 * ((count + 7) / 8))), dim3(2 * F::THREADS), lds, s, p, sp);
+  HIP_TRY(hipGetLastError());
+  set->last_count = count;
+  t_split_last = set;
+  *taken = true;
+  return MOSFHET_HIP_OK;
+}
+// How the bootstraps of this host thread's LAST split launch were taken (synchronises its stream): by a pair of workgroups, or alone by the first to arrive.
+// For tests and bench.py.  EINVAL when the thread has not made one.
+extern "C" int mosfhet_hip_split_last_launch(int *count, int *paired, int *alone) {
+  SplitSet *set = t_split_last;
+  if (!set || !count || !paired || !alone) return fail(MOSFHET_HIP_EINVAL, "split_last_launch: no split launch on this thread yet");
+  HIP_TRY(hipSetDevice(set->device));
+  HIP_TRY(hipStreamSynchronize(set->stream));
+  std::vector<unsigned int> st((size_t)set->last_count);
+  HIP_TRY(hipMemcpy(st.data(), set->state, st.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
+  *count = set->last_count;
+  *paired = *alone = 0;
+  for (unsigned int v : st) {
+    if (v == 2u) ++*paired;
+    else ++*alone;   // 3: the wait ran out; 0: the wait limit was 0 (every bootstrap alone)
+  }
+  return MOSFHET_HIP_OK;
+}
+
 template <class F>
 static int launch_wide_team_f(int l, int Bg, const PbsParams &p, int count, hipStream_t s, bool bounded) {
   if constexpr (F::N == 2048) {
+    // at most half the CUs' worth of ciphertexts at l = 4: two CUs per bootstrap (pbs_split_kernel)
+    if (l == 4 && count <= split_max_batch()) {
+      bool taken = false;
+      const int rc = Bg == 9 ? launch_split<4, 9>(p, count, s, &taken) : launch_split<4, 0>(p, count, s, &taken);
+      if (rc != MOSFHET_HIP_OK || taken) return rc;
+    }
     // one workgroup per CU (137 KiB of LDS each): up to as many ciphertexts as the device has CUs; beyond that pbs_wide_team_kernel runs two workgroups per CU
     if (wide_pairs_enabled() && l % 2 == 0 && count <= device_cus()) {
       if (l == 4 && Bg == 9) return launch_wide_pair<4, 9>(p, count, s);

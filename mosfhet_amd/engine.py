@@ -728,6 +728,23 @@ def set_wide_team_max_batch(max_batch):
     _check(lib().mosfhet_hip_set_wide_team_max_batch(int(max_batch)))
 
 
+def set_split_max_batch(max_batch):
+    """N = 2048, l = 4: batches up to this size take two CUs per bootstrap (pbs_split_kernel; sums per accumulator component: FFT-level different bits). -1 = CUs / 2 (default), 0 = never."""
+    _check(lib().mosfhet_hip_set_split_max_batch(int(max_batch)))
+
+
+def set_split_wait_limit(ticks):
+    """bound (10 ns ticks) of the pairing wait of pbs_split_kernel; 0 = every bootstrap taken alone by one workgroup (same bits)"""
+    _check(lib().mosfhet_hip_set_split_wait_limit(int(ticks)))
+
+
+def split_last_launch():
+    """(count, paired, alone) of this thread's last split launch"""
+    c, p, a = C.c_int(), C.c_int(), C.c_int()
+    _check(lib().mosfhet_hip_split_last_launch(C.byref(c), C.byref(p), C.byref(a)))
+    return c.value, p.value, a.value
+
+
 class VectorOps:
     """Handle of the digit-parallel integer callers (mosfhet_hip_vec_*): add / sub / ReLU / encrypted LUT over M independent radix-B integers"""
     def __init__(self, eng, h, bsk, torus_base):

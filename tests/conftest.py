@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "split_kernel: runs with the library's default kernel selection at N = 2048, l = 4 (two CUs per bootstrap for small batches: "
+                                       "sums per accumulator component) and compares with the oracle in that order (tests/test_gpu_parity.py: reference_product_order)")
 
 
 @pytest.fixture(scope="session")

@@ -55,6 +55,57 @@ def test_fft_and_external_product_random(oracle, ref):
         assert oracle.torus_dist(mine, ref.external_product(c, g, l, Bg)).max() < 2.0 ** 32
 
 
+def test_by_component_product_order_is_held_to_the_reference_too(oracle, ref):
+    """The oracle's second summation order (orc_set_product_order(1): the l rows of each accumulator component chained from zero, the partial sums added -- what a
+    bootstrap split over one workgroup per component computes, mosfhet_amd/csrc/bootstrap_kernels.h: pbs_split_kernel) against the reference itself, at the SAME
+    tolerances as the reference order: external products at both rings (2^32 on the ciphertext), a blind rotation and programmable bootstraps over a short key at
+    SET_1's ring (2^38 on the ciphertext: no digit has diverged yet) and at the lvl2 gadget (by PHASE: with 36 bits of digits a rounding difference of 2^28 flips a
+    last digit somewhere in every step, in this order as in the reference order -- the ciphertexts then differ by a key row and decrypt alike).  It differs from
+    the reference order by no more than either differs from the reference."""
+    rng = oracle.Rng(0xC0DE)
+    for N, l, Bg, sigma in ((1024, 2, 8, 2.98e-8), (2048, 4, 9, 2.0 ** -44)):
+        s = oracle.gen_binary_key(rng, N).reshape(1, N)
+        g = oracle.trgsw_monomial_sample(rng, 1, 7, s, l, Bg, sigma)
+        c = oracle.trlwe_sample(rng, oracle.u64(rng.words(N)), s, sigma)
+        g_dft = oracle.trgsw_to_dft(g, 1, l)
+        plain = oracle.external_product(c, g_dft, l, Bg)
+        with oracle.product_order("by_component"):
+            mine = oracle.external_product(c, g_dft, l, Bg)
+        assert (oracle.external_product(c, g_dft, l, Bg) == plain).all()          # the switch is back
+        assert oracle.torus_dist(mine, ref.external_product(c, g, l, Bg)).max() < 2.0 ** 32
+        assert oracle.torus_dist(mine, plain).max() < 2.0 ** 30
+    for N, l, Bg, sigma, by_phase in ((1024, 2, 8, 2.98e-8, False), (2048, 4, 9, 2.0 ** -44, True)):
+        n = 12
+        lwe_s = oracle.gen_binary_key(rng, n)
+        rlwe_s = oracle.gen_binary_key(rng, N).reshape(1, N)
+        bk = oracle.gen_bootstrap_key(rng, lwe_s, rlwe_s, l, Bg, sigma)
+        bk_dft = oracle.bk_to_dft(bk, 1, l)
+        h = ref.bk_new(bk, 1, l, Bg)
+        lut = oracle.u64(rng.words(4))
+        tv = oracle.trlwe_torus_packing(lut, 1, N)
+        c = oracle.tlwe_sample(rng, oracle.double2torus(0.125), lwe_s, 2.0 ** -25)
+        acc = oracle.trlwe_sample(rng, oracle.u64(rng.words(N)), rlwe_s, sigma)
+        a = np.ascontiguousarray(c[:-1])
+        out_s = rlwe_s.reshape(-1)
+
+        def close(mine, theirs, trlwe):
+            if not by_phase:
+                return oracle.torus_dist(mine, theirs).max() < 2.0 ** 38
+            ph = (lambda x: oracle.trlwe_phase(x, rlwe_s)) if trlwe else (lambda x: oracle.tlwe_phase(x, out_s))
+            return np.max(oracle.torus_dist(ph(mine), ph(theirs))) < 2.0 ** 46
+
+        plain = oracle.programmable_bootstrap(tv, c, bk_dft, l, Bg, 3, 0, 0)
+        assert close(plain, ref.programmable_bootstrap(tv, c, h, 3, 0, 0), False)        # (the reference order under the same criterion)
+        with oracle.product_order("by_component"):
+            assert close(oracle.blind_rotate(acc, a, bk_dft, l, Bg), ref.blind_rotate(acc, a, h), True)
+            got = oracle.programmable_bootstrap(tv, c, bk_dft, l, Bg, 3, 0, 0)
+            assert close(got, ref.programmable_bootstrap(tv, c, h, 3, 0, 0), False)
+            got2 = oracle.programmable_bootstrap(tv, c, bk_dft, l, Bg, 4, 2, 1)
+            assert close(got2, ref.programmable_bootstrap(tv, c, h, 4, 2, 1), False)
+        assert (got != plain).any() and close(got, plain, False)
+        ref.bk_free(h)
+
+
 def test_keyswitch_random(oracle, ref):
     rng = oracle.Rng(0x123)
     n_in, n_out, t, bb = 80, 20, 5, 2

@@ -14,11 +14,22 @@ typedef double __attribute__((ext_vector_type(2))) d2;
 constexpr uint64_t SENTINEL = 0xFFF7A5C3DEADBEEFull;
 constexpr int T = 128, M = 1024;
 
-__device__ __forceinline__ void store_dev(d2 *p, d2 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+// (s_nop 1: a store of more than 8 bytes reads its data registers late; the VALU instruction behind it must not overwrite them for two wait states, and the
+// compiler's hazard recognizer does not look into inline assembly -- without it lanes 12-15 of every 16 sent the NEXT item's half-computed real part)
+__device__ __forceinline__ void store_dev(d2 *p, d2 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ d2 load_dev(const d2 *p) {
   d2 v;
   asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
   return v;
+}
+
+// a finite double with all 52 mantissa bits in use (the first version sent small integers: their low dwords are zero and a torn item went unnoticed)
+__device__ __forceinline__ double payload(int r, int m, int t, int h, int c) {
+  uint64_t x = (uint64_t)r * 0x9E3779B97F4A7C15ull + (uint64_t)(m * 131 + t * 8 + h * 2 + c + 1) * 0xC2B2AE3D27D4EB4Full;
+  x ^= x >> 29;
+  x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 32;
+  return __builtin_bit_cast(double, (x & 0x800FFFFFFFFFFFFFull) | 0x4330000000000000ull);
 }
 
 // the lane's eight items (stride T) requested together, one wait
@@ -52,7 +63,7 @@ __global__ __launch_bounds__(256) void k_xchg(d2 *buf, int a, int b, int rounds,
     if (team != h) {
       d2 *dst = buf + ((size_t)(1 - h) * 2 + par) * M;
 #pragma unroll
-      for (int m = 0; m < 8; m++) store_dev(dst + m * T + t, d2{(double)(r * 8 + m), (double)(t + 1000 * h)});
+      for (int m = 0; m < 8; m++) store_dev(dst + m * T + t, d2{payload(r, m, t, h, 0), payload(r, m, t, h, 1)});
     } else {
       d2 *src = buf + ((size_t)h * 2 + par) * M;
       d2 v[8];
@@ -61,11 +72,25 @@ __global__ __launch_bounds__(256) void k_xchg(d2 *buf, int a, int b, int rounds,
         all = true;
         load8_dev(v, src + t);
 #pragma unroll
-        for (int m = 0; m < 8; m++) all = all && __builtin_bit_cast(uint64_t, v[m].x) != SENTINEL && __builtin_bit_cast(uint64_t, v[m].y) != SENTINEL;
+        for (int m = 0; m < 8; m++) {   // (element copies first: __builtin_bit_cast of a vector ELEMENT reads element 0 whichever is named -- clang 22)
+          const double vx = v[m].x, vy = v[m].y;
+          all = all && __builtin_bit_cast(uint64_t, vx) != SENTINEL && __builtin_bit_cast(uint64_t, vy) != SENTINEL;
+        }
       } while (!all);
 #pragma unroll
       for (int m = 0; m < 8; m++) {
-        if (v[m].x != (double)(r * 8 + m) || v[m].y != (double)(t + 1000 * (1 - h))) bad++;
+        const double vx = v[m].x, vy = v[m].y;
+        const uint64_t gx = __builtin_bit_cast(uint64_t, vx), gy = __builtin_bit_cast(uint64_t, vy);
+        const uint64_t wx = __builtin_bit_cast(uint64_t, payload(r, m, t, 1 - h, 0)), wy = __builtin_bit_cast(uint64_t, payload(r, m, t, 1 - h, 1));
+        if (gx != wx || gy != wy) {
+          bad++;
+          if (r < 2) {
+            const unsigned long long slot = atomicAdd(errors + 1, 1ull);
+            if (slot < 16) { errors[2 + 4 * slot] = ((unsigned long long)r << 32) | (h << 16) | (m << 8) | t; errors[3 + 4 * slot] = gx; errors[4 + 4 * slot] = wx; errors[5 + 4 * slot] = gy ^ wy; }
+          }
+          if ((uint32_t)gx == (uint32_t)SENTINEL || (uint32_t)gy == (uint32_t)SENTINEL) bad += 1ull << 20;          // a low dword still holds the sentinel's
+          if ((gx >> 32) == (SENTINEL >> 32) || (gy >> 32) == (SENTINEL >> 32)) bad += 1ull << 40;                  // a high dword does
+        }
         store_dev(src + m * T + t, sent);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the reset is at its coherence point before this workgroup's next send can be observed
@@ -88,8 +113,8 @@ int main() {
   const size_t words = (size_t)2 * 2 * M * 2;
   CHECK(hipMalloc(&buf, words * 8));
   CHECK(hipMalloc(&sink, 64 * 256 * 8));
-  CHECK(hipMalloc(&errors, 8));
-  CHECK(hipMemset(errors, 0, 8));
+  CHECK(hipMalloc(&errors, 8 * 80));
+  CHECK(hipMemset(errors, 0, 8 * 80));
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   const int rounds = 20000;
@@ -103,8 +128,13 @@ int main() {
       float ms = 0;
       CHECK(hipEventElapsedTime(&ms, e0, e1));
       CHECK(hipMemcpy(&h_err, errors, 8, hipMemcpyDeviceToHost));
-      printf("workgroups 0 and %d (%s), %d fma of stand-in work per step: %.2f us per step (16 KiB each way, sentinel slots), wrong words so far %llu\n", b,
-             b % 8 == 0 ? "same XCD if round-robin" : "different XCDs", work, ms * 1e3 / rounds, h_err);
+      printf("workgroups 0 and %d (%s), %d fma of stand-in work per step: %.2f us per step (16 KiB each way, sentinel slots), wrong items so far %llu (of them with a sentinel low dword %llu, high dword %llu)\n", b,
+             b % 8 == 0 ? "same XCD if round-robin" : "different XCDs", work, ms * 1e3 / rounds, h_err & 0xFFFFF, (h_err >> 20) & 0xFFFFF, h_err >> 40);
     }
+  unsigned long long rec[80];
+  CHECK(hipMemcpy(rec, errors, sizeof(rec), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 16 && i < (int)rec[1]; i++)
+    printf("  mismatch: round %llu side %llu item %llu lane %llu: got x %016llx want %016llx, y xor %016llx\n", rec[2 + 4 * i] >> 32, (rec[2 + 4 * i] >> 16) & 0xFFFF, (rec[2 + 4 * i] >> 8) & 0xFF,
+           rec[2 + 4 * i] & 0xFF, rec[3 + 4 * i], rec[4 + 4 * i], rec[5 + 4 * i]);
   return 0;
 }
