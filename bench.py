@@ -22,7 +22,9 @@ Prints ONE JSON line (rank 0) with the contract fields plus
                  (8 LUTs) and Galois-automorphism bootstrap at N = 2048, each checked by phase, each with the FP64 share of its blind rotations, the circuit
                  bootstrap's packing switches against their LDS-gather floor, and ONE GPU's share of the batch when it is split over 8 (128 inputs);
   lvl2_bootstraps : BASELINE.json configs[2] for the record (4096 programmable bootstraps at N = 2048, l = 4 on this GPU: rate, FP64-model fraction,
-                 outputs checked by phase); not part of `value`;
+                 outputs checked by phase); not part of `value`; small_batches: 1 and 128 bootstraps on two CUs each (pbs_split_kernel) against one CU each;
+  gate         : SURVEY 8(f).1 -- 4096 x (tlwe_keyswitch + functional_bootstrap) at SET_1, one call, checked by phase;
+  vector_callers : SURVEY 8(f).4 -- 256 radix-4 integers through add + ReLU + 16-entry encrypted look-up at the reference application's parameter set, decrypted and compared;
   value_regime : how `value` was launched (steps alternate over --streams HIP streams) next to roofline.kernel_ms (the launch alone, timed right
                  after the timed region) and roofline.kernel_ms_in_stream_regime (an event pair around every launch of the same alternating schedule);
   sustained    : the same step back to back for >= 2.5 s (N = 1);
@@ -60,6 +62,15 @@ def flops_per_cmux(P):
     M = N // 2
     fft = 5 * M * (M.bit_length() - 1)
     return ((k + 1) * l + (k + 1)) * fft + 8 * (k + 1) ** 2 * l * M
+
+
+def flops_per_ga_step(P):
+    """One step of the Galois-automorphism blind rotation (src/bootstrap_ga.c:39-60): an external product + trlwe_eval_automorphism's key switch of component a
+    (src/keyswitch.c:162-193: l digit polynomials forward, k + 1 inverse transforms, l (k + 1) complex multiply-adds per point), priced like flops_per_cmux."""
+    k, N, l = P["k"], P["N"], P["l"]
+    M = N // 2
+    fft = 5 * M * (M.bit_length() - 1)
+    return flops_per_cmux(P) + (l + (k + 1)) * fft + 8 * l * (k + 1) * M
 
 
 def lvl2_keys(eng, ma, host):
@@ -101,10 +112,28 @@ def lvl2_bootstrap_leg(eng, ma, host, torch, keys, B2=4096):
     err = np.abs((ph - lut[np.arange(B2) % 4]).astype(np.int64).astype(np.float64)).max()
     ms = min(eng.time_programmable_bootstrap(bsk2, d_tv2, d_ct2, 3, 3, out=out2) for _ in range(3))
     tflops = flops_per_cmux(P2) * P2["n"] * B2 / (ms * 1e-3) / 1e12
+    # small batches (what one GPU gets of configs[3] / [4] over 8): two CUs per bootstrap (pbs_split_kernel, the default up to CUs / 2) against one CU per bootstrap
+    from mosfhet_amd import engine
+    small = {}
+    for nb in (1, 128):
+        sub = out2[:nb]
+        two = min(eng.time_programmable_bootstrap(bsk2, d_tv2, d_ct2[:nb], 3, 3, out=sub) for _ in range(2))
+        try:
+            stats = engine.split_last_launch()
+        except engine.MosfhetHipError:       # (the kernel is switched off: MOSFHET_HIP_SPLIT_MAX=0)
+            stats = (nb, 0, 0)
+        ph_s = host.tlwe_phase(ma.to_numpy(sub), rk2.extracted_lwe_key().s)
+        err_s = np.abs((ph_s - lut[np.arange(nb) % 4]).astype(np.int64).astype(np.float64)).max()
+        engine.set_split_max_batch(0)
+        one = min(eng.time_programmable_bootstrap(bsk2, d_tv2, d_ct2[:nb], 3, 3, out=sub) for _ in range(2))
+        engine.set_split_max_batch(-1)
+        small["batch_%d" % nb] = {"ms_two_cus_per_bootstrap": two, "ms_one_cu_per_bootstrap": one, "taken_by_a_pair_of_workgroups": stats[1], "taken_alone": stats[2],
+                                  "max_phase_error_log2": float(np.log2(err_s + 1)), "decrypts": bool(err_s < 2.0 ** 58)}
     res = {"workload": "batch of %d programmable bootstraps, TFHEpp lvl2 n=632 N=2048 k=1 l=4 Bg=2^9 (BASELINE.json configs[2])" % B2,
            "bootstraps_per_s": B2 / (ms * 1e-3), "ms_per_batch": ms, "kernel": "mosfhet::pbs_kernel<mosfhet::Fft2048T<false, false>, 4, 9>",
            "launches_per_batch": (B2 + 1023) // 1024, "bound": "fp64_valu", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-           "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, "max_phase_error_log2": float(np.log2(err + 1)), "decrypts": bool(err < 2.0 ** 58)}
+           "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, "max_phase_error_log2": float(np.log2(err + 1)), "decrypts": bool(err < 2.0 ** 58),
+           "small_batches": small}
     return res
 
 
@@ -121,7 +150,7 @@ def composition_legs(eng, ma, host, torch, keys, batch=1024, share=8, rank=0, wo
     world > 1 (every rank calls this): the configs' own shape -- the batch of 1024 SPLIT over the GPUs (strong scaling): rank r bootstraps the contiguous slice
       shard_bounds(batch, r, world) against its own replica of the keys (same seeds), no collective on the data path; a leg's time is the max over ranks of a
       barrier-bracketed region (mosfhet_amd/shard.py), its rate batch / that time; every rank phase-checks its own slice and the worst error is reported."""
-    from mosfhet_amd import shard
+    from mosfhet_amd import shard, engine
     P2, lk2, rk2, bsk = keys
     N, l, Bg, n = P2["N"], P2["l"], P2["Bg_bit"], P2["n"]
     s, out_s = rk2.s[0], rk2.extracted_lwe_key().s
@@ -134,7 +163,7 @@ def composition_legs(eng, ma, host, torch, keys, batch=1024, share=8, rank=0, wo
     lo, hi = shard.shard_bounds(batch, rank, world)
     mine = hi - lo                       # this rank's inputs (all of them at world = 1)
 
-    def entry(name, workload, ref, units, run, check, rotations, small_run, extra=None):
+    def entry(name, workload, ref, units, run, check, rotations, small_run, extra=None, split_applies=True):
         run()
         torch.cuda.synchronize()
         err = check()
@@ -155,6 +184,11 @@ def composition_legs(eng, ma, host, torch, keys, batch=1024, share=8, rank=0, wo
         ms = timed_ms(torch, run)
         small_run()
         torch.cuda.synchronize()
+        err_small = check()                # the share's outputs (the first `small` of the buffer) come from the kernels a batch of that size takes: checked like the full batch
+        try:
+            split = engine.split_last_launch() if split_applies else None
+        except engine.MosfhetHipError:
+            split = None
         ms_small = timed_ms(torch, small_run)
         tflops = rotations * flops_rot * units / (ms * 1e-3) / 1e12
         res[name] = {"workload": workload, "reference": ref, "units": units, "ms_per_batch": ms, "units_per_s": units / (ms * 1e-3),
@@ -162,7 +196,13 @@ def composition_legs(eng, ma, host, torch, keys, batch=1024, share=8, rank=0, wo
                      "roofline": {"bound": "fp64_valu", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TFLOPS,
                                   "blind_rotations_per_unit": rotations, "note": "blind-rotation FLOP (SURVEY 8(d)) over the WHOLE composition's time"},
                      "share_of_%d" % share: {"units": units // share, "ms_per_batch": ms_small, "units_per_s": (units // share) / (ms_small * 1e-3),
-                                             "speedup_of_%d_gpus_over_1" % share: ms / ms_small}}
+                                             "max_phase_error_log2": float(np.log2(err_small + 1)), "decrypts": bool(err_small < 2.0 ** 60),
+                                             "single_gpu_time_ratio_full_over_share": ms / ms_small,
+                                             "blind_rotation_kernel": ("mosfhet::pbs_split_kernel (two CUs per bootstrap, one 16 KiB exchange per CMUX step; sums per accumulator "
+                                                                       "component: FFT-level different bits from the full batch's kernel, bit-identical to the oracle in that order)"
+                                                                       if split else "the kernels of the full batch"),
+                                             "last_split_launch": ({"bootstraps": split[0], "by_a_pair_of_workgroups": split[1], "alone": split[2]} if split else None),
+                                             "note": "ONE GPU's share when the config's batch of %d is sharded over %d GPUs, timed on this GPU alone (no other rank involved)" % (units, share)}}
         if extra:
             res[name].update(extra)
 
@@ -235,9 +275,11 @@ def composition_legs(eng, ma, host, torch, keys, batch=1024, share=8, rank=0, wo
     entry("functional_bootstrap_ga", "%d x functional_bootstrap_ga (Galois-automorphism blind rotation), N=2048 l=4 n=632, 2048 automorphism keys (256 MiB) "
           "(BASELINE.json configs[4])" % batch, "/root/reference/src/bootstrap_ga.c:62-76", batch,
           lambda: eng.functional_bootstrap_ga(bk_ga, gak, d_tv4, d_inga, 4, out=d_oga),
-          lambda: phase_err(host.tlwe_phase(ma.to_numpy(d_oga), out_s), lut4[np.arange(lo, hi) % 4]), 1,
+          lambda: phase_err(host.tlwe_phase(ma.to_numpy(d_oga), out_s), lut4[np.arange(lo, hi) % 4]), flops_per_ga_step(P2) / flops_per_cmux(P2),
           lambda: eng.functional_bootstrap_ga(bk_ga, gak, d_tv4, d_inga[:small], 4, out=d_oga[:small]),
-          {"note": "FLOP model of the plain blind rotation; the Galois form runs 1.6 x its transforms (an automorphism key switch per step)"})
+          {"flop_model": "per step: the external product (SURVEY 8(d): %d FLOP) + the automorphism key switch on component a (l forward and k + 1 inverse transforms, "
+                         "8 l (k + 1) M for the products: %d FLOP) = %.3f plain steps; src/bootstrap_ga.c:39-60, src/keyswitch.c:162-193" % (
+                             flops_per_cmux(P2), flops_per_ga_step(P2) - flops_per_cmux(P2), flops_per_ga_step(P2) / flops_per_cmux(P2))}, split_applies=False)
     bk_ga.free()
     gak.free()
     return res
@@ -351,12 +393,91 @@ def external_product_leg(eng, ma, host, P, B_ep, measured_traffic, traffic_file,
     ep_gbs = ep_bytes / (ep_ms * 1e-3) / 1e9
     flops = flops_per_cmux(P) * B_ep
     bsk4.free()
-    return {"bound": "hbm", "achieved": ep_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ep_gbs / HBM_PEAK_GBS, "traffic": measured_traffic(traffic_file, B_ep),
+    traffic = measured_traffic(traffic_file, B_ep)
+    return {"bound": "hbm", "achieved": ep_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ep_gbs / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": ("profiles/%s: rocprofv3 PMC passes of this very build (source hash matched), taken once and committed -- not measured in this run" % traffic_file
+                               if traffic is not None else None),
             "kernel": kernel_name, "kernel_ms": ep_ms, "kernel_ms_min_max": [groups[0], groups[-1]], "units_per_launch": B_ep,
             "algorithmic_bytes_per_launch": ep_bytes, "external_products_per_s": B_ep / (ep_ms * 1e-3),
             "fp64_model_tflops": flops / (ep_ms * 1e-3) / 1e12, "fp64_frac": flops / (ep_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
             "max_phase_error_log2": float(np.log2(ep_err + 1)),
             "workload": "%d x trgsw_mul_trlwe_DFT + trlwe_from_DFT at N=%d l=%d against one TRGSW_DFT (src/trgsw.c:385-423)" % (B_ep, N_, l_)}
+
+
+def gate_leg(eng, ma, host, torch, P, lk, rk, bsk, B=4096):
+    """The reference's canonical gate at SET_1: tlwe_keyswitch from the extracted key (dimension kN) back to n (src/tlwe.c:289-303), then
+    functional_bootstrap (src/bootstrap.c:200-206) -- one call, two launches (mosfhet_hip_keyswitch_functional_bootstrap_batch); B inputs resident, outputs checked by phase."""
+    out_key = rk.extracted_lwe_key()
+    ksk = eng.generate_keyswitch_key(lk.s, out_key.s, P["t"], P["base_bit"], P["lwe_sigma"], seed=21)
+    lut = np.array([host.double2torus(x) for x in (0.0625, 0.3125, -0.1875, 0.4375)], dtype=np.uint64)
+    d_tv = ma.to_device(host.torus_packing(lut, P["k"], P["N"])[None], eng.device)
+    d_in = ma.to_device(host.tlwe_samples([host.double2torus((b % 4) / 8.0) for b in range(B)], out_key), eng.device)
+    d_out = eng.empty(B, P["k"] * P["N"] + 1)
+    d_ks = eng.empty(B, P["n"] + 1)
+    run = lambda: eng.keyswitch_functional_bootstrap(ksk, bsk, d_tv, d_in, 4, out=d_out)
+    run()
+    torch.cuda.synchronize()
+    ph = host.tlwe_phase(ma.to_numpy(d_out), out_key.s)
+    err = float(np.abs((ph - lut[np.arange(B) % 4]).astype(np.int64).astype(np.float64)).max())
+    ms = timed_ms(torch, run, reps=5)
+    ks_ms = timed_ms(torch, lambda: eng.tlwe_keyswitch(ksk, d_in, out=d_ks), reps=5)
+    tflops = flops_per_cmux(P) * P["n"] * B / (ms * 1e-3) / 1e12
+    ksk.free()
+    return {"workload": "%d x (tlwe_keyswitch N=%d -> n=%d, t=%d base 2^%d; functional_bootstrap) at SET_1" % (B, P["N"], P["n"], P["t"], P["base_bit"]),
+            "reference": "/root/reference/src/tlwe.c:289-303, src/bootstrap.c:200-206", "units": B, "ms_per_batch": ms, "gates_per_s": B / (ms * 1e-3),
+            "keyswitch_ms": ks_ms, "keyswitch_share_of_time": ks_ms / ms, "max_phase_error_log2": float(np.log2(err + 1)), "decrypts": bool(err < 2.0 ** 60),
+            "roofline": {"bound": "fp64_valu", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TFLOPS,
+                         "note": "blind-rotation FLOP (SURVEY 8(d)) over the whole gate's time: the key switch counts as time, not as work"}}
+
+
+def vector_callers_leg(eng, ma, host, torch, M=256):
+    """the radix-integer callers of applications/multi-ciphertext-arith (src/integer.c:62-107, src/ml.c:4-20, src/lut.c:49-64) over M independent signed 8-bit
+    integers at the application's own parameter set (src/ufhe.c:18-20: n = 630, N = 2048, l = 6, Bg = 2^7, key switch t = 6 base 2^2, radix 4), digit-parallel: one call each
+    of add, ReLU and a 16-entry encrypted look-up (mosfhet_hip_vec_addsub / _relu / _mux_array).  Every result is decrypted and compared with the arithmetic."""
+    n, N, l, Bg, t, bb, Bt, d = 630, 2048, 6, 7, 6, 2, 4, 4
+    host.seed(SEED + 30)
+    lk = host.LweKey(n, 3.0517578125e-05)
+    rk = host.RlweKey(N, 1, 5.684341886080802e-14)
+    ex = rk.extracted_lwe_key()
+    bsk = eng.generate_bootstrap_key(rk.s[0], lk.s, l, Bg, 5.684341886080802e-14, seed=31)
+    ksk = eng.generate_keyswitch_key(lk.s, ex.s, t, bb, 3.0517578125e-05, seed=32, compressed=True)
+    pksk = eng.generate_lut_packing_key(rk.s[0], ex.s, t, bb, Bt, 5.684341886080802e-14, seed=33)
+    vec = eng.vector_ops(bsk, ksk, pksk, Bt)
+    rng = np.random.default_rng(0xD163)
+    a, b, sel = rng.integers(-128, 128, M), rng.integers(-128, 128, M), rng.integers(0, 16, M)
+    table = rng.integers(-128, 128, (M, 16))
+
+    def encrypt(values, digits):   # ufhe_encrypt_integer (src/integer.c:34-40), digit-major [digits][M][N+1]
+        v = np.asarray(values).astype(np.int64) & 0xff
+        msgs = [host.double2torus(float((int(x) >> (2 * i)) & 3) / (2 * Bt)) for i in range(digits) for x in v]
+        return ma.to_device(host.tlwe_samples(msgs, ex).reshape(digits, len(v), N + 1), eng.device)
+
+    def decrypt(ct):               # ufhe_decrypt_integer (:50-59), signed 8 bit
+        x = ma.to_numpy(ct)
+        digits, m, _ = x.shape
+        ph = host.tlwe_phase(x.reshape(-1, N + 1), ex.s).reshape(digits, m)
+        dig = np.round(ph.astype(np.float64) / 2.0 ** 64 * (2 * Bt)).astype(np.int64) % Bt
+        return (sum(dig[i] << (2 * i) for i in range(digits)) + 128) % 256 - 128
+
+    da, db, dsel = encrypt(a, d), encrypt(b, d), encrypt(sel, 2)
+    dtab = torch.stack([encrypt(table[:, j], d) for j in range(16)]).contiguous()
+    wrap = lambda x: (np.asarray(x) + 128) % 256 - 128
+    c_add, c_relu, c_lut = vec.addsub(da, db), vec.relu(da), vec.mux_array(dtab.clone(), dsel)
+    torch.cuda.synchronize()
+    ok = bool((decrypt(c_add) == wrap(a + b)).all() and (decrypt(c_relu) == np.where(a > 0, a, 0)).all() and (decrypt(c_lut) == table[np.arange(M), sel]).all())
+    tabs = [dtab.clone() for _ in range(3)]      # (the look-up consumes its table)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(3):
+        vec.addsub(da, db)
+        vec.relu(da)
+        vec.mux_array(tabs[k], dsel)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / 3
+    vec.free(); pksk.free(); ksk.free(); bsk.free()
+    return {"workload": "%d signed 8-bit radix-4 integers through add + ReLU + 16-entry encrypted look-up, one call each (n=630 N=2048 l=6 Bg=2^7)" % M,
+            "reference": "/root/reference/applications/multi-ciphertext-arith/src/integer.c:62-107, src/ml.c:4-20, src/lut.c:49-64", "units": M, "ms_per_call_sequence": ms,
+            "integers_per_s": M / (ms * 1e-3), "decrypts_to_the_arithmetic": ok}
 
 
 def usable_cores():
@@ -399,6 +520,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lvl2", action="store_true", help="skip the configs[2] leg (4096 lvl2 bootstraps, ~2 s) and with it configs[3] / [4]")
+    ap.add_argument("--no-callers", action="store_true", help="skip the gate leg (4096 x key switch + bootstrap at SET_1) and the vector_callers leg (256 radix integers: add + ReLU + LUT; ~6 s with its keys)")
     ap.add_argument("--no-configs34", action="store_true", help="skip the configs[3] / [4] legs (circuit bootstrap, FDFB, multi-value, Galois bootstrap: ~10 s; N > 1: the batches split over the ranks)")
     args = ap.parse_args()
 
@@ -603,6 +725,11 @@ def main():
             configs34 = composition_legs(eng, ma, host, torch, keys2, rank=rank, world=world, dist_device=(eng.device if backend == "nccl" else "cpu"))
         keys2[3].free()
 
+    gate = vectors = None
+    if rank == 0 and not args.no_callers:
+        gate = gate_leg(eng, ma, host, torch, P, lk, rk, bsk)
+        vectors = vector_callers_leg(eng, ma, host, torch)
+
     # one bootstrap alone (the latency kernel: one workgroup of 2l wavefronts for the ciphertext), same key, same timing method as roofline.kernel_ms
     latency_ms = eng.time_programmable_bootstrap(bsk, d_tv, d_ct[:1], 3, 5, out=d_out[:1]) if rank == 0 else None
 
@@ -645,6 +772,8 @@ def main():
                                                           "no collective on the data path" % world},
             "roofline": {"bound": "fp64_valu", "achieved": achieved_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tflops / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_source": ("profiles/latest_traffic.json: rocprofv3 PMC passes of this very build (source hash matched), taken once and committed -- not measured in this run"
+                                            if traffic is not None else None),
                          "kernel": "mosfhet::pbs_kernel<mosfhet::Fft1024, 2, 8>", "kernel_ms": kernel_ms,
                          "kernel_ms_vs_ms_per_step": kernel_ms / (1e3 * elapsed / args.steps),
                          "kernel_ms_in_stream_regime": stream_regime,
@@ -656,6 +785,8 @@ def main():
             "roofline_external_product_lvl2": ep2,
             "lvl2_bootstraps": lvl2,
             "configs_3_4": configs34,
+            "gate": gate,
+            "vector_callers": vectors,
             "sustained": sustained,
             "single_bootstrap_ms": latency_ms,
             "replicas": replicas,

@@ -359,6 +359,23 @@ void trlwe_packing_keyswitch(TRLWE out, TLWE *in, LUT_Packing_KS_Key ks_key);   
 void trlwe_save_packing_KS_key(FILE *fd, LUT_Packing_KS_Key key);                                            /* :243-262 (uncompressed rows) */
 LUT_Packing_KS_Key trlwe_load_new_packing_KS_key(FILE *fd);                                                  /* :264-296 */
 void free_trlwe_packing_ks_key(LUT_Packing_KS_Key key);                                                      /* :298-316 */
+/* ---- digit-parallel radix-integer callers on host structs (new; csrc/host/mosfhet_compat_vec.c over mosfhet_hip_vec_*, csrc/capi_vec.inc) ----
+ * M independent integers per call, each an array of TLWE digits under the extracted TRLWE key: x[m] is the `digits` member of the reference application's
+ * ufhe_integer m (applications/multi-ciphertext-arith/include/ufhe.h:18-22), the keys are the members of its ufhe_public_keyset (:12-16), torus_base its radix.
+ * Every carry step / tree level is ONE key switch + ONE packing switch + ONE bootstrap launch over all M; results decrypt to what the application's own loops give
+ * (src/integer.c:62-264, src/lut.c:6-64, src/ml.c:4-20; tests/c/vec_callers.c on tests/golden/ufhe_vectors.npz).  M <= 65535.  Synchronous, abort on error like the rest. */
+typedef struct _mosfhet_vec *mosfhet_vec;
+mosfhet_vec mosfhet_vec_new(Bootstrap_Key bootstrap_key, TLWE_KS_Key ks_key, LUT_Packing_KS_Key packing_key, int torus_base);
+void mosfhet_vec_free(mosfhet_vec v);
+void mosfhet_vec_add_integers(mosfhet_vec v, TLWE **c, TLWE **a, TLWE **b, int M, int d);                       /* c[m] = a[m] + b[m]      (ufhe_add_integer, integer.c:109-113) */
+void mosfhet_vec_sub_integers(mosfhet_vec v, TLWE **c, TLWE **a, TLWE **b, int M, int d);                       /* c[m] = a[m] - b[m]      (ufhe_sub_integer, :136-158) */
+void mosfhet_vec_sl_add_integers(mosfhet_vec v, TLWE **c, int dc, TLWE **a, int da, int g, TLWE **b, int db, int h, bool is_signed, int M);   /* a B^g + b B^h (:79-107) */
+void mosfhet_vec_mul_integers(mosfhet_vec v, TLWE **c, int dc, TLWE **a, int da, TLWE **b, int db, bool is_signed, int M);                    /* a b (:166-203) */
+void mosfhet_vec_cmp_integers(mosfhet_vec v, TLWE *c, TLWE **a, TLWE **b, int M, int d, bool a_signed, bool b_signed);   /* c[m]: one digit, 0 / 1 / 2 for < / = / > (:217-264) */
+void mosfhet_vec_relu_integers(mosfhet_vec v, TLWE **out, TLWE **in, int M, int d);                             /* max(in, 0)              (ufhe_relu_integer, ml.c:4-20) */
+void mosfhet_vec_mux_integer_arrays(mosfhet_vec v, TLWE **out, TLWE **selector, int d_sel, int size, TLWE ***vec, int M, int d);   /* out[m] = vec[selector[m]][m] (lut.c:49-64); vec[e][m]: digits */
+void mosfhet_vec_lut_integers(mosfhet_vec v, TLWE **out, int d_out, TLWE **selector, int d_sel, uint64_t *lut, int size, int M);   /* out[m] = lut[selector[m]], cleartext table (lut.c:23-47) */
+
 /* ---- beyond the path: what the reference's own test-suite needs to link (csrc/host/mosfhet_compat_extra.c; compositions of the calls above) ---- */
 typedef struct _TRGSW_REG { TRGSW_DFT positive, negative; } *TRGSW_REG;                                      /* mosfhet.h:123-125 */
 TRGSW_REG trgsw_reg_alloc(int l, int Bg_bit, int k, int N);                                                  /* register.c:18-24 */

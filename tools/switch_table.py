@@ -4,7 +4,7 @@ tests/test_host_and_abi.py::test_switch_table_matches_the_source (a getenv("MOSF
     python tools/switch_table.py            prints the table        python tools/switch_table.py --write      rewrites docs/SWITCHES.md
 
 Columns: name; default; what it selects; the C-ABI setter that does the same at run time (if any); the test that covers more than one setting.
-None of them changes a result: every row selects between forms that are bit-identical by test.
+None of them changes a result -- every row selects between forms that are bit-identical by test -- with ONE exception, named in its row: MOSFHET_HIP_SPLIT_MAX.
 """
 import glob
 import os
@@ -19,6 +19,12 @@ SWITCHES = {
                              "`mosfhet_hip_set_team_max_batch`", "fixture `kernel_choice` (every bootstrap parity test runs with both kernels), `test_composition_batch_sizes`"),
     "MOSFHET_HIP_WIDE_TEAM_MAX": ("512", "N = 2048 (half the value at N = 4096): the same switch-over for `pbs_wide_team_kernel` / `pbs_wide_pair_kernel`; 0 = never",
                                   "`mosfhet_hip_set_wide_team_max_batch`", "`test_team_pacing_changes_timing_only`, `test_composition_batch_sizes`"),
+    "MOSFHET_HIP_SPLIT_MAX": ("-1 (CUs / 2)", "N = 2048, l = 4: batches up to this size take TWO CUs per bootstrap (`pbs_split_kernel`: one workgroup per accumulator component, one "
+                              "16 KiB exchange per CMUX step); 0 = never.  **The one switch that changes bits**: that kernel adds the rows of an external product per component "
+                              "(FFT-level rounding apart from the other kernels' order; bit-identical to the oracle's by-component order)",
+                              "`mosfhet_hip_set_split_max_batch`", "fixtures `kernel_choice` / `product_order`, tests marked `split_kernel`"),
+    "MOSFHET_HIP_SPLIT_LIMIT": ("200000", "bound (10 ns ticks: 2 ms) of the wait of a pair's first workgroup for its partner, after which it takes the bootstrap alone (same bits); "
+                                "0 = always alone (test switch)", "`mosfhet_hip_set_split_wait_limit`", "`test_split_kernel_batch_sizes_pairs_and_alone`"),
     "MOSFHET_HIP_WIDE_PAIRS": ("1", "N = 2048, even l, at most one ciphertext per CU: the latency kernel takes its rows two at a time (`pbs_wide_pair_kernel`); 0 = single rows",
                                "-", "`test_team_pacing_changes_timing_only`"),
     "MOSFHET_HIP_EP_PAIRS": ("1", "N = 2048, l = 4 external products: 0 forces the plain unit loop (`external_product_kernel` FORM 1) instead of the soaked pipelined one",
@@ -66,7 +72,8 @@ def in_source():
 def markdown():
     lines = ["# Run-time switches of libmosfhet_hip.so", "",
              "GENERATED by `tools/switch_table.py --write` and held to the source by `tests/test_host_and_abi.py::test_switch_table_matches_the_source`.",
-             "None of them changes a result: each selects between forms that are bit-identical by the test named in the last column.", "",
+             "None of them changes a result -- each selects between forms that are bit-identical by the test named in the last column -- except `MOSFHET_HIP_SPLIT_MAX` "
+             "(FFT-level different bits: see its row).", "",
              "| environment variable | default | selects | run-time setter | covered by |", "|---|---|---|---|---|"]
     for name in sorted(SWITCHES):
         lines.append("| `%s` | %s | %s | %s | %s |" % ((name,) + SWITCHES[name]))
