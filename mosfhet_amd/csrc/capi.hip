@@ -274,6 +274,10 @@ extern "C" int mosfhet_hip_ctx_sync(mosfhet_hip_ctx_t ctx, void *stream) {
   return MOSFHET_HIP_OK;
 }
 
+// Compile-time gadgets (2 x 2^8, 4 x 2^9) exist where a parameter set of the reference or of BASELINE.json runs them: N = 1024 and N = 2048.  At N = 4096 (the reference's
+// sets there have l = 1) they take the run-time-gadget instantiations -- same bits, fewer kernels (round 6 pruning: tools/kernel_table.py).
+template <class F> constexpr bool kCompileTimeGadgets = F::N != 4096;
+
 // k = 1 and N in {1024, 2048, 4096}: the tuned kernels.  Any other power-of-two ring up to 16384 and k <= 3: the general path (general_kernels.h).
 static bool general_ring(int k, int N) { return !(k == 1 && ring_ok(N)); }
 static int check_params(const char *who, int k, int N, int l, int Bg_bit, bool allow_general = false) {
@@ -509,8 +513,8 @@ static void launch_external_product(int l, int Bg_bit, hipStream_t s, const d2 *
     if (l == 4 && Bg_bit == 9) { EP_GO_F(Fft2048L, 4, 9); return; }
     if (l == 4) { EP_GO_F(Fft2048L, 4, 0); return; }   // (other even lengths: not measured)
   }
-  if (l == 2 && Bg_bit == 8 && !unbounded_2x8) EP_GO(2, 8);
-  else if (l == 4 && Bg_bit == 9) { if constexpr (!std::is_same<F, Fft2048>::value) EP_GO(4, 9); }   // (N = 2048, l = 4 left above: no instantiation here)
+  if (kCompileTimeGadgets<F> && l == 2 && Bg_bit == 8 && !unbounded_2x8) { if constexpr (kCompileTimeGadgets<F>) EP_GO(2, 8); }
+  else if (kCompileTimeGadgets<F> && l == 4 && Bg_bit == 9) { if constexpr (kCompileTimeGadgets<F> && !std::is_same<F, Fft2048>::value) EP_GO(4, 9); }   // (N = 2048, l = 4 left above: no instantiation here)
   else if (l == 1 && Bg_bit == 23) EP_GO(1, 23);
   else if (l == 1) EP_GO(1, 0);
   else if (l == 2) EP_GO(2, 0);
@@ -642,8 +646,8 @@ static int launch_pbs_f(int l, int Bg_bit, const PbsParams &p, int count, hipStr
   // Gadget bases of the reference's parameter sets get a compile-time instantiation (test/benchmark.c:53-75,
   // test/tests.c:37-62,967); anything else runs the run-time-Bg variant.  bounded: see launch_external_product -- a key view over caller-held
   // TRGSW_DFT objects (blind_rotate(tv, a, TRGSW_DFT *s, size)) takes the reducing run-time-gadget kernel.
-  if (l == 2 && Bg_bit == 8 && (bounded || F::N != 1024)) launch_pbs<F, 2, 8>(p, count, s);
-  else if (l == 4 && Bg_bit == 9) launch_pbs<F, 4, 9>(p, count, s);
+  if (kCompileTimeGadgets<F> && l == 2 && Bg_bit == 8 && (bounded || F::N != 1024)) { if constexpr (kCompileTimeGadgets<F>) launch_pbs<F, 2, 8>(p, count, s); }
+  else if (kCompileTimeGadgets<F> && l == 4 && Bg_bit == 9) { if constexpr (kCompileTimeGadgets<F>) launch_pbs<F, 4, 9>(p, count, s); }
   // 6 x 2^7 at N = 2048: the one parameter set of the reference's radix-integer application (applications/multi-ciphertext-arith/src/ufhe.c:18-20); the compile-time
   // gadget is worth 20 - 35 % on this kernel (l = 4: 17.1 against 21.7 ms per 1024 with the gadget at run time)
   else if (l == 6 && Bg_bit == 7 && F::N == 2048) { if constexpr (F::N == 2048) launch_pbs<F, 6, 7>(p, count, s); }
@@ -845,8 +849,10 @@ static int launch_wide_team_f(int l, int Bg, const PbsParams &p, int count, hipS
       if (l == 6) return launch_wide_pair<6, 0>(p, count, s);
     }
   }
-  if (l == 4 && Bg == 9) return launch_wide_team<F, 4, 9>(p, count, s);
-  if (l == 2 && Bg == 8 && (bounded || F::N != 1024)) return launch_wide_team<F, 2, 8>(p, count, s);
+  if constexpr (kCompileTimeGadgets<F>) {
+    if (l == 4 && Bg == 9) return launch_wide_team<F, 4, 9>(p, count, s);
+    if (l == 2 && Bg == 8 && (bounded || F::N != 1024)) return launch_wide_team<F, 2, 8>(p, count, s);
+  }
   if (l == 1 && Bg == 23) return launch_wide_team<F, 1, 23>(p, count, s);
   if (l == 1) return launch_wide_team<F, 1, 0>(p, count, s);
   if (l == 2) return launch_wide_team<F, 2, 0>(p, count, s);
@@ -1249,8 +1255,10 @@ static int launch_ga_f(int l, int Bg_bit, const GaParams &g, int count, hipStrea
     // The run-time-gadget instantiations spill with either transform and stay where they were.
     if (l == 4 && Bg_bit == 9) { launch_ga<Fft2048L, 4, 9>(g, count, s); HIP_TRY(hipGetLastError()); return MOSFHET_HIP_OK; }
   }
-  if (l == 2 && Bg_bit == 8) launch_ga<F, 2, 8>(g, count, s);
-  else if (l == 4 && Bg_bit == 9) launch_ga<F, 4, 9>(g, count, s);
+  if (kCompileTimeGadgets<F> && l == 2 && Bg_bit == 8) { if constexpr (kCompileTimeGadgets<F>) launch_ga<F, 2, 8>(g, count, s); }
+  else if (kCompileTimeGadgets<F> && !std::is_same<F, Fft2048>::value && l == 4 && Bg_bit == 9) {   // (N = 2048: left above with the LDS-twiddle transform)
+    if constexpr (kCompileTimeGadgets<F> && !std::is_same<F, Fft2048>::value) launch_ga<F, 4, 9>(g, count, s);
+  }
   else if (l == 1) launch_ga<F, 1, 0>(g, count, s);
   else if (l == 2) launch_ga<F, 2, 0>(g, count, s);
   else if (l == 3) launch_ga<F, 3, 0>(g, count, s);

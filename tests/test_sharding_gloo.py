@@ -80,5 +80,6 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                        timeout=600, env=env, cwd=root)
     assert r.returncode != 0
-    assert r.stderr.count("bench.py needs a GPU") == 2, r.stderr[-2000:]
+    # (the launcher ends the other rank as soon as the first has failed: one or two of the messages, and the launcher's own failure report)
+    assert 1 <= r.stderr.count("bench.py needs a GPU") <= 2 and "torch.distributed.elastic" in r.stderr, r.stderr[-2000:]
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
