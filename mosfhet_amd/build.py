@@ -73,8 +73,11 @@ def _check_listing(objdir, src):
     sys.path.insert(0, os.path.join(HERE, "..", "tools"))
     import check_lds_barriers
     stem = os.path.join(objdir, os.path.splitext(src)[0])
-    listing = stem + "-hip-amdgcn-amd-amdhsa-gfx950.s"
-    with open(listing) as fh:
+    found = glob.glob(stem + "-hip-*gfx950*.s")
+    if len(found) != 1:
+        raise RuntimeError("the gfx950 device listing of %s (-save-temps=obj) was not found next to the object (%s-hip-*gfx950*.s matched %d files): the LDS-barrier check "
+                           "of the build cannot run -- MOSFHET_HIPCC_EXTRA must not add or change --offload-arch" % (src, stem, len(found)))
+    with open(found[0]) as fh:
         text = fh.read()
     bad = check_lds_barriers.check(text)
     with open(os.path.join(objdir, "lds_barrier_check.txt"), "w") as fh:

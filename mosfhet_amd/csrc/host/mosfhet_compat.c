@@ -1305,10 +1305,14 @@ TLWE_KS_Key tlwe_new_KS_key(TLWE_Key out_key, TLWE_Key in_key, int t, int base_b
   const size_t rows = (size_t)in_key->n * t * ((1 << base_bit) - 1), words = rows * ((size_t)out_key->n + 1);
   Torus *flat = (Torus *)mc_xmalloc(sizeof(Torus) * words);
   mosfhet_hip_ksk_t dev = NULL;
-  if (mosfhet_hip_tlwe_ksk_generate((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, out_key->s, out_key->n, in_key->s, in_key->n, t, base_bit, out_key->sigma, mc_rnd64(), 0) == 0) {
+  /* (noise: the device generators' ChaCha key is drawn from this layer's seedable generator at engine start-up and again by mosfhet_seed -- csprng.c -- so the table
+   * is reproducible under mosfhet_seed like everything else) */
+  const int rc = mosfhet_hip_tlwe_ksk_generate((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, out_key->s, out_key->n, in_key->s, in_key->n, t, base_bit, out_key->sigma, mc_rnd64(), 0);
+  if (rc == 0) {
     if (mosfhet_hip_ksk_export_rows(dev, 0, rows, flat)) mc_die("tlwe_new_KS_key (read back)");
     return tlwe_ks_wrap_dev(flat, in_key->n, out_key->n, t, base_bit, "tlwe_new_KS_key", dev);
   }
+  if (rc != MOSFHET_HIP_EINVAL) mc_die("tlwe_new_KS_key (device generation)");   /* only parameters the device generator does not take fall back to host encryption */
   mosfhet_gen_tlwe_ks_key_flat(flat, out_key, in_key, t, base_bit);
   return tlwe_ks_wrap(flat, in_key->n, out_key->n, t, base_bit, "tlwe_new_KS_key");
 }

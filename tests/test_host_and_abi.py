@@ -165,6 +165,11 @@ def test_no_lds_reads_emitted_behind_a_workgroup_barrier():
                              "\tds_read_b128 v[2:5], v6", "\ts_endpgm"])
     good_listing = bad_listing.replace("\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n", "").replace("\tds_read_b128 v[2:5], v6\n", "\tds_read_b128 v[2:5], v6\n\ts_barrier\n")
     assert len(chk.check(bad_listing)) == 1 and chk.check(good_listing) == []
+    # the two-wavefront exchanges (ds_write ; s_barrier ; ds_read ; s_barrier -- ADVICE round 5): reads moved behind the barrier that frees the buffer leave LDS writes followed
+    # by two barriers with no read in between
+    cross_bad = "\n".join(["_Z1kv:", "\tds_write_b128 v1, v[2:5]", "\ts_barrier", "\ts_barrier", "\ts_cbranch_scc1 .LBB0_3", ".LBB0_3:", "\tds_read_b128 v[2:5], v1", "\ts_endpgm"])
+    cross_good = "\n".join(["_Z1kv:", "\tds_write_b128 v1, v[2:5]", "\ts_barrier", "\tds_read_b128 v[2:5], v1", "\ts_barrier", "\ts_barrier", "\ts_endpgm"])
+    assert len(chk.check(cross_bad)) == 1 and chk.check(cross_good) == []
     assert chk.build_and_check() == []
     # the minimal reproducer (tools/spill_hazard/minimal_sink_past_barrier.hip): the form with workgroup_sync()'s clobbers must be clean; whether the raw form still shows
     # the reordering is a property of the toolchain and is only reported (today, ROCm 7.2.0: it does)
