@@ -1,9 +1,9 @@
 #!/bin/bash
 # tools/collect_profiles.sh [tag]: copy what tools/profile_r04.sh left under gpurun_out/ into profiles/ (summaries, the kernel-stats table each summary names,
 # the three measured-traffic files bench.py reads).  Run here after the gpurun call that profiled THIS build (the traffic files carry the library's source hash).
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd "$(dirname "$0")/.."
-for pair in pbs:pbs ep:ep ep2:ep_lvl2 lvl2:lvl2 ks:ks cb:cb unf:unf; do
+for pair in pbs:pbs ep:ep ep2:ep_lvl2 lvl2:lvl2 ks:ks cb:cb unf:unf split:split; do
   src=${pair%%:*}; dst=${pair##*:}
   d=gpurun_out/prof_${TAG}_$src
   [ -f $d/summary.txt ] || { echo "no $d/summary.txt"; continue; }
