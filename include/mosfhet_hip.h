@@ -334,7 +334,7 @@ int mosfhet_hip_tlwe_ksk_generate(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t *out,
 int mosfhet_hip_set_team_max_batch(int max_batch);
 /* the same switch-over for N = 2048 and, at half the value, N = 4096 (one workgroup of two transform teams per ciphertext; default 512, MOSFHET_HIP_WIDE_TEAM_MAX; 0 disables) */
 int mosfhet_hip_set_wide_team_max_batch(int max_batch);
-/* N = 2048, l = 4 (the TFHEpp lvl2 set of BASELINE.json configs[2..4]): batches of at most `max_batch` bootstraps take TWO CUs each (pbs_split_kernel: one workgroup per
+/* N = 2048, l = 2, 4 or 6 (l = 4: the TFHEpp lvl2 set of BASELINE.json configs[2..4]; l = 6: the radix-integer application's): batches of at most `max_batch` bootstraps take TWO CUs each (pbs_split_kernel: one workgroup per
  * accumulator component, one 16 KiB exchange per CMUX step) -- the share one GPU gets when a config's batch is sharded over eight leaves half its CUs idle otherwise.
  * -1 = half the device's CUs (default, MOSFHET_HIP_SPLIT_MAX), 0 = never.  The ONE selection that changes bits: that kernel adds the external product's rows per
  * accumulator component and then the two partial sums (src/trgsw.c:393-419 is one chain over all rows); the results differ from every other kernel's by FFT-level

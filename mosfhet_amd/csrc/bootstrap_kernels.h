@@ -917,7 +917,9 @@ __device__ __forceinline__ void split_load8(d2 (&v)[8], const d2 *p) {
 
 template <class F, int L, int BG>
 __global__ __launch_bounds__(2 * F::THREADS) void pbs_split_kernel(PbsParams p, SplitParams sp) {
-  static_assert(F::kForward2 && F::kLtw && L == 4 && F::THREADS == 128, "one double phase of pbs_wide_pair_kernel = the l = 4 rows of one accumulator component");
+  static_assert(F::kForward2 && F::kLtw && L % 2 == 0 && L >= 2 && L <= 6 && F::THREADS == 128,
+                "the l rows of one accumulator component: l / 4 double phases of pbs_wide_pair_kernel (two pipelined rows per team) and, for l = 2 and 6, one row per team");
+  constexpr int QUADS = L / 4, TAIL = L % 4;   // TAIL = 2: the last two levels go one row per team
   constexpr int N = F::N, M = F::M, T = F::THREADS, LOG2N2 = F::LOGM + 2, WG = 2 * T;
   constexpr bool kReduce = !(BG > 0 && kCeilLog2<2 * L>::value + (F::LOGM + 1) + BG - 1 + 63 < 83);   // see pbs_kernel
   extern __shared__ __attribute__((aligned(16))) unsigned char wide_lds[];
@@ -987,7 +989,6 @@ __global__ __launch_bounds__(2 * F::THREADS) void pbs_split_kernel(PbsParams p, 
   const size_t row_sz = (size_t)2 * L * 2 * M;
   const uint32_t mask = (1u << Bg_bit) - 1;
   const int half = 1 << (Bg_bit - 1);
-  const int sx = 64 - (team + 1) * Bg_bit, sy = 64 - (team + 3) * Bg_bit;   // this team's levels: team (x) and team + 2 (y) of the component
   int par = 0;
   for (int i = 0; i < p.n; i++) {
     const int abar = (int)modswitch<LOG2N2>(pbs_pre(ct[i], p, LOG2N2));
@@ -998,17 +999,20 @@ __global__ __launch_bounds__(2 * F::THREADS) void pbs_split_kernel(PbsParams p, 
     double s_re[8], s_im[8];   // this team's output component: sum of the components' partial sums, component 0's first
 #pragma unroll 1
     for (int dp = dp_lo; dp < dp_hi; dp++) {
-      d2 kk[4][8];   // this team's output component of the four key rows of input component dp
-#pragma unroll
-      for (int r = 0; r < 4; r++)
-#pragma unroll
-        for (int m = 0; m < 8; m++) kk[r][m] = bkrow[(size_t)(4 * dp + r) * (2 * M) + (size_t)team * M + m * T + t];
+      const uint64_t *accx = acc + (size_t)dp * N;
+      const d2 *__restrict__ rows = bkrow + (size_t)(dp * L) * (2 * M) + (size_t)team * M + t;   // rows dp L .. dp L + L - 1, this team's output component
       double o_re[8], o_im[8];
 #pragma unroll
       for (int m = 0; m < 8; m++) { o_re[m] = 0.0; o_im[m] = 0.0; }
-      double xr[8], xi[8], yr[8], yi[8];
-      {
-        const uint64_t *accx = acc + (size_t)dp * N;
+#pragma unroll
+      for (int q = 0; q < QUADS; q++) {   // levels 4 q .. 4 q + 3: team w transforms levels 4 q + w (x) and 4 q + 2 + w (y), pipelined
+        d2 kk[4][8];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+          for (int m = 0; m < 8; m++) kk[r][m] = rows[(size_t)(4 * q + r) * (2 * M) + m * T];
+        const int sx = 64 - (4 * q + team + 1) * Bg_bit, sy = 64 - (4 * q + team + 3) * Bg_bit;
+        double xr[8], xi[8], yr[8], yi[8];
 #pragma unroll
         for (int m = 0; m < 8; m++) {
           const int j = m * T + t;
@@ -1019,36 +1023,69 @@ __global__ __launch_bounds__(2 * F::THREADS) void pbs_split_kernel(PbsParams p, 
           yr[m] = (double)((int)((uint32_t)(d_lo >> sy) & mask) - half);
           yi[m] = (double)((int)((uint32_t)(d_hi >> sy) & mask) - half);
         }
-      }
-      fft.forward2_head(xr, xi, yr, yi, xch, t);
-      fft.pass_d_fwd(xr, xi);
-      d2 *hx = hand + (size_t)team * M, *hy = hand + (size_t)(2 + team) * M;   // hand-over buffer r holds row 4 dp + r
+        fft.forward2_head(xr, xi, yr, yi, xch, t);
+        fft.pass_d_fwd(xr, xi);
+        d2 *hx = hand + (size_t)team * M, *hy = hand + (size_t)(2 + team) * M;   // hand-over buffer r holds level 4 q + r
 #pragma unroll
-      for (int m = 0; m < 8; m++) hx[m * T + t] = d2{xr[m], xi[m]};
-      fft.forward2_fetch(yr, yi, xch, t);
-      fft.pass_d_fwd(yr, yi);
-      F::forward2_done();   // (a workgroup barrier: both teams' x rows are handed over)
+        for (int m = 0; m < 8; m++) hx[m * T + t] = d2{xr[m], xi[m]};
+        fft.forward2_fetch(yr, yi, xch, t);
+        fft.pass_d_fwd(yr, yi);
+        F::forward2_done();   // (a workgroup barrier: both teams' x rows are handed over)
 #pragma unroll
-      for (int m = 0; m < 8; m++) hy[m * T + t] = d2{yr[m], yi[m]};
+        for (int m = 0; m < 8; m++) hy[m * T + t] = d2{yr[m], yi[m]};
 #pragma unroll
-      for (int r = 0; r < 2; r++) {   // fma chain over the component's rows in order: the x rows (levels 0, 1) while the y rows land
-        const d2 *__restrict__ dr = hand + (size_t)r * M;
+        for (int r = 0; r < 2; r++) {   // fma chain over the component's rows in order: the x rows while the y rows land
+          const d2 *__restrict__ dr = hand + (size_t)r * M;
 #pragma unroll
-        for (int m = 0; m < 8; m++) {
-          const d2 d = dr[m * T + t], k = kk[r][m];
-          o_re[m] = __builtin_fma(-d.y, k.y, __builtin_fma(d.x, k.x, o_re[m]));
-          o_im[m] = __builtin_fma(d.y, k.x, __builtin_fma(d.x, k.y, o_im[m]));
+          for (int m = 0; m < 8; m++) {
+            const d2 d = dr[m * T + t], k = kk[r][m];
+            o_re[m] = __builtin_fma(-d.y, k.y, __builtin_fma(d.x, k.x, o_re[m]));
+            o_im[m] = __builtin_fma(d.y, k.x, __builtin_fma(d.x, k.y, o_im[m]));
+          }
         }
-      }
-      workgroup_sync();
+        workgroup_sync();
 #pragma unroll
-      for (int r = 2; r < 4; r++) {
-        const d2 *__restrict__ dr = hand + (size_t)r * M;
+        for (int r = 2; r < 4; r++) {
+          const d2 *__restrict__ dr = hand + (size_t)r * M;
+#pragma unroll
+          for (int m = 0; m < 8; m++) {
+            const d2 d = dr[m * T + t], k = kk[r][m];
+            o_re[m] = __builtin_fma(-d.y, k.y, __builtin_fma(d.x, k.x, o_re[m]));
+            o_im[m] = __builtin_fma(d.y, k.x, __builtin_fma(d.x, k.y, o_im[m]));
+          }
+        }
+        if (q + 1 < QUADS || TAIL) workgroup_sync();   // the hand-over buffers are consumed (the last phase's barrier stands behind the sum below)
+      }
+      if constexpr (TAIL == 2) {   // levels L - 2, L - 1: one row per team
+        d2 kk[2][8];
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+          for (int m = 0; m < 8; m++) kk[r][m] = rows[(size_t)(L - 2 + r) * (2 * M) + m * T];
+        const int sz = 64 - (L - 2 + team + 1) * Bg_bit;
+        double zr[8], zi[8];
 #pragma unroll
         for (int m = 0; m < 8; m++) {
-          const d2 d = dr[m * T + t], k = kk[r][m];
-          o_re[m] = __builtin_fma(-d.y, k.y, __builtin_fma(d.x, k.x, o_re[m]));
-          o_im[m] = __builtin_fma(d.y, k.x, __builtin_fma(d.x, k.y, o_im[m]));
+          const int j = m * T + t;
+          const uint64_t d_lo = rot_coeff<N>(accx, j, a_lo, flip) - accx[j] + off;
+          const uint64_t d_hi = rot_coeff<N>(accx, j + M, a_lo, flip) - accx[j + M] + off;
+          zr[m] = (double)((int)((uint32_t)(d_lo >> sz) & mask) - half);
+          zi[m] = (double)((int)((uint32_t)(d_hi >> sz) & mask) - half);
+        }
+        fft.forward(zr, zi, xch, t);
+        d2 *hz = hand + (size_t)team * M;
+#pragma unroll
+        for (int m = 0; m < 8; m++) hz[m * T + t] = d2{zr[m], zi[m]};
+        workgroup_sync();
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+          const d2 *__restrict__ dr = hand + (size_t)r * M;
+#pragma unroll
+          for (int m = 0; m < 8; m++) {
+            const d2 d = dr[m * T + t], k = kk[r][m];
+            o_re[m] = __builtin_fma(-d.y, k.y, __builtin_fma(d.x, k.x, o_re[m]));
+            o_im[m] = __builtin_fma(d.y, k.x, __builtin_fma(d.x, k.y, o_im[m]));
+          }
         }
       }
       if (dp == dp_lo) {

@@ -722,7 +722,7 @@ static int launch_wide_pair(const PbsParams &p, int count, hipStream_t s) {
   return MOSFHET_HIP_OK;
 }
 
-// ---- one bootstrap on two workgroups (pbs_split_kernel): N = 2048, l = 4, batches of at most half the CUs ----
+// ---- one bootstrap on two workgroups (pbs_split_kernel): N = 2048, l = 2, 4, 6, batches of at most half the CUs ----
 // MOSFHET_HIP_SPLIT_MAX: largest batch that takes it (-1 = CUs / 2, the default; 0 = never).  The ONE switch of this library that changes bits: the split kernel sums
 // the external product per accumulator component (see the kernel), within FFT rounding of every other kernel's order.
 static std::atomic<int> g_split_max{-2};
@@ -835,10 +835,13 @@ extern "C" int mosfhet_hip_split_last_launch(int *count, int *paired, int *alone
 template <class F>
 static int launch_wide_team_f(int l, int Bg, const PbsParams &p, int count, hipStream_t s, bool bounded) {
   if constexpr (F::N == 2048) {
-    // at most half the CUs' worth of ciphertexts at l = 4: two CUs per bootstrap (pbs_split_kernel)
-    if (l == 4 && count <= split_max_batch()) {
+    // at most half the CUs' worth of ciphertexts, even gadget lengths up to 6: two CUs per bootstrap (pbs_split_kernel)
+    if ((l == 2 || l == 4 || l == 6) && count <= split_max_batch()) {
       bool taken = false;
-      const int rc = Bg == 9 ? launch_split<4, 9>(p, count, s, &taken) : launch_split<4, 0>(p, count, s, &taken);
+      int rc;
+      if (l == 4) rc = Bg == 9 ? launch_split<4, 9>(p, count, s, &taken) : launch_split<4, 0>(p, count, s, &taken);
+      else if (l == 6) rc = Bg == 7 ? launch_split<6, 7>(p, count, s, &taken) : launch_split<6, 0>(p, count, s, &taken);   // 6 x 2^7: the radix-integer application's set
+      else rc = launch_split<2, 0>(p, count, s, &taken);
       if (rc != MOSFHET_HIP_OK || taken) return rc;
     }
     // one workgroup per CU (137 KiB of LDS each): up to as many ciphertexts as the device has CUs; beyond that pbs_wide_team_kernel runs two workgroups per CU

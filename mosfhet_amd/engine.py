@@ -729,7 +729,7 @@ def set_wide_team_max_batch(max_batch):
 
 
 def set_split_max_batch(max_batch):
-    """N = 2048, l = 4: batches up to this size take two CUs per bootstrap (pbs_split_kernel; sums per accumulator component: FFT-level different bits). -1 = CUs / 2 (default), 0 = never."""
+    """N = 2048, l = 2, 4, 6: batches up to this size take two CUs per bootstrap (pbs_split_kernel; sums per accumulator component: FFT-level different bits). -1 = CUs / 2 (default), 0 = never."""
     _check(lib().mosfhet_hip_set_split_max_batch(int(max_batch)))
 
 

@@ -19,7 +19,7 @@ SWITCHES = {
                              "`mosfhet_hip_set_team_max_batch`", "fixture `kernel_choice` (every bootstrap parity test runs with both kernels), `test_composition_batch_sizes`"),
     "MOSFHET_HIP_WIDE_TEAM_MAX": ("512", "N = 2048 (half the value at N = 4096): the same switch-over for `pbs_wide_team_kernel` / `pbs_wide_pair_kernel`; 0 = never",
                                   "`mosfhet_hip_set_wide_team_max_batch`", "`test_team_pacing_changes_timing_only`, `test_composition_batch_sizes`"),
-    "MOSFHET_HIP_SPLIT_MAX": ("-1 (CUs / 2)", "N = 2048, l = 4: batches up to this size take TWO CUs per bootstrap (`pbs_split_kernel`: one workgroup per accumulator component, one "
+    "MOSFHET_HIP_SPLIT_MAX": ("-1 (CUs / 2)", "N = 2048, l = 2, 4, 6: batches up to this size take TWO CUs per bootstrap (`pbs_split_kernel`: one workgroup per accumulator component, one "
                               "16 KiB exchange per CMUX step); 0 = never.  **The one switch that changes bits**: that kernel adds the rows of an external product per component "
                               "(FFT-level rounding apart from the other kernels' order; bit-identical to the oracle's by-component order)",
                               "`mosfhet_hip_set_split_max_batch`", "fixtures `kernel_choice` / `product_order`, tests marked `split_kernel`"),
