@@ -198,7 +198,7 @@ def composition_legs(eng, ma, host, torch, keys, batch=1024, share=8, rank=0, wo
                      "share_of_%d" % share: {"units": units // share, "ms_per_batch": ms_small, "units_per_s": (units // share) / (ms_small * 1e-3),
                                              "max_phase_error_log2": float(np.log2(err_small + 1)), "decrypts": bool(err_small < 2.0 ** 60),
                                              "single_gpu_time_ratio_full_over_share": ms / ms_small,
-                                             "blind_rotation_kernel": ("mosfhet::pbs_split_kernel (two CUs per bootstrap, one 16 KiB exchange per CMUX step; sums per accumulator "
+                                             "blind_rotation_kernel": ("mosfhet::pbs_split_kernel / pbs_ga_split_kernel (two CUs per bootstrap, one 16 KiB exchange per CMUX step -- two for the Galois form; sums per accumulator "
                                                                        "component: FFT-level different bits from the full batch's kernel, bit-identical to the oracle in that order)"
                                                                        if split else "the kernels of the full batch"),
                                              "last_split_launch": ({"bootstraps": split[0], "by_a_pair_of_workgroups": split[1], "alone": split[2]} if split else None),
@@ -279,7 +279,7 @@ def composition_legs(eng, ma, host, torch, keys, batch=1024, share=8, rank=0, wo
           lambda: eng.functional_bootstrap_ga(bk_ga, gak, d_tv4, d_inga[:small], 4, out=d_oga[:small]),
           {"flop_model": "per step: the external product (SURVEY 8(d): %d FLOP) + the automorphism key switch on component a (l forward and k + 1 inverse transforms, "
                          "8 l (k + 1) M for the products: %d FLOP) = %.3f plain steps; src/bootstrap_ga.c:39-60, src/keyswitch.c:162-193" % (
-                             flops_per_cmux(P2), flops_per_ga_step(P2) - flops_per_cmux(P2), flops_per_ga_step(P2) / flops_per_cmux(P2))}, split_applies=False)
+                             flops_per_cmux(P2), flops_per_ga_step(P2) - flops_per_cmux(P2), flops_per_ga_step(P2) / flops_per_cmux(P2))})
     bk_ga.free()
     gak.free()
     return res

@@ -1547,6 +1547,288 @@ __global__ __launch_bounds__(2 * F::THREADS) void pbs_ga_wide_kernel(GaParams g,
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// pbs_ga_split_kernel: the Galois-automorphism bootstrap on TWO workgroups, like pbs_split_kernel (which see: pairing, sentinel slots, the take-it-alone fall-back).
+// Workgroup 0 keeps accumulator component a, workgroup 1 component b.  Per step (src/bootstrap_ga.c:48-52):
+//   * acc <- BK_i (.) acc: each workgroup decomposes ITS component (l = 4 rows, the double phase of pbs_wide_pair_kernel), multiplies into both output components,
+//     sends the partial sum it does not keep, adds its partner's, inverse-transforms and REPLACES its component -- the per-component summation order of
+//     pbs_split_kernel (oracle: orc_set_product_order(1); orc_blind_rotate_ga goes through the same external product);
+//   * acc <- Auto_gen(acc): each workgroup permutes its own component; the key switch of the permuted a (src/keyswitch.c:162-193: l digit polynomials against the
+//     key's l rows, ONE chain -- the reference's order, nothing to split) runs on workgroup 0, which has a: team 0 gets -as(a) for its own component, team 1's sum
+//     goes to workgroup 1 (a second slot set), whose team 1 inverse-transforms it and subtracts it from the permuted b.
+// Two exchanges per step; a step is two forward pairs and two inverse transforms deep instead of the three forward phases and two inverse pairs of one CU.
+// ------------------------------------------------------------------------------------------------------------
+template <class F, int L, int BG>
+__global__ __launch_bounds__(2 * F::THREADS) void pbs_ga_split_kernel(GaParams g, SplitParams sp) {
+  static_assert(F::kForward2 && F::kLtw && L == 4 && F::THREADS == 128, "one double phase = the l = 4 rows of a component / of an automorphism key");
+  constexpr int N = F::N, M = F::M, T = F::THREADS, LOG2N2 = F::LOGM + 2, WG = 2 * T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char wide_lds[];
+  d2 *xch_all = reinterpret_cast<d2 *>(wide_lds);                                   // [2][F::XCH_SLOTS]
+  d2 *hand = xch_all + (size_t)2 * F::XCH_SLOTS;                                    // [4][M]
+  uint64_t *acc = reinterpret_cast<uint64_t *>(hand + (size_t)4 * M);               // [2][N] (paired: only component h is kept up to date)
+  __shared__ int mode_s;
+  const PbsParams &p = g.p;
+  const int tid = threadIdx.x, team = __builtin_amdgcn_readfirstlane(tid / T), t = tid % T;
+  d2 *xch = xch_all + (size_t)team * F::XCH_SLOTS;
+  const int h = (int)((blockIdx.x >> 3) & 1u);
+  const size_t b = (size_t)(blockIdx.x >> 4) * 8 + (blockIdx.x & 7u);
+  if (b >= (size_t)sp.count) return;
+  if (tid == 0) {   // pairing: see pbs_split_kernel
+    unsigned int *st = sp.state + b;
+    int mode;
+    if (sp.limit <= 0) {
+      mode = h == 0 ? 1 : 2;
+    } else {
+      unsigned int seen = 0u;
+      if (__hip_atomic_compare_exchange_strong(st, &seen, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        const long long t0 = wall_clock64();
+        mode = -1;
+        while (mode < 0) {
+          if (__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2u) mode = 0;
+          else if (wall_clock64() - t0 > sp.limit) {
+            unsigned int one = 1u;
+            mode = __hip_atomic_compare_exchange_strong(st, &one, 3u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+          } else __builtin_amdgcn_s_sleep(8);
+        }
+      } else if (seen == 1u) {
+        unsigned int one = 1u;
+        mode = __hip_atomic_compare_exchange_strong(st, &one, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0 : 2;
+      } else {
+        mode = 2;
+      }
+    }
+    mode_s = mode;
+  }
+  workgroup_sync();
+  const int mode = mode_s;
+  if (mode == 2) return;
+  const bool alone = mode == 1;
+  const int dp_lo = alone ? 0 : h, dp_hi = alone ? 2 : h + 1;
+  d2 *recv_ep = sp.xbuf + ((size_t)b * 2 + (size_t)h) * 2 * M, *send_ep = sp.xbuf + ((size_t)b * 2 + (size_t)(1 - h)) * 2 * M;
+  d2 *slot_ks = sp.xbuf + (size_t)sp.count * 4 * M + (size_t)b * 2 * M;   // [2 parities][M]: workgroup 0's team 1 -> workgroup 1's team 1
+
+  const int Bg_bit = BG > 0 ? BG : p.Bg_bit;
+  F fft;
+  fft_setup(fft, p.tw, t);
+  const uint64_t *__restrict__ ct = p.in + b * (size_t)(p.n + 1);
+  if (p.skip_init) {
+    const uint64_t *src = p.out + b * (size_t)(2 * N);
+    for (int x = tid; x < 2 * N; x += WG) acc[x] = src[x];
+  } else {
+    const uint64_t *__restrict__ tv = p.tv + b * (size_t)p.tv_stride;
+    const uint32_t bbar = modswitch<LOG2N2>(ct[p.n] + p.prec_offset);
+    const int rot = (2 * N - (int)bbar) & (2 * N - 1);
+    const int a_lo = rot & (N - 1);
+    const bool flip = (rot & N) != 0;
+    for (int x = tid; x < 2 * N; x += WG) acc[x] = rot_coeff<N>(tv + (x / N) * N, x & (N - 1), a_lo, flip);
+  }
+  workgroup_sync();
+  uint64_t off = 1ull << (63 - L * Bg_bit);
+#pragma unroll
+  for (int i = 0; i < L; i++) off += 1ull << (63 - i * Bg_bit);
+  const RoundCtx scale(0x1p-64 / (double)M);
+  const size_t row_sz = (size_t)2 * L * 2 * M, ak_sz = (size_t)L * 2 * M;
+  const uint32_t dmask = (1u << Bg_bit) - 1;
+  const int half = 1 << (Bg_bit - 1);
+  const int sx = 64 - (team + 1) * Bg_bit, sy = 64 - (team + 3) * Bg_bit;   // this team's levels: team (x) and team + 2 (y)
+  const double sent = __builtin_bit_cast(double, kSplitSentinel);
+
+  // o = the chain over the four rows `rows` (this team's output component, lane offset included) of DFT(digit_level(accx)): the double phase of pbs_wide_pair_kernel
+  auto quad = [&](const uint64_t *accx, const d2 *__restrict__ rows, double (&o_re)[8], double (&o_im)[8]) {
+    d2 kk[4][8];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int m = 0; m < 8; m++) kk[r][m] = rows[(size_t)r * (2 * M) + m * T];
+#pragma unroll
+    for (int m = 0; m < 8; m++) { o_re[m] = 0.0; o_im[m] = 0.0; }
+    double xr[8], xi[8], yr[8], yi[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const uint64_t d_lo = accx[m * T + t] + off, d_hi = accx[M + m * T + t] + off;
+      xr[m] = (double)((int)((uint32_t)(d_lo >> sx) & dmask) - half);
+      xi[m] = (double)((int)((uint32_t)(d_hi >> sx) & dmask) - half);
+      yr[m] = (double)((int)((uint32_t)(d_lo >> sy) & dmask) - half);
+      yi[m] = (double)((int)((uint32_t)(d_hi >> sy) & dmask) - half);
+    }
+    fft.forward2_head(xr, xi, yr, yi, xch, t);
+    fft.pass_d_fwd(xr, xi);
+    d2 *hx = hand + (size_t)team * M, *hy = hand + (size_t)(2 + team) * M;
+#pragma unroll
+    for (int m = 0; m < 8; m++) hx[m * T + t] = d2{xr[m], xi[m]};
+    fft.forward2_fetch(yr, yi, xch, t);
+    fft.pass_d_fwd(yr, yi);
+    F::forward2_done();
+#pragma unroll
+    for (int m = 0; m < 8; m++) hy[m * T + t] = d2{yr[m], yi[m]};
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const d2 *__restrict__ dr = hand + (size_t)r * M;
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const d2 d = dr[m * T + t], k = kk[r][m];
+        o_re[m] = __builtin_fma(-d.y, k.y, __builtin_fma(d.x, k.x, o_re[m]));
+        o_im[m] = __builtin_fma(d.y, k.x, __builtin_fma(d.x, k.y, o_im[m]));
+      }
+    }
+    workgroup_sync();
+#pragma unroll
+    for (int r = 2; r < 4; r++) {
+      const d2 *__restrict__ dr = hand + (size_t)r * M;
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const d2 d = dr[m * T + t], k = kk[r][m];
+        o_re[m] = __builtin_fma(-d.y, k.y, __builtin_fma(d.x, k.x, o_re[m]));
+        o_im[m] = __builtin_fma(d.y, k.x, __builtin_fma(d.x, k.y, o_im[m]));
+      }
+    }
+    workgroup_sync();   // the hand-over buffers are consumed
+  };
+  // the lane's eight items of a slot set: wait for them, put the sentinel back
+  auto receive = [&](d2 *slot, d2 (&v)[8]) {
+    bool all;
+    do {
+      split_load8(v, slot);
+      all = true;
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const double vx = v[m].x, vy = v[m].y;
+        all = all && __builtin_bit_cast(uint64_t, vx) != kSplitSentinel && __builtin_bit_cast(uint64_t, vy) != kSplitSentinel;
+      }
+    } while (!all);
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const d2 sv = d2{sent, sent};
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(slot + m * 128), "v"(sv) : "memory");
+    }
+  };
+  int par_ep = 0, par_ks = 0;
+
+  // acc <- BK (.) acc (the product REPLACES the accumulator: src/bootstrap_ga.c:50)
+  auto external_product = [&](const d2 *__restrict__ bkrow) {
+    double s_re[8], s_im[8];
+#pragma unroll 1
+    for (int dp = dp_lo; dp < dp_hi; dp++) {
+      double o_re[8], o_im[8];
+      quad(acc + (size_t)dp * N, bkrow + (size_t)(dp * L) * (2 * M) + (size_t)team * M + t, o_re, o_im);
+      if (dp == dp_lo) {
+#pragma unroll
+        for (int m = 0; m < 8; m++) { s_re[m] = o_re[m]; s_im[m] = o_im[m]; }
+      } else {
+#pragma unroll
+        for (int m = 0; m < 8; m++) { s_re[m] = s_re[m] + o_re[m]; s_im[m] = s_im[m] + o_im[m]; }
+      }
+    }
+    bool inv = true;
+    if (!alone) {
+      if (team != h) {
+        split_store8(send_ep + (size_t)par_ep * M + t, s_re, s_im);
+        inv = false;
+      } else {
+        d2 v[8];
+        receive(recv_ep + (size_t)par_ep * M + t, v);
+#pragma unroll
+        for (int m = 0; m < 8; m++) { s_re[m] = s_re[m] + v[m].x; s_im[m] = s_im[m] + v[m].y; }
+      }
+      par_ep ^= 1;
+    }
+    if (inv) {
+      fft.inverse(s_re, s_im, xch, t);
+      uint64_t *accw = acc + (size_t)team * N;
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        accw[m * T + t] = round_mod_2_64(s_re[m], scale);
+        accw[M + m * T + t] = round_mod_2_64(s_im[m], scale);
+      }
+    } else {
+      F::transform_barriers_only();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the slots put back are at their coherence point before the barrier that precedes the next send)
+    workgroup_sync();
+  };
+
+  // acc <- Auto_gen(acc) [src/trlwe.c:775-781, src/keyswitch.c:162-193]: permute (out[(i gen) mod N] = +-in[i]), then a = -as(a), b = b - as(a)
+  auto eval_automorphism = [&](const d2 *__restrict__ entry, int gen) {
+    constexpr int PER = N / WG;
+    for (int c = dp_lo; c < dp_hi; c++) {   // the components this workgroup keeps
+      uint64_t *ac = acc + (size_t)c * N;
+      uint64_t v[PER];
+#pragma unroll
+      for (int j = 0; j < PER; j++) v[j] = ac[j * WG + tid];
+      workgroup_sync();
+#pragma unroll
+      for (int j = 0; j < PER; j++) {
+        const int i = j * WG + tid, ig = i * gen;
+        ac[ig & (N - 1)] = (ig & N) ? (0 - v[j]) : v[j];
+      }
+      workgroup_sync();
+    }
+    double o_re[8], o_im[8];
+    if (alone || h == 0) quad(acc, entry + (size_t)team * M + t, o_re, o_im);   // the key switch of the permuted a: team w's output component w
+    bool inv = alone || team == h;
+    if (!alone) {
+      if (h == 0 && team == 1) split_store8(slot_ks + (size_t)par_ks * M + t, o_re, o_im);
+      if (h == 1 && team == 1) {
+        d2 v[8];
+        receive(slot_ks + (size_t)par_ks * M + t, v);
+#pragma unroll
+        for (int m = 0; m < 8; m++) { o_re[m] = v[m].x; o_im[m] = v[m].y; }
+      }
+      par_ks ^= 1;
+    }
+    if (inv) {
+      fft.inverse(o_re, o_im, xch, t);
+      uint64_t *accw = acc + (size_t)team * N;
+      if (team == 0) {
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          accw[m * T + t] = 0 - round_mod_2_64(o_re[m], scale);
+          accw[M + m * T + t] = 0 - round_mod_2_64(o_im[m], scale);
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          accw[m * T + t] -= round_mod_2_64(o_re[m], scale);
+          accw[M + m * T + t] -= round_mod_2_64(o_im[m], scale);
+        }
+      }
+    } else {
+      F::transform_barriers_only();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    workgroup_sync();
+  };
+
+  const uint32_t mask2n = 2 * N - 1;
+  uint32_t a_cur = modswitch<LOG2N2>(ct[0]) | 1u;
+  {
+    const int gen = (int)inverse_mod_2n(a_cur, mask2n);
+    eval_automorphism(g.ak + (size_t)((gen - 1) >> 1) * ak_sz, gen);
+  }
+  for (int i = 0; i < p.n; i++) {
+    int gen;
+    if (i + 1 < p.n) {
+      const uint32_t a_next = modswitch<LOG2N2>(ct[i + 1]) | 1u;
+      gen = (int)((a_cur * inverse_mod_2n(a_next, mask2n)) & mask2n);
+      a_cur = a_next;
+    } else {
+      gen = (int)a_cur;
+    }
+    external_product(p.bk + (size_t)i * row_sz);
+    eval_automorphism(g.ak + (size_t)((gen - 1) >> 1) * ak_sz, gen);
+  }
+  const bool mine0 = alone || h == 0, mine1 = alone || h == 1;
+  if (p.extract) {
+    uint64_t *dst = p.out + b * (size_t)(N + 1);
+    if (mine0) for (int j = tid; j < N; j += WG) dst[j] = (j == 0) ? acc[0] : (0 - acc[N - j]);
+    if (mine1 && tid == 0) dst[N] = acc[N];
+  } else {
+    uint64_t *dst = p.out + b * (size_t)(2 * N);
+    for (int x = tid; x < 2 * N; x += WG)
+      if (x < N ? mine0 : mine1) dst[x] = acc[x];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // FFT-based TRLWE key switch with run-time (t, base_bit) [src/keyswitch.c:162-193] and trlwe_priv_keyswitch_2
 // [src/keyswitch.c:52-63], used by circuit_bootstrap_3 (kska: t = 20, base_bit = 2 in the reference's test).
 // One team per TRLWE sample; everything stays in registers (thread owns coefficients m*T+t and m*T+t+M).

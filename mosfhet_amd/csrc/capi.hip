@@ -780,7 +780,8 @@ static SplitSet *split_set(hipStream_t s, int count) {
   }
   if (!free_slot) return nullptr;
   const int cap = device_cus() / 2 > count ? device_cus() / 2 : count;
-  if (hipMalloc((void **)&free_slot->xbuf, (size_t)cap * 2 * 2 * 1024 * sizeof(d2)) != hipSuccess) { (void)hipGetLastError(); free_slot->xbuf = nullptr; return nullptr; }
+  // per bootstrap: [2 receivers][2 step parities][M] slots of the external product's exchange + [2 parities][M] of the Galois bootstrap's key-switch exchange
+  if (hipMalloc((void **)&free_slot->xbuf, (size_t)cap * 6 * 1024 * sizeof(d2)) != hipSuccess) { (void)hipGetLastError(); free_slot->xbuf = nullptr; return nullptr; }
   if (hipMalloc((void **)&free_slot->state, (size_t)cap * sizeof(unsigned int)) != hipSuccess) {
     (void)hipGetLastError();
     (void)hipFree(free_slot->xbuf);
@@ -814,6 +815,29 @@ static int launch_split(const PbsParams &p, int count, hipStream_t s, bool *take
   *taken = true;
   return MOSFHET_HIP_OK;
 }
+template <int LL, int BB>
+static int launch_ga_split(const GaParams &g, int count, hipStream_t s, bool *taken) {
+  using F = Fft2048L;
+  *taken = false;
+  SplitSet *set = split_set(s, count);
+  if (!set) return MOSFHET_HIP_OK;
+  constexpr size_t lds = sizeof(d2) * ((size_t)2 * F::XCH_SLOTS + (size_t)4 * F::M) + sizeof(uint64_t) * 2 * F::N;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_ga_split_kernel<F, LL, BB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const size_t words = (size_t)count * 6 * F::M * 2;
+  hipLaunchKernelGGL(split_prepare_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, reinterpret_cast<uint64_t *>(set->xbuf), words, set->state, count);
+  SplitParams sp;
+  sp.xbuf = set->xbuf;
+  sp.state = set->state;
+  sp.count = count;
+  sp.limit = split_wait_limit();
+  hipLaunchKernelGGL((pbs_ga_split_kernel<F, LL, BB>), dim3((unsigned)(16 * ((count + 7) / 8))), dim3(2 * F::THREADS), lds, s, g, sp);
+  HIP_TRY(hipGetLastError());
+  set->last_count = count;
+  t_split_last = set;
+  *taken = true;
+  return MOSFHET_HIP_OK;
+}
+
 // How the bootstraps of this host thread's LAST split launch were taken (synchronises its stream): by a pair of workgroups, or alone by the first to arrive.
 // For tests and bench.py.  EINVAL when the thread has not made one.
 extern "C" int mosfhet_hip_split_last_launch(int *count, int *paired, int *alone) {
@@ -1241,6 +1265,16 @@ static void launch_ga(const GaParams &g_in, int count, hipStream_t s) {
 
 template <class F>
 static int launch_ga_f(int l, int Bg_bit, const GaParams &g, int count, hipStream_t s) {
+  // at most half the CUs' worth of ciphertexts at N = 2048, l = 4: two CUs per bootstrap (pbs_ga_split_kernel; the external products in pbs_split_kernel's summation order)
+  if constexpr (F::N == 2048) {
+    if (g.mode == 0 && l == 4 && count <= split_max_batch()) {
+      GaParams gs = g;
+      gs.p.Bg_bit = Bg_bit;
+      bool taken = false;
+      const int rc = Bg_bit == 9 ? launch_ga_split<4, 9>(gs, count, s, &taken) : launch_ga_split<4, 0>(gs, count, s, &taken);
+      if (rc != MOSFHET_HIP_OK || taken) return rc;
+    }
+  }
   // few ciphertexts: two transform teams per ciphertext (pbs_ga_wide_kernel, bit-identical; the switch-overs of the plain bootstrap's latency kernels)
   if constexpr (F::N <= 2048) {
     if (g.mode == 0 && count <= (F::N == 1024 ? team_max_batch() : wide_team_max_batch())) {
