@@ -796,6 +796,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if world > 1 or force_dist:
+        dist.barrier()                  # (rank 0 runs a few legs of its own after the last collective: the ranks leave together)
         dist.destroy_process_group()
 
 
