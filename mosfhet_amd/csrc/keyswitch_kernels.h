@@ -246,7 +246,10 @@ inline hipError_t launch_tlwe_keyswitch_nw(const uint64_t *ksk, uint64_t *out, s
   // packing switch 7.4 -> 6.3 ms, lvl2 LWE switch 6.1 -> 5.1 ms per batch.
   constexpr int target_wgs = 6144;
   int split = (target_wgs + slices * ct_blocks - 1) / (slices * ct_blocks);
-  if (split > 16) split = 16;
+  // one or two tiles of ciphertexts (one GPU's share of a sharded batch: 128 inputs) leave each workgroup a long serial walk -- 128 input words x 4 stages at 16 splits,
+  // ~1 ms whatever the batch -- so few tiles are cut finer (64 splits: 128 lvl2 switches 1.02 -> 0.4 ms; the partial sums are integers mod 2^64: same bits)
+  const int max_split = ct_blocks <= 2 ? 64 : 16;
+  if (split > max_split) split = max_split;
   if (split > n_in / 8) split = n_in / 8;
   if (split < 1) split = 1;
   const int i_per_split = (n_in + split - 1) / split;
