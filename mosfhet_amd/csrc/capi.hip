@@ -758,9 +758,9 @@ extern "C" int mosfhet_hip_set_split_wait_limit(int ticks) {
   return MOSFHET_HIP_OK;
 }
 // Exchange slots + pairing words of the split launches of this host thread: one set per (device, stream) -- launches on one stream are ordered, launches on
-// different streams may overlap and must not share slots.  At most SPLIT_SETS streams per thread and device; a further stream takes the one-CU kernel.
+// different streams may overlap and must not share slots.  SPLIT_SETS sets per thread; a further stream takes over the least recently used one (after a device synchronisation).
 constexpr int SPLIT_SETS = 8;
-struct SplitSet { int device = -1; hipStream_t stream = nullptr; d2 *xbuf = nullptr; unsigned int *state = nullptr; int cap = 0, last_count = 0; };
+struct SplitSet { int device = -1; hipStream_t stream = nullptr; d2 *xbuf = nullptr; unsigned int *state = nullptr; int cap = 0, last_count = 0; unsigned long long used = 0; };
 struct SplitSets {
   SplitSet set[SPLIT_SETS];
   ~SplitSets() {
@@ -773,12 +773,22 @@ static thread_local SplitSet *t_split_last = nullptr;
 static SplitSet *split_set(hipStream_t s, int count) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  SplitSet *free_slot = nullptr;
+  static thread_local unsigned long long tick = 0;
+  SplitSet *free_slot = nullptr, *oldest = nullptr;
   for (SplitSet &x : t_split.set) {
-    if (x.xbuf && x.device == dev && x.stream == s && x.cap >= count) return &x;
+    if (x.xbuf && x.device == dev && x.stream == s && x.cap >= count) { x.used = ++tick; return &x; }
     if (!x.xbuf && !free_slot) free_slot = &x;
+    if (x.xbuf && x.device == dev && x.cap >= count && (!oldest || x.used < oldest->used)) oldest = &x;
   }
-  if (!free_slot) return nullptr;
+  if (!free_slot) {
+    // more streams than sets: the least recently used set of this device changes hands once everything queued on the device has finished (rare, and better than
+    // a kernel choice -- and with it the low bits -- that depends on how many streams a thread has used)
+    if (!oldest || hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    oldest->stream = s;
+    oldest->used = ++tick;
+    return oldest;
+  }
+  free_slot->used = ++tick;
   const int cap = device_cus() / 2 > count ? device_cus() / 2 : count;
   // per bootstrap: [2 receivers][2 step parities][M] slots of the external product's exchange + [2 parities][M] of the Galois bootstrap's key-switch exchange
   if (hipMalloc((void **)&free_slot->xbuf, (size_t)cap * 6 * 1024 * sizeof(d2)) != hipSuccess) { (void)hipGetLastError(); free_slot->xbuf = nullptr; return nullptr; }
