@@ -16,7 +16,13 @@ constexpr int T = 128, M = 1024;
 
 // (s_nop 1: a store of more than 8 bytes reads its data registers late; the VALU instruction behind it must not overwrite them for two wait states, and the
 // compiler's hazard recognizer does not look into inline assembly -- without it lanes 12-15 of every 16 sent the NEXT item's half-computed real part)
-__device__ __forceinline__ void store_dev(d2 *p, d2 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
+#ifndef ST_BITS
+#define ST_BITS "sc1"
+#endif
+#ifndef LD_BITS
+#define LD_BITS "sc1"
+#endif
+__device__ __forceinline__ void store_dev(d2 *p, d2 v) { asm volatile("global_store_dwordx4 %0, %1, off " ST_BITS "\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ d2 load_dev(const d2 *p) {
   d2 v;
   asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
@@ -35,14 +41,14 @@ __device__ __forceinline__ double payload(int r, int m, int t, int h, int c) {
 // the lane's eight items (stride T) requested together, one wait
 __device__ __forceinline__ void load8_dev(d2 (&v)[8], const d2 *p) {
   asm volatile(
-      "global_load_dwordx4 %0, %8, off sc1\n\t"
-      "global_load_dwordx4 %1, %8, off offset:2048 sc1\n\t"
-      "global_load_dwordx4 %2, %9, off sc1\n\t"
-      "global_load_dwordx4 %3, %9, off offset:2048 sc1\n\t"
-      "global_load_dwordx4 %4, %10, off sc1\n\t"
-      "global_load_dwordx4 %5, %10, off offset:2048 sc1\n\t"
-      "global_load_dwordx4 %6, %11, off sc1\n\t"
-      "global_load_dwordx4 %7, %11, off offset:2048 sc1\n\t"
+      "global_load_dwordx4 %0, %8, off " LD_BITS "\n\t"
+      "global_load_dwordx4 %1, %8, off offset:2048 " LD_BITS "\n\t"
+      "global_load_dwordx4 %2, %9, off " LD_BITS "\n\t"
+      "global_load_dwordx4 %3, %9, off offset:2048 " LD_BITS "\n\t"
+      "global_load_dwordx4 %4, %10, off " LD_BITS "\n\t"
+      "global_load_dwordx4 %5, %10, off offset:2048 " LD_BITS "\n\t"
+      "global_load_dwordx4 %6, %11, off " LD_BITS "\n\t"
+      "global_load_dwordx4 %7, %11, off offset:2048 " LD_BITS "\n\t"
       "s_waitcnt vmcnt(0)"
       : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
       : "v"(p), "v"(p + 2 * T), "v"(p + 4 * T), "v"(p + 6 * T)
@@ -68,7 +74,9 @@ __global__ __launch_bounds__(256) void k_xchg(d2 *buf, int a, int b, int rounds,
       d2 *src = buf + ((size_t)h * 2 + par) * M;
       d2 v[8];
       bool all;
+      int polls = 0;
       do {
+        if (++polls > 200000) { bad += 1ull << 40; break; }   // (a variant whose loads never see the partner's stores: give up, counted in the last field)
         all = true;
         load8_dev(v, src + t);
 #pragma unroll
