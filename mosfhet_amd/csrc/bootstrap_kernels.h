@@ -858,8 +858,8 @@ __global__ __launch_bounds__(2 * F::THREADS) void pbs_wide_pair_kernel(PbsParams
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// pbs_split_kernel: ONE bootstrap on TWO workgroups (two CUs), split by accumulator component -- for batches that leave half the chip idle (N = 2048, l = 4:
-// up to CUs / 2 ciphertexts, the share of configs[3] / [4] one GPU of eight gets).  Workgroup h of a pair keeps accumulator component h.  The rows h l ..
+// pbs_split_kernel: ONE bootstrap on TWO workgroups (two CUs), split by accumulator component -- for batches that leave half the chip idle (N = 2048, l = 2 / 4 / 6:
+// up to CUs / 2 ciphertexts, the share of configs[3] / [4] one GPU of eight gets; l = 4: one double phase, l = 6: a double phase and one row per team, l = 2: one row per team).  Workgroup h of a pair keeps accumulator component h.  The rows h l ..
 // h l + l - 1 of a TRGSW sample are exactly the rows that decompose component h (src/trgsw.c:393-419), so per CMUX step workgroup h
 //   * rotates and decomposes ITS component (both teams read it), runs the l forward transforms (pbs_wide_pair_kernel's double phase: team w takes rows
 //     h l + w and h l + 2 + w, pipelined, handed over through LDS) and multiplies-accumulates them against the key rows' two components, team w the output
@@ -2159,17 +2159,13 @@ __global__ __launch_bounds__(F::THREADS, 2) void external_product_kernel(const d
 // The same at N = 1024 when the whole batch shares ONE key entry (key_stride = 0): eight teams (wavefronts) per workgroup, one workgroup per CU, and
 // the 2 l rows of the entry (64 KiB at l = 2) staged ONCE into LDS next to the teams' transpose buffers (8 x 9 KiB) -- the key rows then cost
 // ds_read_b128 instead of 64 KiB of L2 traffic per unit behind the HBM loads in the wavefront's in-order memory queue.  l <= 2.
-// TEAMS / F: 8 teams with full transpose buffers (Fft1024, 64 + 72 KiB), or up to 16 with half-size ones (Fft1024H, 64 + 72 KiB at 16: four wavefronts per SIMD).
-#ifndef MOSFHET_EPL_AHEAD
-#define MOSFHET_EPL_AHEAD 2
-#endif
-template <int L, int BG, bool CMUX, int TEAMS = 8, class F = Fft1024, int AHEAD = MOSFHET_EPL_AHEAD>
-__global__ __launch_bounds__(64 * TEAMS, (TEAMS + 3) / 4) void external_product_ldskey_kernel(const d2 *__restrict__ bkrow0, const d2 *__restrict__ tw,
-                                                                       const uint64_t *__restrict__ in,
+// (More teams per CU, half-size transpose buffers and other request schedules were measured and dropped in round 6: experiments/README.md, r06_ldskey_teams_halfbuffer_ahead.patch.)
+template <int L, int BG, bool CMUX>
+__global__ __launch_bounds__(512, 2) void external_product_ldskey_kernel(const d2 *__restrict__ bkrow0, const d2 *__restrict__ tw, const uint64_t *__restrict__ in,
                                                                        uint64_t *out, int Bg_bit_rt, int count, size_t in_stride,
                                                                        const uint64_t *in0, d2 *__restrict__ out_dft) {   // out may alias in0: no __restrict__
-  constexpr int N = F::N, M = F::M, T = 64;
-  static_assert(N == 1024 && (2 * L * 2 * M + TEAMS * F::XCH_SLOTS) * 16 <= 160 * 1024, "key entry + transpose buffers must fit the CU's LDS");
+  using F = Fft1024;
+  constexpr int N = F::N, M = F::M, T = 64, TEAMS = 8;
   using D = Digits<L, BG>;
   constexpr bool kReduce = !(BG > 0 && kCeilLog2<2 * L>::value + (F::LOGM + 1) + BG - 1 + 63 < 83);
   __shared__ __attribute__((aligned(16))) d2 key[2 * L * 2 * M];
@@ -2212,9 +2208,9 @@ __global__ __launch_bounds__(64 * TEAMS, (TEAMS + 3) / 4) void external_product_
   };
   // Compile-time gadgets whose rounding bit 2^(63 - L BG) lies in the HIGH dword (L BG <= 31), no CMUX operand: the digits of a word are a function of its high
   // dword alone -- off has no bits below 2^32, so no carry crosses -- and only the high dwords are requested: the same HBM lines (every line still moves once:
-  // 8(d)'s bytes are unchanged), half the registers per component in flight.  AHEAD = 2 spends them on distance: BOTH components of the team's next unit are
+  // 8(d)'s bytes are unchanged), half the registers per component in flight.  They are spent on distance: BOTH components of the team's next unit are
   // requested while this one is computed (component a over the whole unit, component b over two thirds of it), where the 64-bit form has one third / two thirds.
-  constexpr bool kHi = AHEAD > 0 && !CMUX && D::kPacked && L * BG <= 31;
+  constexpr bool kHi = !CMUX && D::kPacked && L * BG <= 31;
   if constexpr (kHi) {
     const uint32_t off_hi = (uint32_t)(off >> 32);
     uint32_t h_lo[2][8], h_hi[2][8];
@@ -2232,7 +2228,7 @@ __global__ __launch_bounds__(64 * TEAMS, (TEAMS + 3) / 4) void external_product_
     };
     if (first < (size_t)count) {
       request_hi(first, 0);
-      if (AHEAD == 2) request_hi(first, 1);
+      request_hi(first, 1);
     }
     for (size_t u = first; u < (size_t)count; u += stride) {
       double o_re[2][8], o_im[2][8];
@@ -2242,10 +2238,10 @@ __global__ __launch_bounds__(64 * TEAMS, (TEAMS + 3) / 4) void external_product_
         for (int m = 0; m < 8; m++) { o_re[c][m] = 0.0; o_im[c][m] = 0.0; }
       const bool more = u + stride < (size_t)count;
       pack_hi(0);
-      if (AHEAD == 2) { if (more) request_hi(u + stride, 0); } else request_hi(u, 1);
+      if (more) request_hi(u + stride, 0);
       cmux_rows<F, L, BG, true>(w_lo, w_hi, ext, 0, o_re, o_im, xch, fft, key, Bg_bit, t);
       pack_hi(1);
-      if (AHEAD == 2) { if (more) request_hi(u + stride, 1); } else if (more) request_hi(u + stride, 0);
+      if (more) request_hi(u + stride, 1);
       cmux_rows<F, L, BG, true>(w_lo, w_hi, ext, 1, o_re, o_im, xch, fft, key, Bg_bit, t);
       if (out_dft) {
         d2 *dd = out_dft + u * 2 * M;

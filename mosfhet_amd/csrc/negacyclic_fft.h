@@ -246,63 +246,6 @@ struct Fft1024 {
   }
 };
 
-// The same transform through a HALF-SIZE transpose buffer (576 doubles = 4.5 KiB per wavefront): every exchange moves the real parts, then the imaginary
-// parts, through the same slot maps f1 / f2 with 8-byte elements (ds_write_b64 / ds_read_b64: a half-wave's 32 slots fall into 32 different bank pairs
-// under both maps on both sides, like the 16-byte form).  DS operations of a wavefront execute in order, so the imaginary parts' writes may be queued right
-// behind the real parts' reads of the same slots.  Same butterflies, same values: bit-identical to Fft1024.  For kernels that trade transpose space for
-// wavefronts per CU (external_product_ldskey_kernel with 16 teams next to the 64 KiB key entry).
-struct Fft1024H : Fft1024 {
-  static constexpr int XCH_SLOTS = 288;   // in 16-byte units, like Fft1024::XCH_SLOTS
-  template <int WS, int RS>
-  static __device__ __forceinline__ void exchange(double (&re)[8], double (&im)[8], double *wp, const double *rp) {
-#pragma unroll
-    for (int m = 0; m < 8; m++) wp[WS * m] = re[m];
-    wave_lds_sync();
-#pragma unroll
-    for (int m = 0; m < 8; m++) re[m] = rp[RS * m];
-    wave_lds_sync();
-#pragma unroll
-    for (int m = 0; m < 8; m++) wp[WS * m] = im[m];
-    wave_lds_sync();
-#pragma unroll
-    for (int m = 0; m < 8; m++) im[m] = rp[RS * m];
-    wave_lds_sync();
-  }
-  __device__ __forceinline__ void forward_head(double (&re)[8], double (&im)[8], d2 *xch, int lane) const {
-    double *x = reinterpret_cast<double *>(xch), *pa = x + lane, *pb = x + 72 * (lane >> 3) + (lane & 7), *pc = x + 9 * lane;
-    pass_fwd(re, im, wa);
-    exchange<72, 8>(re, im, pa, pb);
-    pass_fwd(re, im, wb);
-    exchange<9, 1>(re, im, pb, pc);
-  }
-  __device__ __forceinline__ void forward(double (&re)[8], double (&im)[8], d2 *xch, int lane) const {
-    forward_head(re, im, xch, lane);
-    forward_tail(re, im);
-  }
-  __device__ __forceinline__ void inverse(double (&re)[8], double (&im)[8], d2 *xch, int lane) const {
-    double *x = reinterpret_cast<double *>(xch), *pa = x + lane, *pb = x + 72 * (lane >> 3) + (lane & 7), *pc = x + 9 * lane;
-    pass_inv(re, im, wc);
-    exchange<1, 9>(re, im, pc, pb);
-    pass_inv(re, im, wb);
-    exchange<8, 72>(re, im, pb, pa);
-    pass_inv(re, im, wa);
-  }
-  // two inverse transforms: each one's register pass is issued behind the other's exchange, so it runs while that exchange is in flight
-  __device__ __forceinline__ void inverse2(double (&xr)[8], double (&xi)[8], double (&yr)[8], double (&yi)[8], d2 *xch, int lane) const {
-    double *x = reinterpret_cast<double *>(xch), *pa = x + lane, *pb = x + 72 * (lane >> 3) + (lane & 7), *pc = x + 9 * lane;
-    pass_inv(xr, xi, wc);
-    exchange<1, 9>(xr, xi, pc, pb);
-    pass_inv(yr, yi, wc);
-    exchange<1, 9>(yr, yi, pc, pb);
-    pass_inv(xr, xi, wb);
-    exchange<8, 72>(xr, xi, pb, pa);
-    pass_inv(yr, yi, wb);
-    exchange<8, 72>(yr, yi, pb, pa);
-    pass_inv(xr, xi, wa);
-    pass_inv(yr, yi, wa);
-  }
-};
-
 // ------------------------------------------------------------------------------------------------
 // N = 2048 (M = 1024): two wavefronts (128 threads) x 8 points share one transform.
 // Index j has 10 bits; passes of 3, 3, 3 and 1 radix-2 levels:

@@ -48,22 +48,14 @@ extern "C" int ab_ep(const double *d_row, const double *d_tw, const uint64_t *d_
 }
 
 #if AB_N == 1024
-// LDS-key variant: one workgroup of AB_TEAMS teams per CU (-DAB_HALF: half-size transpose buffers, Fft1024H)
-#ifndef AB_TEAMS
-#define AB_TEAMS 8
-#endif
-#ifdef AB_HALF
-#define AB_EPL_F Fft1024H
-#else
-#define AB_EPL_F Fft1024
-#endif
+// LDS-key variant: one workgroup of 8 teams per CU
 extern "C" int ab_epl(const double *d_row, const double *d_tw, const uint64_t *d_in, uint64_t *d_out, int count, int grid, int reps, float *ms_per_launch) {
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1;
   hipEventRecord(e0, nullptr);
   for (int r = 0; r < reps; r++)
-    hipLaunchKernelGGL((external_product_ldskey_kernel<2, 8, false, AB_TEAMS, AB_EPL_F>), dim3((unsigned)grid), dim3(64 * AB_TEAMS), 0, nullptr, (const d2 *)d_row, (const d2 *)d_tw, d_in,
-                       d_out, 8, count, (size_t)2048, (const uint64_t *)nullptr, (d2 *)nullptr);
+    hipLaunchKernelGGL((external_product_ldskey_kernel<2, 8, false>), dim3((unsigned)grid), dim3(512), 0, nullptr, (const d2 *)d_row, (const d2 *)d_tw, d_in, d_out, 8, count,
+                       (size_t)2048, (const uint64_t *)nullptr, (d2 *)nullptr);
   hipEventRecord(e1, nullptr);
   if (hipEventSynchronize(e1) != hipSuccess) return -2;
   float ms = 0.f;
