@@ -433,6 +433,10 @@ inline hipError_t launch_tlwe_keyswitch_scaled(const uint64_t *ksk, uint64_t *ou
   return hipGetLastError();
 }
 
+}  // namespace mosfhet
+#include "keyswitch_words_kernels.h"   // the other orientation (output words on the lanes): launch_tlwe_keyswitch_words
+namespace mosfhet {
+
 // Tile of 256 ciphertexts per workgroup for small digit sets (the table is cache resident), 512 for base_bit >= 3, where the
 // multi-gigabyte table is re-read once per tile (packing switch 5.3 -> 4.9 ms, lvl2 LWE switch 4.45 -> 4.16 ms; SET_1 prefers 256).
 inline hipError_t launch_tlwe_keyswitch(const uint64_t *ksk, uint64_t *out, size_t out_stride, const uint64_t *in, size_t in_stride, int count,
@@ -444,6 +448,9 @@ inline hipError_t launch_tlwe_keyswitch(const uint64_t *ksk, uint64_t *out, size
   static const int small_max = getenv("MOSFHET_KS_SMALL_MAX") ? atoi(getenv("MOSFHET_KS_SMALL_MAX")) : 16;
   if (count <= small_max)
     return launch_tlwe_keyswitch_small(ksk, out, out_stride, in, in_stride, count, n_in, row, b_word, t, base_bit, ws, s, compressed, seed, mask_words);
+  // digit sets of at most 15 candidates: output words on the lanes, wave-uniform digits (keyswitch_words_kernels.h; MOSFHET_HIP_KS_WORDS=0: the LDS-gather tiles below)
+  if (ks_words_applies(count, n_in, row, t, base_bit))
+    return launch_tlwe_keyswitch_words(ksk, out, out_stride, in, in_stride, count, n_in, row, b_word, t, base_bit, ws, s, compressed, seed, mask_words);
   // (up to 256 ciphertexts one 256-wide tile holds them all: the 512-wide tile's extra wavefronts would only stage rows -- +15 % on circuit bootstraps of
   // 64 - 256 ciphertexts, the shape of a batch of 1024 split over 8 GPUs)
   if (base_bit >= 3 && (count > 256 || base_bit > 4))   // (wider digits need the 512-thread tile's staging width)
