@@ -20,7 +20,7 @@ Prints ONE JSON line (rank 0) with the contract fields plus
   roofline_external_product_lvl2 : the same at N = 2048, l = 4 (64 KiB per unit, 256 KiB key entry);
   configs_3_4  : BASELINE.json configs[3] and [4] (N = 1: on this GPU; N > 1: each batch of 1024 SPLIT over the ranks, strong scaling, max over ranks): 1024 x circuit_bootstrap_3, full-domain functional bootstrap, multi-value bootstrap
                  (8 LUTs) and Galois-automorphism bootstrap at N = 2048, each checked by phase, each with the FP64 share of its blind rotations, the circuit
-                 bootstrap's packing switches against their LDS-gather floor, and ONE GPU's share of the batch when it is split over 8 (128 inputs);
+                 bootstrap's packing switches against the 64-bit-add issue rate that bounds them, and ONE GPU's share of the batch when it is split over 8 (128 inputs);
   lvl2_bootstraps : BASELINE.json configs[2] for the record (4096 programmable bootstraps at N = 2048, l = 4 on this GPU: rate, FP64-model fraction,
                  outputs checked by phase); not part of `value`; small_batches: 1 and 128 bootstraps on two CUs each (pbs_split_kernel) against one CU each;
   gate         : SURVEY 8(f).1 -- 4096 x (tlwe_keyswitch + functional_bootstrap) at SET_1, one call, checked by phase;
@@ -137,7 +137,7 @@ def lvl2_bootstrap_leg(eng, ma, host, torch, keys, B2=4096):
     return res
 
 
-LDS_GATHER_PEAK_GBS = 256 * 256 * 2.0   # table key switches: 256 B / clock / CU of ds_read_b128 x 256 CUs x 2.0 GHz sustained = 131 TB/s
+U64_ADD_PEAK_TOPS = 1024 * 64 / 4 * 2.4e9 / 1e12   # table key switches (word-lane form): one v_lshl_add_u64 (64 lanes) per SIMD per 4 clocks, 1024 SIMDs, 2.4 GHz = 39.3 T adds/s
 
 
 def composition_legs(eng, ma, host, torch, keys, batch=1024, share=8, rank=0, world=1, dist_device=None):
@@ -146,7 +146,7 @@ def composition_legs(eng, ma, host, torch, keys, batch=1024, share=8, rank=0, wo
       bb = 2), full_domain_functional_bootstrap (:519-538, precision 3), multivalue_bootstrap_CLOT21 (:222-230, torus_base 2, 8 LUTs) and functional_bootstrap_ga
       (src/bootstrap_ga.c:62-76).  All keys but the private key-switch pair are generated on the device.  Every leg is checked by PHASE (no oracle on the measured path);
       each carries the share of the chip's FP64 vector peak its blind rotations reach (SURVEY 8(d) FLOP model over the composition's whole time -- the key switches,
-      extractions and copies count as time, not as work) and, for the circuit bootstrap, its packing switches alone against the LDS-gather floor that bounds them.
+      extractions and copies count as time, not as work) and, for the circuit bootstrap, its packing switches alone against the 64-bit-add issue rate that bounds them.
     world > 1 (every rank calls this): the configs' own shape -- the batch of 1024 SPLIT over the GPUs (strong scaling): rank r bootstraps the contiguous slice
       shard_bounds(batch, r, world) against its own replica of the keys (same seeds), no collective on the data path; a leg's time is the max over ranks of a
       barrier-bracketed region (mosfhet_amd/shard.py), its rate batch / that time; every rank phase-checks its own slice and the worst error is reported."""
@@ -209,7 +209,7 @@ def composition_legs(eng, ma, host, torch, keys, batch=1024, share=8, rank=0, wo
     small = max(1, mine // share)
     # ---- configs[3]: circuit_bootstrap_3 ----
     kska = eng.load_trlwe_ks_keys(host.gen_priv_ks_key(rk2, rk2, 20, 2), 2)
-    pk = eng.generate_table_key(0, s, s, 6, 4, P2["rlwe_sigma"], seed=99, compressed=True)   # 6 GB of rows, 3 GB in HBM: masks regenerated in the kernel
+    pk = eng.generate_table_key(0, s, s, 6, 4, P2["rlwe_sigma"], seed=99)   # 6 GB of rows, all of them in HBM (seed-compressed keys -- 3 GB, masks regenerated in the kernel -- switch 25 % slower)
     d_cb_in = ma.to_device(host.tlwe_samples([host.double2torus(0.25 * (b & 1)) for b in range(lo, hi)], lk2), eng.device)
     d_cb_out = eng.empty(mine, 2 * l, 2, N)
     pick = np.unique(np.concatenate([[0, 1, mine // 2, mine - 1], np.random.default_rng(3).integers(0, mine, 12)]))
@@ -221,19 +221,21 @@ def composition_legs(eng, ma, host, torch, keys, batch=1024, share=8, rank=0, wo
         for i in range(l):
             want[:, i, 0] = ((pick + lo) & 1).astype(np.uint64) << np.uint64(64 - (i + 1) * Bg)
         return phase_err(ph, want)
-    # the packing switches of one batch alone (l switches of `batch` extracted samples), against the LDS-gather floor
+    # the packing switches of one batch alone (l switches of `batch` extracted samples), against the issue rate of their 64-bit adds
     d_ext = ma.to_device(np.random.default_rng(4).integers(0, 2 ** 64, size=(mine, N + 1), dtype=np.uint64), eng.device)
     d_pk_out = eng.empty(mine, 2, N)
     eng.trlwe_packing1_keyswitch(pk, d_ext, out=d_pk_out)
     pk_ms = timed_ms(torch, lambda: eng.trlwe_packing1_keyswitch(pk, d_ext, out=d_pk_out))
-    pk_bytes = mine * N * 6 * (2 * N) * 8
-    entry("circuit_bootstrap_3", "%d x circuit_bootstrap_3 at N=2048 l=4 n=632, packing key t=6 bb=4 (6 GB of rows, seed-compressed to 3 GB), private key t=20 bb=2 "
+    pk_adds = mine * N * 6 * (2 * N)
+    entry("circuit_bootstrap_3", "%d x circuit_bootstrap_3 at N=2048 l=4 n=632, packing key t=6 bb=4 (6 GB of rows), private key t=20 bb=2 "
           "(BASELINE.json configs[3])" % batch, "/root/reference/src/bootstrap.c:346-366", batch,
           lambda: eng.circuit_bootstrap_3(bsk, kska, pk, d_cb_in, out=d_cb_out), chk_cb, 1,
           lambda: eng.circuit_bootstrap_3(bsk, kska, pk, d_cb_in[:small], out=d_cb_out[:small]),
-          {"packing_switch": {"bound": "lds_gather", "kernel": "mosfhet::tlwe_keyswitch_kernel (TRLWE rows)", "kernel_ms": pk_ms, "switches_per_launch": mine,
-                              "launches_per_batch": l, "algorithmic_lds_bytes_per_launch": pk_bytes, "achieved": pk_bytes / (pk_ms * 1e-3) / 1e9,
-                              "peak": LDS_GATHER_PEAK_GBS, "unit": "GB/s", "frac": pk_bytes / (pk_ms * 1e-3) / 1e9 / LDS_GATHER_PEAK_GBS,
+          {"packing_switch": {"bound": "valu_issue", "kernel": "mosfhet::table_ks_words_kernel<15, false> (TRLWE rows; output words on the lanes)", "kernel_ms": pk_ms,
+                              "switches_per_launch": mine, "launches_per_batch": l, "adds_per_launch": pk_adds,
+                              "achieved": pk_adds / (pk_ms * 1e-3) / 1e12, "peak": U64_ADD_PEAK_TOPS, "unit": "T adds/s", "frac": pk_adds / (pk_ms * 1e-3) / 1e12 / U64_ADD_PEAK_TOPS,
+                              "note": "one 64-bit add per (ciphertext, input word, digit position, output word) = src/keyswitch.c:470-473's subtraction; peak = one v_lshl_add_u64 per "
+                                      "SIMD and 4 clocks on 1024 SIMDs at 2.4 GHz.  The ciphertext-lane form it replaces (keyswitch_kernels.h) was bound by its per-lane LDS gather",
                               "share_of_batch_time": None}})
     if world == 1:
         res["circuit_bootstrap_3"]["packing_switch"]["share_of_batch_time"] = l * pk_ms / res["circuit_bootstrap_3"]["ms_per_batch"]
@@ -242,7 +244,7 @@ def composition_legs(eng, ma, host, torch, keys, batch=1024, share=8, rank=0, wo
     del d_cb_out, d_pk_out
 
     # ---- configs[4]: full-domain functional bootstrap, multi-value bootstrap ----
-    ksk = eng.generate_keyswitch_key(lk2.s, out_s, P2["t"], P2["base_bit"], P2["lwe_sigma"], seed=7, compressed=True)
+    ksk = eng.generate_keyswitch_key(lk2.s, out_s, P2["t"], P2["base_bit"], P2["lwe_sigma"], seed=7)
     lut8 = np.array([host.double2torus(((3 * i + 1) % 8) / 8.0) for i in range(8)], dtype=np.uint64)
     d_tv8 = ma.to_device(host.torus_packing_many_lut(lut8, 1, N, 4, 2)[None], eng.device)
     d_in5 = ma.to_device(host.tlwe_samples([(b % 8) << 61 for b in range(lo, hi)], lk2), eng.device)

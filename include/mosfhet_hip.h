@@ -341,6 +341,11 @@ int mosfhet_hip_set_wide_team_max_batch(int max_batch);
  * rounding -- the tolerance the reference's own tests accept between its two FFT back-ends -- and are bit-identical to the oracle's restatement of that order
  * (oracle/oracle_tfhe.c: orc_set_product_order). */
 int mosfhet_hip_set_split_max_batch(int max_batch);
+/* Table key switches (tlwe_keyswitch, trlwe_packing1_keyswitch, trlwe_priv_keyswitch: src/tlwe.c:289-303, src/keyswitch.c:458-475,639-656) with 2 - 4 digit bits:
+ * from `min_count` ciphertexts on they run with OUTPUT WORDS on the lanes (wave-uniform digits pick the candidate by register-relative addressing: one scalar move and
+ * one 64-bit add per ciphertext, input word, digit position and output word) instead of ciphertexts on the lanes (a per-lane LDS gather).  Integer sums: the same
+ * bits either way.  Default 64 (MOSFHET_HIP_KS_WORDS); 0 = never. */
+int mosfhet_hip_set_ks_words(int min_count);
 /* how long (10 ns ticks; default 200000 = 2 ms, MOSFHET_HIP_SPLIT_LIMIT) the first workgroup of such a pair waits for its partner before it takes the whole bootstrap
  * alone (same summation order, same bits); 0 = always alone (test switch) */
 int mosfhet_hip_set_split_wait_limit(int ticks);

@@ -740,6 +740,11 @@ extern "C" int mosfhet_hip_set_split_max_batch(int max_batch) {
   g_split_max = max_batch < -1 ? -1 : max_batch;
   return MOSFHET_HIP_OK;
 }
+// MOSFHET_HIP_KS_WORDS: from how many ciphertexts a table key switch with 2 - 4 digit bits takes the word-lane kernel (keyswitch_words_kernels.h); 0 = never
+extern "C" int mosfhet_hip_set_ks_words(int min_count) {
+  g_ks_words_min = min_count < 0 ? 64 : min_count;
+  return MOSFHET_HIP_OK;
+}
 // MOSFHET_HIP_SPLIT_LIMIT: how long the first workgroup of a pair waits for the second before it takes the bootstrap alone, in 10 ns ticks (default 2 ms);
 // 0 = every bootstrap alone (test switch: same bits)
 static std::atomic<int> g_split_limit{-1};
@@ -1097,7 +1102,7 @@ extern "C" int mosfhet_hip_ksk_create(mosfhet_hip_ctx_t ctx, mosfhet_hip_ksk_t *
   k->ctx = ctx; k->n_in = n_in; k->n_out = n_out; k->t = t; k->base_bit = base_bit;
   k->row = n_out + 1; k->b_word = n_out;
   k->bytes = (size_t)n_in * t * ((1u << base_bit) - 1) * (n_out + 1) * sizeof(uint64_t);
-  HIP_TRY(hipMalloc((void **)&k->d_ksk, k->bytes));
+  HIP_TRY(hipMalloc((void **)&k->d_ksk, k->bytes + ksw_slack_bytes(k->row)));   // (+ slack: the word-lane key switch reads past the last row, keyswitch_words_kernels.h)
   HIP_TRY(hipMemcpy(k->d_ksk, h_ksk, k->bytes, hipMemcpyHostToDevice));
   *out = k_owner.release();
   return MOSFHET_HIP_OK;

@@ -733,6 +733,11 @@ def set_split_max_batch(max_batch):
     _check(lib().mosfhet_hip_set_split_max_batch(int(max_batch)))
 
 
+def set_ks_words(min_count):
+    """Table key switches with 2 - 4 digit bits take the word-lane kernel (keyswitch_words_kernels.h) from this many ciphertexts on (default 64, 0 = never; same bits)."""
+    _check(lib().mosfhet_hip_set_ks_words(int(min_count)))
+
+
 def set_split_wait_limit(ticks):
     """bound (10 ns ticks) of the pairing wait of pbs_split_kernel; 0 = every bootstrap taken alone by one workgroup (same bits)"""
     _check(lib().mosfhet_hip_set_split_wait_limit(int(ticks)))

@@ -43,7 +43,7 @@ static int run_case(int count, int n_in, int row, int b_word, int t, int bb, int
   const size_t rows = (size_t)n_in * t * cands, key_words = rows * (size_t)(row - mask_words);
   const int in_words = n_in + (b_word >= 0 ? 1 : 0);
   uint64_t *ksk, *in, *out_a, *out_b;
-  CHECK(hipMalloc(&ksk, key_words * 8));
+  CHECK(hipMalloc(&ksk, key_words * 8 + ksw_slack_bytes(row)));   // (the word-lane form reads past the last row: keyswitch_words_kernels.h)
   CHECK(hipMalloc(&in, (size_t)count * in_words * 8));
   CHECK(hipMalloc(&out_a, (size_t)count * row * 8));
   CHECK(hipMalloc(&out_b, (size_t)count * row * 8));

@@ -18,6 +18,10 @@ Register plan (fixed physical registers, declared as clobbers; the accumulators 
     s[36:67]    entries of an even position, s[68:99] of an odd one;  s[34:35] the running address of the entries
 Operands: %0 .. %63 accumulators; %[la] LDS byte address of the lane's word in candidate row 0 of the stage (advanced inside); %[dp] address of the
 wavefront's entries of the stage; %[np] positions left (counted down inside).
+LDS-DMA of a later stage, spread over the block (one global_load_lds_dwordx4 behind the adds of a position, so that its issue costs the wavefront one slot
+instead of a burst's queueing): %[nd] DMAs left to issue, %[ga] the lane's source address, %[gs] the (wave-uniform) byte step to the wavefront's next row
+pair, %[ld] LDS byte address the DMA writes to (its step: 8 KiB = the workgroup's eight row pairs), %[na] times the address still advances (a wavefront
+with fewer row pairs than DMAs repeats its last one: same bytes to the same place, and every wavefront's vmcnt counts the same).
 """
 import os
 import sys
@@ -49,6 +53,13 @@ def adds(blk, sset):
     return out
 
 
+def dma(tag):
+    return ["s_cmp_eq_u32 %[nd], 0", "s_cbranch_scc1 %sf" % tag,
+            "s_mov_b32 m0, %[ld]", "s_nop 0", "global_load_lds_dwordx4 %[ga], off", "s_sub_u32 %[nd], %[nd], 1",
+            "s_cmp_eq_u32 %[na], 0", "s_cbranch_scc1 %sf" % tag,
+            "v_lshl_add_u64 %[ga], %[ga], 0, %[gs]", "s_add_u32 %[ld], %[ld], 0x2000", "s_sub_u32 %[na], %[na], 1", "%s:" % tag]
+
+
 def block(cands):
     L = []
     L += ["s_mov_b64 s[34:35], %[dp]"]
@@ -60,10 +71,12 @@ def block(cands):
     L += loads(cands, Y, SB, 1)
     L += ["2:"]
     L += adds(X, SA)
+    L += dma("5")
     L += ["s_cmp_lt_u32 %[np], 2", "s_cbranch_scc1 4f", "s_waitcnt lgkmcnt(0)", "s_cmp_lt_u32 %[np], 3", "s_cbranch_scc1 3f"]
     L += loads(cands, X, SA, 2)
     L += ["3:"]
     L += adds(Y, SB)
+    L += dma("6")
     L += ["s_add_u32 s34, s34, 0x100", "s_addc_u32 s35, s35, 0", "v_add_u32 %%[la], %d, %%[la]" % (2 * cands * 512),
           "s_sub_u32 %[np], %[np], 2", "s_cmp_lg_u32 %[np], 0", "s_cbranch_scc1 1b", "4:"]
     return L
