@@ -1515,10 +1515,11 @@ static Generic_KS_Key table_key_new(int kind, TRLWE_Key out_key, TLWE_Key in_key
   Generic_KS_Key res = (Generic_KS_Key)mc_xmalloc(sizeof(*res));
   res->s = NULL; res->base_bit = base_bit; res->t = t; res->n = in_key->n; res->include_b = kind;
   mosfhet_hip_ksk_t dev = NULL;
-  /* seed-compressed, like the reference's default build (USE_COMPRESSED_TRLWE, src/keyswitch.c:231-241): half the bytes in HBM, the key switches
-   * regenerate the masks; MOSFHET_HIP_FULL_TABLE_KEYS=1 keeps full rows instead (same results either way) */
+  /* full rows in HBM by default (6 GB for the lvl2 packing key: nothing on a 288 GB part, and the word-lane key switch streams stored rows 25 % faster than it
+   * regenerates masks); MOSFHET_HIP_FULL_TABLE_KEYS=0 keeps the rows seed-compressed like the reference's default build (USE_COMPRESSED_TRLWE,
+   * src/keyswitch.c:231-241): half the bytes, the key switches regenerate the masks (same results either way) */
   const char *full = getenv("MOSFHET_HIP_FULL_TABLE_KEYS");
-  int rc = (full && full[0] == '1')
+  int rc = !(full && full[0] == '0')
                ? mosfhet_hip_trlwe_table_ksk_generate((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, kind, out_key->s[0]->coeffs, N, in_key->s, in_key->n, t,
                                                       base_bit, out_key->sigma, mc_rnd64())
                : mosfhet_hip_trlwe_table_ksk_generate_compressed((mosfhet_hip_ctx_t)mosfhet_engine_ctx(), &dev, kind, out_key->s[0]->coeffs, N, in_key->s,

@@ -29,7 +29,7 @@ want ep && EP_GROUPS=60 prof ep "FETCH_SIZE;WRITE_SIZE;$LDS;$SQ2" $ROOT/tools/gp
 want ep2 && EP_GROUPS=60 prof ep2 "FETCH_SIZE;WRITE_SIZE;$SQ1;$SQ2" $ROOT/tools/gpu_perf_ep.py 16384 lvl2
 want lvl2 && prof lvl2 "$ALL" $ROOT/tools/gpu_perf.py 4096 lvl2
 want ks && prof ks "FETCH_SIZE;$LDS;$SQ2" $ROOT/tools/gpu_perf_ks.py 4096 lvl2 device
-want cb && prof cb "FETCH_SIZE;$SQ2" $ROOT/tools/gpu_perf_cb.py 1024
+want cb && prof cb "FETCH_SIZE;$SQ1;$SQ2" $ROOT/tools/gpu_perf_cb.py 1024
 want split && prof split "FETCH_SIZE;$SQ1;TCC_HIT_sum TCC_MISS_sum;$SQ2" $ROOT/tools/gpu_perf_split.py
 want unf && prof unf "FETCH_SIZE;$SQ1;TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum;$SQ2" $ROOT/tools/gpu_perf_unfold.py 4096 lvl2
 for n in $ONLY; do echo "=== $n"; grep -E "kernel stats|calls=|per-dispatch" $ROOT/gpurun_out/prof_${TAG}_$n/summary.txt | head -40; done

@@ -52,7 +52,7 @@ SWITCHES = {
                             "`test_multi_device_compat`"),
     "MOSFHET_HIP_DEVICES": ("unset", "drop-in API: comma-separated device list, first = primary (same as `mosfhet_set_devices`)", "`mosfhet_set_devices`", "`test_multi_device_compat`"),
     "MOSFHET_HIP_DEVICE": ("0", "drop-in API: the one device to use when no list is given", "`mosfhet_set_devices`", "`tests/c/compat_suite.c`"),
-    "MOSFHET_HIP_FULL_TABLE_KEYS": ("unset", "drop-in API: 1 keeps table key-switch keys as full rows in HBM instead of seed-compressed (same results)", "-",
+    "MOSFHET_HIP_FULL_TABLE_KEYS": ("1", "drop-in API: table key-switch keys as full rows in HBM (1) or seed-compressed like the reference's default build (0: half the bytes, masks regenerated in the key switches; same results)", "-",
                                     "`test_seed_compressed_table_keys_are_the_same_keys`"),
     "MOSFHET_HIP_MARSHAL_THREADS": ("min(cores, 8)", "drop-in API: host threads that pack / unpack sample structs around the batched calls", "-", "`tests/c/compat_suite.c` case `big_batch`"),
     "MOSFHET_HIP_PIPE_CHUNK": ("1024", "drop-in API: ciphertexts per chunk of the two-stream upload / bootstrap / download pipeline of `*_batch`", "-", "`tools/compat_latency.c` (timing)"),
