@@ -346,6 +346,8 @@ int mosfhet_hip_set_split_max_batch(int max_batch);
  * one 64-bit add per ciphertext, input word, digit position and output word) instead of ciphertexts on the lanes (a per-lane LDS gather).  Integer sums: the same
  * bits either way.  Default 64 (MOSFHET_HIP_KS_WORDS); 0 = never. */
 int mosfhet_hip_set_ks_words(int min_count);
+/* wavefronts of that kernel whose bounded wait on their workgroup's counters ran out since the library was loaded (synchronises the device): 0 unless something is broken */
+int mosfhet_hip_ks_words_gave_up(mosfhet_hip_ctx_t ctx, unsigned int *count);
 /* how long (10 ns ticks; default 200000 = 2 ms, MOSFHET_HIP_SPLIT_LIMIT) the first workgroup of such a pair waits for its partner before it takes the whole bootstrap
  * alone (same summation order, same bits); 0 = always alone (test switch) */
 int mosfhet_hip_set_split_wait_limit(int ticks);

@@ -745,6 +745,15 @@ extern "C" int mosfhet_hip_set_ks_words(int min_count) {
   g_ks_words_min = min_count < 0 ? 64 : min_count;
   return MOSFHET_HIP_OK;
 }
+// wavefronts of table_ks_words_kernel whose bounded wait on the workgroup's LDS counters ran out since the library was loaded (synchronises the device): 0 unless
+// something is broken -- the waits involve the eight resident wavefronts of one workgroup only.  For tests and the soak.
+extern "C" int mosfhet_hip_ks_words_gave_up(mosfhet_hip_ctx_t ctx, unsigned int *count) {
+  if (!ctx || !count) return fail(MOSFHET_HIP_EINVAL, "ks_words_gave_up: null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(count, HIP_SYMBOL(ksw_gave_up_count), sizeof(unsigned int)));
+  return MOSFHET_HIP_OK;
+}
 // MOSFHET_HIP_SPLIT_LIMIT: how long the first workgroup of a pair waits for the second before it takes the bootstrap alone, in 10 ns ticks (default 2 ms);
 // 0 = every bootstrap alone (test switch: same bits)
 static std::atomic<int> g_split_limit{-1};

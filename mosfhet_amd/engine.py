@@ -384,6 +384,12 @@ class Engine:
         assert len(key32) == 32
         _check(lib().mosfhet_hip_set_keygen_secret(key32))
 
+    def ks_words_gave_up(self):
+        """wavefronts of the word-lane key-switch kernel whose bounded counter wait ran out since the library was loaded (0 unless something is broken)"""
+        n = C.c_uint()
+        _check(lib().mosfhet_hip_ks_words_gave_up(self.h, C.byref(n)))
+        return n.value
+
     def generate_table_key(self, kind, s_out, s_in, t, base_bit, sigma, seed, compressed=False):
         """On-device packing (kind 0) / private (kind 1) key-switch key; returns a KeySwitchKey.  compressed: keep only the b halves in HBM and
         regenerate the masks inside the key-switch kernels (same rows, same results)."""

@@ -20,6 +20,14 @@ __global__ void fill_kernel(uint64_t *p, size_t n, uint64_t seed) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = keygen_mix(seed, i >> 20, i & 0xfffff, 3);
 }
 
+__global__ void count_diff_kernel(const uint64_t *a, const uint64_t *b, size_t n, unsigned long long *diff) {
+  unsigned long long d = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d += a[i] != b[i];
+  if (d) atomicAdd(diff, d);
+}
+
+static int g_soak = 0;   // ksw_ab soak <launches> <case...>: the word-lane kernel repeated, every launch's output compared on the device with the tiles' output
+
 static float time_ms(hipStream_t s, int reps, const std::function<void()> &f) {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -70,6 +78,22 @@ static int run_case(int count, int n_in, int row, int b_word, int t, int bb, int
   size_t bad = 0, first = (size_t)-1;
   for (size_t i = 0; i < a.size(); i++)
     if (a[i] != b[i]) { if (!bad) first = i; bad++; }
+  if (g_soak) {
+    unsigned long long *d_diff, h_diff = 0;
+    CHECK(hipMalloc(&d_diff, 8));
+    CHECK(hipMemsetAsync(d_diff, 0, 8, s));
+    for (int r = 0; r < g_soak; r++) {
+      CHECK(hipMemsetAsync(out_b, 0x5A, (size_t)count * row * 8, s));
+      words();
+      hipLaunchKernelGGL(count_diff_kernel, dim3(1024), dim3(256), 0, s, out_a, out_b, (size_t)count * row, d_diff);
+    }
+    CHECK(hipStreamSynchronize(s));
+    CHECK(hipMemcpy(&h_diff, d_diff, 8, hipMemcpyDeviceToHost));
+    unsigned int gave_up = 0;
+    CHECK(hipMemcpyFromSymbol(&gave_up, HIP_SYMBOL(ksw_gave_up_count), sizeof(gave_up)));
+    printf("soak: %d launches of the word-lane kernel, %llu differing words in total, %u wavefronts gave up a wait\n", g_soak, h_diff, gave_up);
+    (void)hipFree(d_diff);
+  }
   const KsWordsPlan p = ks_words_plan(count, n_in, row, t, bb);
   printf("count=%5d n_in=%5d row=%5d b_word=%5d t=%2d bb=%d %s  tiles %8.3f ms  words %8.3f ms  (x%.2f; JB=%d groups=%d wblocks=%d splits=%d lds=%zu)  differing words: %zu%s\n",
          count, n_in, row, b_word, t, bb, compressed ? "compressed" : "plain     ", ms_a, ms_b, ms_a / ms_b, p.JB, p.groups, p.wblocks, p.splits, p.lds, bad,
@@ -87,6 +111,11 @@ static int run_case(int count, int n_in, int row, int b_word, int t, int bb, int
 
 int main(int argc, char **argv) {
   int fails = 0;
+  if (argc >= 3 && !strcmp(argv[1], "soak")) {
+    g_soak = atoi(argv[2]);
+    argc -= 2;
+    argv += 2;
+  }
   if (argc >= 8) {
     for (int k = 1; k + 6 < argc; k += 7)
       fails += run_case(atoi(argv[k]), atoi(argv[k + 1]), atoi(argv[k + 2]), atoi(argv[k + 3]), atoi(argv[k + 4]), atoi(argv[k + 5]), atoi(argv[k + 6]));
