@@ -14,7 +14,7 @@ LIB = os.path.join(HERE, "libmosfhet_hip.so")
 
 HIP_SOURCES = ["capi.hip"]
 HOST_C_SOURCES = ["host/mosfhet_compat.c", "host/mosfhet_compat_dft.c", "host/mosfhet_compat_multi.c", "host/mosfhet_compat_legacy.c", "host/mosfhet_compat_extra.c", "host/mosfhet_compat_vec.c", "host/csprng.c"]
-DEPS = ["negacyclic_fft.h", "bootstrap_kernels.h", "general_kernels.h", "keyswitch_kernels.h", "ext_kernels.h", "unfold_kernels.h", "keygen_kernels.h", "capi_ext.inc", "capi_dft.inc", "capi_vec.inc", "../../include/mosfhet_hip.h",
+DEPS = ["negacyclic_fft.h", "bootstrap_kernels.h", "general_kernels.h", "keyswitch_kernels.h", "keyswitch_words_kernels.h", "ks_words_asm.inc", "ext_kernels.h", "unfold_kernels.h", "keygen_kernels.h", "capi_ext.inc", "capi_dft.inc", "capi_vec.inc", "../../include/mosfhet_hip.h",
         "../../include/mosfhet_compat.h", "../../include/mosfhet.h", "host/compat_internal.h", "../build.py", "../../tools/check_lds_barriers.py"]
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value",

@@ -55,7 +55,7 @@ def adds(blk, sset):
 
 def dma(tag):
     return ["s_cmp_eq_u32 %[nd], 0", "s_cbranch_scc1 %sf" % tag,
-            "s_mov_b32 m0, %[ld]", "s_nop 0", "global_load_lds_dwordx4 %[ga], off", "s_sub_u32 %[nd], %[nd], 1",
+            "s_mov_b32 m0, %[ld]", "s_sub_u32 %[nd], %[nd], 1", "global_load_lds_dwordx4 %[ga], off",      # (the s_sub is the wait state between the M0 write and the DMA)
             "s_cmp_eq_u32 %[na], 0", "s_cbranch_scc1 %sf" % tag,
             "v_lshl_add_u64 %[ga], %[ga], 0, %[gs]", "s_add_u32 %[ld], %[ld], 0x2000", "s_sub_u32 %[na], %[na], 1", "%s:" % tag]
 
