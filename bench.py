@@ -442,7 +442,7 @@ def vector_callers_leg(eng, ma, host, torch, M=256):
     rk = host.RlweKey(N, 1, 5.684341886080802e-14)
     ex = rk.extracted_lwe_key()
     bsk = eng.generate_bootstrap_key(rk.s[0], lk.s, l, Bg, 5.684341886080802e-14, seed=31)
-    ksk = eng.generate_keyswitch_key(lk.s, ex.s, t, bb, 3.0517578125e-05, seed=32, compressed=True)
+    ksk = eng.generate_keyswitch_key(lk.s, ex.s, t, bb, 3.0517578125e-05, seed=32)
     pksk = eng.generate_lut_packing_key(rk.s[0], ex.s, t, bb, Bt, 5.684341886080802e-14, seed=33)
     vec = eng.vector_ops(bsk, ksk, pksk, Bt)
     rng = np.random.default_rng(0xD163)
