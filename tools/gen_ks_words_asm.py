@@ -29,6 +29,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "..", "mosfhet_amd", "csrc", "ks_words_asm.inc")
 X, Y, SA, SB = 192, 224, 36, 68
+UNROLLED = ((15, 6), (15, 4))     # (candidates, positions per stage) that get a written-out block: the packing switch and the lvl2 LWE switch of the BASELINE configs
 
 
 EXP = set(sys.argv[2].split(",")) if len(sys.argv) > 2 else set()     # timing experiments: "nosload" (entries loaded for the first position only), "nods"
@@ -82,6 +83,23 @@ def block(cands):
     return L
 
 
+def block_unrolled(cands, jb):
+    """the same block with its `jb` positions written out: no position counter, no pointer updates (immediate offsets), the DMA slots compare against constants"""
+    L = ["s_mov_b64 s[34:35], %[dp]"]
+    L += ["v_mov_b32 v%d, 0" % r for r in (X, X + 1, Y, Y + 1)]
+    L += loads(cands, X, SA, 0)
+    for p in range(jb):
+        blk, sset = (X, SA) if p % 2 == 0 else (Y, SB)
+        L += ["s_waitcnt lgkmcnt(0)"]
+        if p + 1 < jb:
+            L += loads(cands, Y if p % 2 == 0 else X, SB if p % 2 == 0 else SA, p + 1)
+        L += adds(blk, sset)
+        if p >= 1:
+            L += ["s_cmp_lt_u32 %%[na], %d" % p, "s_cbranch_scc1 %df" % (10 + p), "v_lshl_add_u64 %[ga], %[ga], 0, %[gs]", "s_add_u32 %[ld], %[ld], 0x2000", "%d:" % (10 + p)]
+        L += ["s_cmp_le_u32 %%[nd], %d" % p, "s_cbranch_scc1 %df" % (20 + p), "s_mov_b32 m0, %[ld]", "s_nop 0", "global_load_lds_dwordx4 %[ga], off", "%d:" % (20 + p)]
+    return L
+
+
 def main():
     with open(OUT, "w") as f:
         f.write("// ks_words_asm.inc -- GENERATED by tools/gen_ks_words_asm.py (see its header for the register plan); included by keyswitch_words_kernels.h\n")
@@ -91,6 +109,9 @@ def main():
             lines = block(cands)
             text = ['  "%s\\n\\t"' % ln for ln in lines]
             f.write(" \\\n".join(text) + "\n\n")
+        for cands, jb in UNROLLED:
+            f.write("#define KS_WORDS_CONSUME_%d_U%d \\\n" % (cands, jb))
+            f.write(" \\\n".join('  "%s\\n\\t"' % ln for ln in block_unrolled(cands, jb)) + "\n\n")
         f.write("// clang-format on\n")
 
 
