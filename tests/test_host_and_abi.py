@@ -205,6 +205,15 @@ def test_switch_table_matches_the_source():
     assert len(switch_table.SWITCHES) <= 24
 
 
+def test_generated_key_switch_block_matches_its_generator(tmp_path):
+    """mosfhet_amd/csrc/ks_words_asm.inc (the inline-assembly consume block of the word-lane key switch) is what tools/gen_ks_words_asm.py writes"""
+    import subprocess
+    import sys
+    out = tmp_path / "ks_words_asm.inc"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_ks_words_asm.py"), str(out)], check=True)
+    assert out.read_text() == open(os.path.join(ROOT, "mosfhet_amd", "csrc", "ks_words_asm.inc")).read(), "ks_words_asm.inc is stale: python tools/gen_ks_words_asm.py"
+
+
 def test_no_cpu_fallback(native_lib):
     import torch
     import mosfhet_amd as ma
