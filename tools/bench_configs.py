@@ -102,7 +102,7 @@ def main():
     # ---- configs[3] ----
     if not args.only or args.only == "circuit":
         kska = eng.load_trlwe_ks_keys(host.gen_priv_ks_key(rk, rk, 20, 2), 2)
-        pk = eng.generate_table_key(0, s, s, 6, 4, P["rlwe_sigma"], seed=99, compressed=True)   # seed-compressed rows: 3 GB in HBM, masks regenerated in the kernel (same results, 2-3 % faster)
+        pk = eng.generate_table_key(0, s, s, 6, 4, P["rlwe_sigma"], seed=99)   # 6 GB of rows in HBM (seed-compressed: 3 GB, masks regenerated in the kernel, same results, switches 25 % slower)
         lo, hi = shard.shard_bounds(1024, rank, world) if args.share == 1 else shard.shard_bounds(1024, 0, args.share)
         d_cb_in = ma.to_device(host.tlwe_samples([host.double2torus(0.25 * (b & 1)) for b in range(lo, hi)], lk), eng.device)
         d_cb_out = eng.empty(hi - lo, 2 * l, 2, N)
