@@ -348,6 +348,9 @@ int mosfhet_hip_set_split_max_batch(int max_batch);
 int mosfhet_hip_set_ks_words(int min_count);
 /* wavefronts of that kernel whose bounded wait on their workgroup's counters ran out since the library was loaded (synchronises the device): 0 unless something is broken */
 int mosfhet_hip_ks_words_gave_up(mosfhet_hip_ctx_t ctx, unsigned int *count);
+/* its launch plan for a shape, without a device (tests): plan = { taken at the current setting, digit positions per stage, stages per input word, LDS-DMA requests per wavefront
+ * and stage, LDS bytes per workgroup, workgroups, ciphertext groups of 512, input-word splits }; compressed_lwe: seed-compressed LWE rows (they stay with the other form) */
+int mosfhet_hip_ks_words_plan(int count, int n_in, int row, int t, int base_bit, int compressed_lwe, long long plan[8]);
 /* how long (10 ns ticks; default 200000 = 2 ms, MOSFHET_HIP_SPLIT_LIMIT) the first workgroup of such a pair waits for its partner before it takes the whole bootstrap
  * alone (same summation order, same bits); 0 = always alone (test switch) */
 int mosfhet_hip_set_split_wait_limit(int ticks);

@@ -745,6 +745,18 @@ extern "C" int mosfhet_hip_set_ks_words(int min_count) {
   g_ks_words_min = min_count < 0 ? 64 : min_count;
   return MOSFHET_HIP_OK;
 }
+// The launch plan of the word-lane key switch for a shape (no device needed): plan[8] = applies (0 / 1 at the current MOSFHET_HIP_KS_WORDS), positions per stage, stages per
+// input word, LDS-DMA requests per wavefront and stage, LDS bytes, workgroups, ciphertext groups, input-word splits.  For the CPU test that sweeps the shapes.
+extern "C" int mosfhet_hip_ks_words_plan(int count, int n_in, int row, int t, int base_bit, int compressed_lwe, long long plan[8]) {
+  if (!plan || count < 1 || n_in < 1 || row < 1 || t < 1 || base_bit < 1 || base_bit > 8) return fail(MOSFHET_HIP_EINVAL, "ks_words_plan: bad shape");
+  plan[0] = ks_words_applies(count, n_in, row, t, base_bit, compressed_lwe != 0, compressed_lwe ? row - 1 : 0) ? 1 : 0;
+  for (int k = 1; k < 8; k++) plan[k] = 0;
+  if (base_bit < 2 || base_bit > 4) return MOSFHET_HIP_OK;
+  const KsWordsPlan p = ks_words_plan(count > 8192 ? 8192 : count, n_in, row, t, base_bit);
+  plan[1] = p.JB; plan[2] = p.chunks; plan[3] = p.pf; plan[4] = (long long)p.lds;
+  plan[5] = (long long)((p.wblocks * p.splits + 7) / 8) * 8 * p.groups; plan[6] = p.groups; plan[7] = p.splits;
+  return MOSFHET_HIP_OK;
+}
 // wavefronts of table_ks_words_kernel whose bounded wait on the workgroup's LDS counters ran out since the library was loaded (synchronises the device): 0 unless
 // something is broken -- the waits involve the eight resident wavefronts of one workgroup only.  For tests and the soak.
 extern "C" int mosfhet_hip_ks_words_gave_up(mosfhet_hip_ctx_t ctx, unsigned int *count) {

@@ -214,6 +214,38 @@ def test_generated_key_switch_block_matches_its_generator(tmp_path):
     assert out.read_text() == open(os.path.join(ROOT, "mosfhet_amd", "csrc", "ks_words_asm.inc")).read(), "ks_words_asm.inc is stale: python tools/gen_ks_words_asm.py"
 
 
+def test_word_lane_key_switch_plans_fit_the_machine(native_lib):
+    """mosfhet_hip_ks_words_plan over a sweep of shapes (no device needed): the stage divides the digit positions, its candidate rows fit three LDS buffers inside the CU's
+    160 KiB, a wavefront never has more LDS-DMA requests per stage than the consume block has slots (one per position) nor than vmcnt can count, the grid is a multiple of
+    the eight XCDs; digit sets outside 2 - 4 bits, batches below the threshold and seed-compressed LWE rows are left to the other form."""
+    import ctypes as C
+    lib = native_lib
+    lib.mosfhet_hip_ks_words_plan.argtypes = [C.c_int] * 6 + [C.POINTER(C.c_longlong)]
+    plan = (C.c_longlong * 8)()
+    seen = 0
+    for bb in range(1, 9):
+        for t in (1, 2, 3, 5, 6, 7, 8, 9, 11, 12, 16, 20, 30):
+            if t * bb > 63:
+                continue
+            for count in (1, 63, 64, 65, 512, 513, 1024, 4096, 9000):
+                for n_in, row in ((1, 2), (7, 17), (585, 1025), (1024, 586), (2048, 633), (2048, 4096), (4097, 8192)):
+                    assert lib.mosfhet_hip_ks_words_plan(count, n_in, row, t, bb, 0, plan) == 0
+                    taken, jb, chunks, pf, lds, wgs, groups, splits = list(plan)
+                    assert taken == (1 if (2 <= bb <= 4 and count >= 64) else 0), (bb, t, count, n_in, row)
+                    if not 2 <= bb <= 4:
+                        continue
+                    cands = (1 << bb) - 1
+                    assert jb >= 1 and jb * chunks == t and jb * cands <= 96, (bb, t, jb, chunks)
+                    assert 1 <= pf <= min(jb, 8) and 16 * pf >= jb * cands, (bb, t, jb, pf)
+                    assert lds == 3 * 16 * pf * 512 + 16 + 8192 and lds <= 160 * 1024, (bb, t, lds)
+                    assert wgs % 8 == 0 and wgs >= groups * splits and 1 <= splits <= max(1, n_in // 8), (wgs, groups, splits, n_in)
+                    assert groups == -(-(-(-min(count, 8192) // 64)) // 8)
+                    seen += 1
+    assert seen > 1000
+    assert lib.mosfhet_hip_ks_words_plan(1024, 2048, 633, 8, 4, 1, plan) == 0 and plan[0] == 0      # seed-compressed LWE rows: the ciphertext-lane tiles
+    assert lib.mosfhet_hip_ks_words_plan(0, 1, 1, 1, 2, 0, plan) != 0
+
+
 def test_no_cpu_fallback(native_lib):
     import torch
     import mosfhet_amd as ma
