@@ -344,7 +344,7 @@ int mosfhet_hip_set_split_max_batch(int max_batch);
 /* Table key switches (tlwe_keyswitch, trlwe_packing1_keyswitch, trlwe_priv_keyswitch: src/tlwe.c:289-303, src/keyswitch.c:458-475,639-656) with 2 - 4 digit bits:
  * from `min_count` ciphertexts on they run with OUTPUT WORDS on the lanes (wave-uniform digits pick the candidate by register-relative addressing: one scalar move and
  * one 64-bit add per ciphertext, input word, digit position and output word) instead of ciphertexts on the lanes (a per-lane LDS gather).  Integer sums: the same
- * bits either way.  Default 64 (MOSFHET_HIP_KS_WORDS); 0 = never. */
+ * bits either way.  Default 17 = every batch the direct kernels of up to 16 ciphertexts leave (MOSFHET_HIP_KS_WORDS); 0 = never. */
 int mosfhet_hip_set_ks_words(int min_count);
 /* wavefronts of that kernel whose bounded wait on their workgroup's counters ran out since the library was loaded (synchronises the device): 0 unless something is broken */
 int mosfhet_hip_ks_words_gave_up(mosfhet_hip_ctx_t ctx, unsigned int *count);

@@ -742,7 +742,7 @@ extern "C" int mosfhet_hip_set_split_max_batch(int max_batch) {
 }
 // MOSFHET_HIP_KS_WORDS: from how many ciphertexts a table key switch with 2 - 4 digit bits takes the word-lane kernel (keyswitch_words_kernels.h); 0 = never
 extern "C" int mosfhet_hip_set_ks_words(int min_count) {
-  g_ks_words_min = min_count < 0 ? 64 : min_count;
+  g_ks_words_min = min_count < 0 ? 17 : min_count;
   return MOSFHET_HIP_OK;
 }
 // The launch plan of the word-lane key switch for a shape (no device needed): plan[8] = applies (0 / 1 at the current MOSFHET_HIP_KS_WORDS), positions per stage, stages per

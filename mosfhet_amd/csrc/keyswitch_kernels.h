@@ -448,7 +448,7 @@ inline hipError_t launch_tlwe_keyswitch(const uint64_t *ksk, uint64_t *out, size
   static const int small_max = getenv("MOSFHET_KS_SMALL_MAX") ? atoi(getenv("MOSFHET_KS_SMALL_MAX")) : 16;
   if (count <= small_max)
     return launch_tlwe_keyswitch_small(ksk, out, out_stride, in, in_stride, count, n_in, row, b_word, t, base_bit, ws, s, compressed, seed, mask_words);
-  // digit sets of at most 15 candidates: output words on the lanes, wave-uniform digits (keyswitch_words_kernels.h, from 64 ciphertexts; MOSFHET_HIP_KS_WORDS / mosfhet_hip_set_ks_words: 0 = the LDS-gather tiles below)
+  // digit sets of at most 15 candidates: output words on the lanes, wave-uniform digits (keyswitch_words_kernels.h; MOSFHET_HIP_KS_WORDS / mosfhet_hip_set_ks_words: 0 = the LDS-gather tiles below)
   if (ks_words_applies(count, n_in, row, t, base_bit, compressed, mask_words))
     return launch_tlwe_keyswitch_words(ksk, out, out_stride, in, in_stride, count, n_in, row, b_word, t, base_bit, ws, s, compressed, seed, mask_words);
   // (up to 256 ciphertexts one 256-wide tile holds them all: the 512-wide tile's extra wavefronts would only stage rows -- +15 % on circuit bootstraps of

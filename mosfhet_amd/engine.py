@@ -740,7 +740,7 @@ def set_split_max_batch(max_batch):
 
 
 def set_ks_words(min_count):
-    """Table key switches with 2 - 4 digit bits take the word-lane kernel (keyswitch_words_kernels.h) from this many ciphertexts on (default 64, 0 = never; same bits)."""
+    """Table key switches with 2 - 4 digit bits take the word-lane kernel (keyswitch_words_kernels.h) from this many ciphertexts on (default 17, 0 = never; same bits)."""
     _check(lib().mosfhet_hip_set_ks_words(int(min_count)))
 
 

@@ -227,11 +227,11 @@ def test_word_lane_key_switch_plans_fit_the_machine(native_lib):
         for t in (1, 2, 3, 5, 6, 7, 8, 9, 11, 12, 16, 20, 30):
             if t * bb > 63:
                 continue
-            for count in (1, 63, 64, 65, 512, 513, 1024, 4096, 9000):
+            for count in (1, 16, 17, 64, 65, 512, 513, 1024, 4096, 9000):
                 for n_in, row in ((1, 2), (7, 17), (585, 1025), (1024, 586), (2048, 633), (2048, 4096), (4097, 8192)):
                     assert lib.mosfhet_hip_ks_words_plan(count, n_in, row, t, bb, 0, plan) == 0
                     taken, jb, chunks, pf, lds, wgs, groups, splits = list(plan)
-                    assert taken == (1 if (2 <= bb <= 4 and count >= 64) else 0), (bb, t, count, n_in, row)
+                    assert taken == (1 if (2 <= bb <= 4 and count >= 17) else 0), (bb, t, count, n_in, row)
                     if not 2 <= bb <= 4:
                         continue
                     cands = (1 << bb) - 1
@@ -239,6 +239,7 @@ def test_word_lane_key_switch_plans_fit_the_machine(native_lib):
                     assert 1 <= pf <= min(jb, 8) and 16 * pf >= jb * cands, (bb, t, jb, pf)
                     assert lds == 3 * 16 * pf * 512 + 16 + 8192 and lds <= 160 * 1024, (bb, t, lds)
                     assert wgs % 8 == 0 and wgs >= groups * splits and 1 <= splits <= max(1, n_in // 8), (wgs, groups, splits, n_in)
+                    assert splits == 1 or wgs <= 256 + 8 * groups, (wgs, groups, splits)      # one round of the chip (the grid is padded to a multiple of 8 per group)
                     assert groups == -(-(-(-min(count, 8192) // 64)) // 8)
                     seen += 1
     assert seen > 1000

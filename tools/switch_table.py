@@ -45,7 +45,7 @@ SWITCHES = {
     "MOSFHET_HIP_UNFOLD_BUDGET_GIB": ("2", "device memory the selectors-first form may take for its per-ciphertext selectors", "-", "`test_unfolded_bootstraps_full_size_lvl2`"),
     "MOSFHET_KS_SMALL_MAX": ("16", "table key switches: up to this many ciphertexts take the direct (row-gather) kernels instead of the tiled one; 0 = never", "-",
                              "`test_keyswitch_ragged_batches` (sizes on both sides of it)"),
-    "MOSFHET_HIP_KS_WORDS": ("64", "table key switches with 2 - 4 digit bits: from this many ciphertexts on the word-lane kernel (`table_ks_words_kernel`: output words on the lanes, "
+    "MOSFHET_HIP_KS_WORDS": ("17", "table key switches with 2 - 4 digit bits: from this many ciphertexts on the word-lane kernel (`table_ks_words_kernel`: output words on the lanes, "
                              "wave-uniform digits, no LDS gather) instead of the ciphertext-lane tiles; 0 = never", "`mosfhet_hip_set_ks_words`",
                              "fixture `ks_form` (the key-switch parity tests run with both forms)"),
     "MOSFHET_HIP_NO_PEER": ("unset", "key replication between contexts: 1 = skip peer access, 2 = go through the pinned host buffer even on one device (test switch)", "-",
