@@ -69,9 +69,11 @@ static int run_case(int count, int n_in, int row, int b_word, int t, int bb, int
     else
       CHECK(launch_tlwe_keyswitch_nw<KS_NW>(ksk, out_a, row, in, in_words, count, n_in, row, b_word, t, bb, wa, s, compressed, seed, mask_words));
   };
+  auto direct = [&]() { CHECK(launch_tlwe_keyswitch_small(ksk, out_a, row, in, in_words, count, n_in, row, b_word, t, bb, wa, s, compressed, seed, mask_words)); };
   auto words = [&]() { CHECK(launch_tlwe_keyswitch_words(ksk, out_b, row, in, in_words, count, n_in, row, b_word, t, bb, wb, s, compressed, seed, mask_words)); };
   const int reps = (size_t)count * n_in * t * row > (1ull << 34) ? 5 : 20;
-  const float ms_a = time_ms(s, reps, tiles), ms_b = time_ms(s, reps, words);
+  const bool use_direct = getenv("KSW_AB_DIRECT") != nullptr;      // compare with the direct (row-gather) kernels of <= 16 ciphertexts instead of the tiles
+  const float ms_a = use_direct ? time_ms(s, reps, direct) : time_ms(s, reps, tiles), ms_b = time_ms(s, reps, words);
   std::vector<uint64_t> a((size_t)count * row), b((size_t)count * row);
   CHECK(hipMemcpy(a.data(), out_a, a.size() * 8, hipMemcpyDeviceToHost));
   CHECK(hipMemcpy(b.data(), out_b, b.size() * 8, hipMemcpyDeviceToHost));
